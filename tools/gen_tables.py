@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Regenerate the ADX/HCA constant tables from their defining formulas (tools/gen_tables.py).
+
+Writes the same generated header to pycricodecs_amd/csrc/cri_tables.h (product) and oracle/cri_tables.h
+(test-only CPU restatement) -- two copies so that nothing on the product path includes anything under oracle/.
+
+Every table is rebuilt from a rule (CRC polynomial, 2^(53/128) scale ladders, truncated-binary prefix
+codebooks, DCT-IV twiddle angles, ...).  Three tables have no closed form and are carried as compact data:
+the ATH base curve (run-length pairs), the curve->resolution staircase (run-length pairs) and the 128-tap
+synthesis window (float bit patterns).  When the reference is mounted (this container only) the script asks
+oracle/_ref/criref for a dump of the reference's own arrays and asserts bit-equality of every table
+(reference locations: /root/reference/CriCodecs/hca.cpp:168-185, 407-449, 1260-1287, 1513-1537, 1579-1598,
+1689-1693, 1741-1894, 2026-2204; adx.cpp:45).
+"""
+import math
+import os
+import subprocess
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+f32 = np.float32
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.int64)
+
+
+# ----------------------------------------------------------------------------------------------- rules
+def crc16_table():
+    t = []
+    for v in range(256):
+        r = v << 8
+        for _ in range(8):
+            r = ((r << 1) ^ 0x8005) & 0xFFFF if r & 0x8000 else (r << 1) & 0xFFFF
+        t.append(r)
+    return np.array(t, dtype=np.int64)
+
+
+ATH_RUNS = ("120 95 86 81 78 76 75 73 72*2 71 70*2 69*3 68*4 67*6 66*8 65*10 64*9 63*14 62*6 61*7 60*8 59*32 60*8 "
+            "61*8 62*7 63*21 64*21 65*30 66*22 67*17 68*14 69*12 70*10 71*10 72*8 73*8 74*8 75*7 76*6 77*6 78*6 79*6 "
+            "80*5 81*5 82*5 83*4 84*5 85*4 86*4 87*5 88*3 89*4 90*4 91*4 92*3 93*4 94*3 95*3 96*3 97*4 98*3 99*3 "
+            "100*3 101*2 102*3 103*3 104*3 105*2 106*3 107*3 108*2 109*3 110*2 111*2 112*3 113*2 114*2 115*3 116*2 "
+            "117*2 118*2 119*2 120*3 121*2 122*2 123*2 124*2 125*2 126*2 127*2 128*2 129*2 130 131*2 132*2 133*2 "
+            "134*2 135 136*2 137*2 138*2 139 140*2 141*2 142 143*2 144*2 145 146*2 147 148*2 149*2 150 151*2 152 "
+            "153*2 154 155*2 156 157*2 158 159 160*2 161 162*2 163 164 165*2 166 167*2 168 169 170*2 171 172 173 "
+            "174*2 175 176 177*2 178 179 180 181 182*2 183 184 185 186*2 187 188 189 190 191 192 193*2 194 195 196 "
+            "197 198 199 200 201*2 202 203 204 205 206 207 208 209 210 211 212 213 214 215 216 217 218 219 220 221 "
+            "222 223 224 225 226 227 228 229 230 231 232 233 234 235 237 238 239 240 241 242 243 244 245 247 248 249 "
+            "250 251 252 253 255*2")
+CURVE_RUNS = "14*6 13*6 12*6 11*6 10*7 9*6 8*6 7 6*2 5 4*3 3*3 2*4 1*9"   # curve position 0..65 -> resolution
+
+WINDOW_HEX = """
+3A3504F0 3B0183B8 3B70C538 3BBB9268 3C04A809 3C308200 3C61284C 3C8B3F17 3CA83992 3CC77FBD 3CE91110 3D0677CD
+3D198FC4 3D2DD35C 3D434643 3D59ECC1 3D71CBA8 3D85741E 3D92A413 3DA078B4 3DAEF522 3DBE1C9E 3DCDF27B 3DDE7A1D
+3DEFB6ED 3E00D62B 3E0A2EDA 3E13E72A 3E1E00B1 3E287CF2 3E335D55 3E3EA321 3E4A4F75 3E56633F 3E62DF37 3E6FC3D1
+3E7D1138 3E8563A2 3E8C72B7 3E93B561 3E9B2AEF 3EA2D26F 3EAAAAAB 3EB2B222 3EBAE706 3EC34737 3ECBD03D 3ED47F46
+3EDD5128 3EE6425C 3EEF4EFF 3EF872D7 3F00D4A9 3F0576CA 3F0A1D3B 3F0EC548 3F136C25 3F180EF2 3F1CAAC2 3F213CA2
+3F25C1A5 3F2A36E7 3F2E9998 3F32E705 3F371C9E 3F3B37FE 3F3F36F2 3F431780 3F46D7E6 3F4A76A4 3F4DF27C 3F514A6F
+3F547DC5 3F578C03 3F5A74EE 3F5D3887 3F5FD707 3F6250DA 3F64A699 3F66D908 3F68E90E 3F6AD7B1 3F6CA611 3F6E5562
+3F6FE6E7 3F715BEF 3F72B5D1 3F73F5E6 3F751D89 3F762E13 3F7728D7 3F780F20 3F78E234 3F79A34C 3F7A5397 3F7AF439
+3F7B8648 3F7C0ACE 3F7C82C8 3F7CEF26 3F7D50CB 3F7DA88E 3F7DF737 3F7E3D86 3F7E7C2A 3F7EB3CC 3F7EE507 3F7F106C
+3F7F3683 3F7F57CA 3F7F74B6 3F7F8DB6 3F7FA32E 3F7FB57B 3F7FC4F6 3F7FD1ED 3F7FDCAD 3F7FE579 3F7FEC90 3F7FF22E
+3F7FF688 3F7FF9D0 3F7FFC32 3F7FFDDA 3F7FFEED 3F7FFF8F 3F7FFFDF 3F7FFFFC
+"""  # |w[i]|; the stored synthesis window carries a minus sign on taps 64..127
+
+
+def runs(s):
+    out = []
+    for tok in s.split():
+        v, _, n = tok.partition("*")
+        out += [int(v)] * (int(n) if n else 1)
+    return np.array(out, dtype=np.int64)
+
+
+MAX_BITS = np.array([0, 2, 3, 3, 4, 4, 4, 4, 5, 6, 7, 8, 9, 10, 11, 12], dtype=np.int64)
+
+
+def prefix_codebooks():
+    """Truncated-binary prefix codes for resolutions 1..7 over the alphabet 0,+1,-1,...,+r,-r.
+    Returned as decode tables indexed by (res<<4)|peeked_bits: code length and value."""
+    length = np.zeros(128, dtype=np.int64)
+    value = np.zeros(128, dtype=np.int64)
+    for r in range(1, 8):
+        L = int(MAX_BITS[r])
+        alphabet = [0]
+        for m in range(1, r + 1):
+            alphabet += [m, -m]
+        nshort = (1 << L) - len(alphabet)
+        idx = r << 4
+        for j, v in enumerate(alphabet):
+            span, ln = (2, L - 1) if j < nshort else (1, L)
+            for _ in range(span):
+                length[idx] = ln
+                value[idx] = v
+                idx += 1
+    return length, value
+
+
+def encoder_codebooks(dec_len, dec_val):
+    """Invert the decode tables: for res 1..7 and value -8..7 (biased by 8) -> (code, bits)."""
+    ebits = np.zeros((8, 16), dtype=np.int64)
+    ecode = np.zeros((8, 16), dtype=np.int64)
+    for r in range(1, 8):
+        L = int(MAX_BITS[r])
+        for v in range(-r, r + 1):
+            first = next(i for i in range(16) if dec_len[(r << 4) + i] and dec_val[(r << 4) + i] == v)
+            ln = int(dec_len[(r << 4) + first])
+            ebits[r][v + 8] = ln
+            ecode[r][v + 8] = first >> (L - ln)
+    return ebits.reshape(-1), ecode.reshape(-1)
+
+
+def build():
+    T = {}
+    T["crc16"] = ("u16", crc16_table())
+    T["ath_base_curve"] = ("u8", runs(ATH_RUNS))
+    T["invert_table"] = ("u8", runs(CURVE_RUNS))
+    step = 2.0 ** (53.0 / 128.0)
+    k = np.arange(64, dtype=np.float64)
+    T["dequant_scaling"] = ("f32", bits(f32(math.sqrt(128.0) * step ** (k - 63.0))))
+    inv_step = np.array([0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 15.5, 31.5, 63.5, 127.5, 255.5, 511.5, 1023.5, 2047.5])
+    rng = 1.0 / inv_step
+    rng[0] = 1.0
+    T["dequant_range"] = ("f32", bits(f32(rng)))
+    T["max_bit"] = ("u8", MAX_BITS)
+    dl, dv = prefix_codebooks()
+    T["read_bit"] = ("u8", dl)
+    T["read_val"] = ("i8", dv)
+    conv = step ** (np.arange(128, dtype=np.float64) - 63.0)
+    conv[0] = conv[126] = conv[127] = 0.0
+    T["scale_conversion"] = ("f32", bits(f32(conv)))
+    ir = (14.0 - np.arange(16, dtype=np.float64)) / 7.0
+    ir[14] = ir[15] = 0.0
+    T["intensity_ratio"] = ("f32", bits(f32(ir)))
+    # DCT-IV rotation stages of the decoder: stage i, t = 0..63, k = t mod 2^i, angle x = pi(2k+1)/(8*2^i);
+    # stored "sin" = cos(x), stored "cos" = -/+ sin(x) by the parity of (t >> i); stage 0 carries 1/sqrt(128).
+    dsin = np.zeros((7, 64), dtype=np.float32)
+    dcos = np.zeros((7, 64), dtype=np.float32)
+    for i in range(7):
+        n = 1 << i
+        amp = 1.0 / math.sqrt(128.0) if i == 0 else 1.0
+        for t in range(64):
+            x = math.pi * (2 * (t % n) + 1) / (8.0 * n)
+            sgn = 1.0 if bin(t >> i).count("1") & 1 else -1.0
+            dsin[i][t] = f32(math.cos(x) * amp)
+            dcos[i][t] = f32(sgn * f32(math.sin(x) * amp))
+    T["dec_sin"] = ("f32", bits(dsin.reshape(-1)))
+    T["dec_cos"] = ("f32", bits(dcos.reshape(-1)))
+    w = np.array([int(h, 16) for h in WINDOW_HEX.split()], dtype=np.int64)
+    w[64:] |= 0x80000000
+    T["imdct_window"] = ("f32", w)
+    # ---- encoder side
+    T["default_channel_mapping"] = ("u8", np.array([0, 1, 0, 4, 0, 1, 3, 7, 3], dtype=np.int64))
+    vcm = np.zeros((8, 8), dtype=np.int64)
+    for row, cols in enumerate([(1,), (0,), (1, 2, 4), (0, 3, 5), (1, 2, 7), (3,), (7,), (3,)]):
+        for c in cols:
+            vcm[row][c] = 1
+    T["valid_channel_mappings"] = ("u8", vcm.reshape(-1))
+    T["enc_max_bits"] = ("u8", MAX_BITS)
+    T["enc_inv_step"] = ("f32", bits(f32(inv_step)))
+    s2r = np.concatenate([[15], runs(CURVE_RUNS)[:58]])
+    T["enc_scale_to_res"] = ("u8", s2r)
+    eb, ec = encoder_codebooks(dl, dv)
+    T["enc_spectrum_bits"] = ("u8", eb)
+    T["enc_spectrum_value"] = ("u8", ec)
+    T["enc_intensity_bounds"] = ("f32", bits(f32((27.0 - 2.0 * np.arange(14, dtype=np.float64)) / 14.0)))
+    dz = 0.5 / inv_step
+    dz[0] = 0.0
+    T["enc_dead_zone"] = ("f32", bits(f32(dz)))
+
+    def bitrev7(v):
+        return int("{:07b}".format(v)[::-1], 2)
+    T["enc_shuffle"] = ("u8", np.array([bitrev7(i ^ (i >> 1)) for i in range(128)], dtype=np.int64))
+    qs = step ** (63.0 - k) / math.sqrt(128.0)
+    T["enc_quant_scaling"] = ("f32", bits(f32(qs)))
+    esin = np.zeros((8, 128), dtype=np.float32)
+    ecos = np.zeros((8, 128), dtype=np.float32)
+    for s in range(8):
+        size = 1 << s
+        for i in range(size):
+            v = math.pi * (4 * i + 1) / (4.0 * size)
+            esin[s][i] = f32(math.sin(v))
+            ecos[s][i] = f32(math.cos(v))
+    T["enc_sin"] = ("f32", bits(esin.reshape(-1)))
+    T["enc_cos"] = ("f32", bits(ecos.reshape(-1)))
+    T["adx_static_coefs"] = ("i16", np.array([0, 0, 0x0F00, 0, 0x1CC0, -0x0D00, 0x1880, -0x0DC0], dtype=np.int64))
+    return T
+
+
+# ------------------------------------------------------------------------------------------ verification
+def verify_against_reference(T):
+    tool = os.path.join(ROOT, "oracle", "_ref", "criref")
+    if not (os.path.exists(tool) and os.path.isdir("/root/reference")):
+        print("gen_tables: reference not available here, skipping bit-equality check")
+        return
+    dump = "/tmp/_criref_tables.txt"
+    subprocess.run([tool, "dump-tables", dump], check=True)
+    ref = {}
+    for line in open(dump):
+        p = line.split()
+        ref[p[0]] = np.array(p[3:], dtype=np.int64)
+    bad = 0
+    for name, (kind, arr) in T.items():
+        r = ref[name]
+        a = np.asarray(arr, dtype=np.int64)
+        if kind == "i8" and name == "read_val":      # reference stores these as floats
+            r = np.array(r, dtype=np.uint32).view(np.float32).astype(np.int64)
+        if kind in ("f32", "u16", "u8"):
+            a = a & 0xFFFFFFFF
+            r = r & 0xFFFFFFFF
+        if name in ("enc_sin", "enc_cos"):           # only the first 2^s entries of each row are defined
+            m = np.zeros((8, 128), dtype=bool)
+            for s in range(8):
+                m[s, : 1 << s] = True
+            a, r = a[m.reshape(-1)], r[m.reshape(-1)]
+        if a.shape != r.shape or not np.array_equal(a, r):
+            bad += 1
+            print("MISMATCH", name, int((a != r).sum()) if a.shape == r.shape else (a.shape, r.shape))
+    if bad:
+        sys.exit("gen_tables: %d table(s) differ from the reference" % bad)
+    print("gen_tables: all %d tables bit-identical to the reference's arrays" % len(T))
+
+
+# ----------------------------------------------------------------------------------------------- emit
+CNAME = {
+    "crc16": "CRI_CRC16_TAB", "ath_base_curve": "HCA_ATH_BASE", "invert_table": "HCA_CURVE_TO_RES",
+    "dequant_scaling": "HCA_DEQ_SCALE", "dequant_range": "HCA_DEQ_RANGE", "max_bit": "HCA_MAX_BITS",
+    "read_bit": "HCA_CODE_LEN", "read_val": "HCA_CODE_VAL", "scale_conversion": "HCA_SCALE_CONV",
+    "intensity_ratio": "HCA_INTENSITY_RATIO", "dec_sin": "HCA_IMDCT_SIN", "dec_cos": "HCA_IMDCT_COS",
+    "imdct_window": "HCA_WINDOW", "default_channel_mapping": "HCA_DEFAULT_CHANNEL_CONFIG",
+    "valid_channel_mappings": "HCA_VALID_CHANNEL_CONFIG", "enc_inv_step": "HCA_ENC_INV_STEP",
+    "enc_scale_to_res": "HCA_ENC_CURVE_TO_RES", "enc_spectrum_bits": "HCA_ENC_CODE_LEN",
+    "enc_spectrum_value": "HCA_ENC_CODE", "enc_intensity_bounds": "HCA_ENC_INTENSITY_BOUNDS",
+    "enc_dead_zone": "HCA_ENC_DEAD_ZONE", "enc_shuffle": "HCA_ENC_SHUFFLE", "enc_quant_scaling": "HCA_ENC_SCALE",
+    "enc_sin": "HCA_ENC_SIN", "enc_cos": "HCA_ENC_COS", "adx_static_coefs": "ADX_STATIC_COEFS",
+}
+CTYPE = {"u8": "uint8_t", "i8": "int8_t", "u16": "uint16_t", "i16": "int16_t", "f32": "float"}
+SHAPE = {"dec_sin": (7, 64), "dec_cos": (7, 64), "enc_sin": (8, 128), "enc_cos": (8, 128),
+         "valid_channel_mappings": (8, 8), "enc_spectrum_bits": (8, 16), "enc_spectrum_value": (8, 16)}
+
+
+def fmt(kind, v):
+    if kind == "f32":
+        x = float(np.array([v & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+        return "0.0f" if x == 0.0 else x.hex() + "f"
+    return str(int(v))
+
+
+def emit(T):
+    out = ["/* cri_tables.h -- GENERATED by tools/gen_tables.py; do not edit.",
+           " * Constant tables of the ADX / HCA formats, rebuilt from their defining rules and checked bit-for-bit",
+           " * against the reference's arrays (see the generator's docstring for reference locations).",
+           " * Float tables are exact C99 hex-float literals of the binary32 values. */",
+           "#ifndef CRI_TABLES_H", "#define CRI_TABLES_H", "#include <stdint.h>",
+           "#ifndef CRI_TABLE_QUAL", "#define CRI_TABLE_QUAL static const", "#endif", ""]
+    for name, (kind, arr) in T.items():
+        if name == "enc_max_bits":
+            continue
+        a = [fmt(kind, v) for v in np.asarray(arr, dtype=np.int64)]
+        shp = SHAPE.get(name, (len(a),))
+        dims = "".join("[%d]" % d for d in shp)
+        out.append("CRI_TABLE_QUAL %s %s%s = {" % (CTYPE[kind], CNAME[name], dims))
+        per = 8 if kind == "f32" else 16
+        for i in range(0, len(a), per):
+            out.append("    " + ", ".join(a[i:i + per]) + ",")
+        out.append("};")
+        out.append("")
+    out.append("#endif /* CRI_TABLES_H */")
+    return "\n".join(out) + "\n"
+
+
+def main():
+    T = build()
+    verify_against_reference(T)
+    text = emit(T)
+    for rel in ("pycricodecs_amd/csrc/cri_tables.h", "oracle/cri_tables.h"):
+        with open(os.path.join(ROOT, rel), "w") as f:
+            f.write(text)
+        print("wrote", rel)
+
+
+if __name__ == "__main__":
+    main()
