@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/* from the REAL reference (oracle/_ref/criref built from /root/reference).
+Run in the build container only:  python tests/golden/make_golden.py
+Writes small binary fixtures (inputs and the reference's outputs) plus manifest.json (sha256 of every
+reference output, including the ones too large to commit)."""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import hca_forge  # noqa: E402
+import ref_tool as R  # noqa: E402
+from pycricodecs_amd import synth  # noqa: E402
+
+KEY = 0xCF222F1FE0748978
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def main():
+    assert R.available(), "build oracle/_ref/criref first (make -C oracle ref)"
+    man = {"key": hex(KEY), "cases": []}
+
+    def put(name, data):
+        with open(os.path.join(HERE, name), "wb") as f:
+            f.write(data)
+
+    wavs = [("s0_3008_2_48000", (0, 3008, 2, 48000)), ("s1_2048_1_44100", (1, 2048, 1, 44100)),
+            ("s2_1600_2_22050", (2, 1600, 2, 22050))]
+    for tag, (seed, n, ch, sr) in wavs:
+        w = synth.wav(seed, n, ch, sr)
+        put(tag + ".wav", w)
+        case = {"wav": tag + ".wav", "wav_sha": sha(w), "adx": [], "hca": []}
+        for (bd, bs, mode, filt, ver) in [(4, 18, 3, 0, 4), (4, 18, 4, 0, 4), (4, 18, 2, 0, 3), (8, 18, 3, 0, 5), (2, 10, 3, 0, 4)]:
+            adx = R.adx_encode(w, bd, bs, mode, 500, filt, ver)
+            dec = R.adx_decode(adx)
+            name = "%s_bd%d_bs%d_m%d_v%d.adx" % (tag, bd, bs, mode, ver)
+            put(name, adx)
+            case["adx"].append({"file": name, "params": [bd, bs, mode, 500, filt, ver], "sha": sha(adx), "decoded_sha": sha(dec)})
+        for q in (0, 1, 2, 3):
+            hca = R.hca_encode(w, q)
+            name = "%s_q%d.hca" % (tag, q)
+            put(name, hca)
+            enc = R.hca_crypt(hca, 1, 56, KEY)
+            enc1 = R.hca_crypt(hca, 1, 1, 0)
+            ent = {"file": name, "quality": q, "sha": sha(hca), "decoded_sha": sha(R.hca_decode(hca)),
+                   "float_sha": sha(R.hca_decode_float(hca).tobytes()),
+                   "enc56_sha": sha(enc), "enc56_decoded_sha": sha(R.hca_decode(enc, KEY)),
+                   "enc56_sub_sha": sha(R.hca_crypt(hca, 1, 56, 0x1234567, 0x4321)),
+                   "enc1_sha": sha(enc1), "dec_of_enc56_sha": sha(R.hca_crypt(enc, 0, 0, KEY))}
+            case["hca"].append(ent)
+        man["cases"].append(case)
+    # one fully stored decode pair (WAV out) so a byte diff can be inspected without the reference
+    w = synth.wav(0, 3008, 2, 48000)
+    put("s0_3008_2_48000_q1.decoded.wav", R.hca_decode(R.hca_encode(w, 1)))
+    put("s0_3008_2_48000_bd4_bs18_m3_v4.decoded.wav", R.adx_decode(R.adx_encode(w)))
+    # forged streams: v3.0 noise fill, v1.x ATH, random frames
+    forged = []
+    base = {q: R.hca_encode(synth.wav(5, 2500, 2, 48000), q) for q in (1, 2)}
+    for q in (1, 2):
+        for tag, f in (("v3min0", hca_forge.forge_v3(base[q], 0)), ("v101", hca_forge.forge_v1(base[q], 0x0101))):
+            name = "forged_q%d_%s.hca" % (q, tag)
+            put(name, f)
+            forged.append({"file": name, "float_sha": sha(R.hca_decode_float(f).tobytes()), "decoded_sha": sha(R.hca_decode(f))})
+    one = R.hca_encode(synth.wav(0, 800, 2, 48000), 2)
+    kept = 0
+    for v3 in (False, True):
+        b = hca_forge.forge_v3(one, 0) if v3 else one
+        for seed in range(40):
+            f = hca_forge.random_frames(b, seed, density=1.0 if seed % 2 else 0.35)
+            try:
+                fl = R.hca_decode_float(f)
+            except R.RefError:
+                continue
+            name = "fuzz_%s_%02d.hca" % ("v3" if v3 else "v2", seed)
+            put(name, f)
+            forged.append({"file": name, "float_sha": sha(fl.tobytes()), "decoded_sha": sha(R.hca_decode(f))})
+            kept += 1
+            if kept % 4 == 0:
+                break
+    man["forged"] = forged
+    # generator-independent known answers
+    man["known"] = {"crc16_123456789": 0xFEE8,
+                    "adx_coefs": {"500,48000": [7400, -3342], "500,44100": [7334, -3283], "500,22050": [6569, -2634], "0,48000": [8192, -4096]},
+                    "cipher56_first16": "001440b36c5d81f1a893cc34e5d50b72"}
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+    print("golden: %d wav cases, %d forged" % (len(man["cases"]), len(forged)))
+
+
+if __name__ == "__main__":
+    main()

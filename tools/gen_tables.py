@@ -244,7 +244,11 @@ SHAPE = {"dec_sin": (7, 64), "dec_cos": (7, 64), "enc_sin": (8, 128), "enc_cos":
 def fmt(kind, v):
     if kind == "f32":
         x = float(np.array([v & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
-        return "0.0f" if x == 0.0 else x.hex() + "f"
+        if x == 0.0:
+            return "0.0f"
+        m, e = x.hex().split("p")
+        m = m.rstrip("0")
+        return (m + "0" if m.endswith(".") else m) + "p" + e + "f"
     return str(int(v))
 
 
@@ -263,8 +267,16 @@ def emit(T):
         dims = "".join("[%d]" % d for d in shp)
         out.append("CRI_TABLE_QUAL %s %s%s = {" % (CTYPE[kind], CNAME[name], dims))
         per = 8 if kind == "f32" else 16
-        for i in range(0, len(a), per):
-            out.append("    " + ", ".join(a[i:i + per]) + ",")
+        if len(shp) == 2:
+            for r in range(shp[0]):
+                row = a[r * shp[1]:(r + 1) * shp[1]]
+                out.append("    {")
+                for i in range(0, len(row), per):
+                    out.append("        " + ", ".join(row[i:i + per]) + ",")
+                out.append("    },")
+        else:
+            for i in range(0, len(a), per):
+                out.append("    " + ", ".join(a[i:i + per]) + ",")
         out.append("};")
         out.append("")
     out.append("#endif /* CRI_TABLES_H */")
