@@ -1,0 +1,142 @@
+/* cricodecs_hip.h -- C ABI of libcricodecs_hip.so: MI355X-native ADX / HCA encode + decode core.
+ *
+ * This is the drop-in boundary for the hot path of Youjose/PyCriCodecs: the five codec methods of the
+ * reference's CPython extension `CriCodecs` (/root/reference/CriCodecs/CriCodecs.cpp:8-17) are replaced by the
+ * five single-file entry points below; everything they compute per frame/block runs as hand-written HIP
+ * kernels for gfx950.  Plain C types only (no torch / Python types); the library links libamdhip64 only.
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * There is NO CPU fallback: every entry point that has device work returns CRI_ERR_HIP when no gfx950 device
+ * (or the HIP runtime) is available.
+ *
+ * Return codes (0 = success).  Negative codes keep the reference's own numbering per domain so that a binding
+ * can raise the identical Python exception type and message:
+ *   -1 .. -18    ADX domain        (adx.cpp:11-30; -3 maps to NotImplementedError, the rest to ValueError, adx.cpp:32-38)
+ *   -101 .. -110 WAV/PCM domain    (pcm.cpp:22-33 numbered 1..10, offset by 100; ValueError, pcm.cpp:35-38)
+ *   -201 .. -204 HCA domain        (py_codec_err(-1..-4), hca.cpp:3252-3268; ValueError)
+ *   -211 .. -216 HCA per-frame detail (HCA_ERROR_PARAMS..BITREADER, hca.cpp:64-70, offset by 210); single-file
+ *                entry points collapse them to -202 exactly as HcaDecode does (hca.cpp:3441-3444)
+ *   -301 ..      library domain (argument, memory, HIP runtime, unsupported-on-device)
+ */
+#ifndef CRICODECS_HIP_H
+#define CRICODECS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRI_OK 0
+#define CRI_ERR_ADX(n) (-(n))
+#define CRI_ERR_PCM(n) (-(100 + (n)))
+#define CRI_ERR_HCA_HEADER (-201)
+#define CRI_ERR_HCA_DECODE (-202)
+#define CRI_ERR_HCA_CHANNEL_CONFIG (-203)
+#define CRI_ERR_HCA_ENCODE (-204)
+#define CRI_ERR_HCA_FRAME(n) (-(210 + (n))) /* n = 1 params, 2 header, 3 checksum, 4 sync, 5 unpack, 6 bitreader */
+#define CRI_ERR_INVALID_ARG (-301)
+#define CRI_ERR_NOMEM (-302)
+#define CRI_ERR_HIP (-303)
+#define CRI_ERR_UNSUPPORTED (-304)
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Single-file entry points, host buffers in / host buffers out (malloc'ed; release with cri_free).
+ * One call == one call of the reference extension method named in the comment.
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* CriCodecs.AdxDecode(bytes) -> WAV bytes.  Replaces AdxDecode, adx.cpp:546-558 (ADX::Decode 380-415). */
+int cri_adx_decode(const uint8_t* adx, size_t len, uint8_t** out, size_t* out_len);
+
+/* CriCodecs.AdxEncode(wav, bitdepth, blocksize, encoding, highpass, filter, adx_version, force_no_looping).
+ * Replaces AdxEncode, adx.cpp:517-544 (ADX::Encode 416-506); argument order as parsed at adx.cpp:527. */
+int cri_adx_encode(const uint8_t* wav, size_t len, uint32_t bitdepth, uint32_t blocksize, uint32_t encoding_mode,
+                   uint32_t highpass_frequency, uint32_t filter, uint32_t adx_version, int force_no_looping,
+                   uint8_t** out, size_t* out_len);
+
+/* CriCodecs.HcaDecode(data, header_size, key, subkey) -> WAV bytes.  Replaces HcaDecode, hca.cpp:3340-3457. */
+int cri_hca_decode(const uint8_t* hca, size_t len, uint32_t header_size, uint64_t key, uint16_t subkey,
+                   uint8_t** out, size_t* out_len);
+
+/* CriCodecs.HcaEncode(wav, force_nolooping, quality) -> HCA bytes.  Replaces HcaEncode, hca.cpp:3459-3489.
+ * quality: 0 Highest, 1 High, 2 Middle, 3 Low, 4 Lowest; any other value behaves as High (chunk.py:73 passes 5). */
+int cri_hca_encode(const uint8_t* wav, size_t len, uint32_t force_no_looping, uint32_t quality,
+                   uint8_t** out, size_t* out_len);
+
+/* CriCodecs.HcaCrypt(buf, crypt, header_size, type, key, subkey): whole-file en/decrypt IN PLACE on `hca`
+ * (the binding copies first and returns new bytes).  Replaces HcaCrypt, hca.cpp:3271-3337.
+ * encrypt: 1 = encrypt with `type` (56 or 1), 0 = decrypt (type ignored). */
+int cri_hca_crypt(uint8_t* hca, size_t len, uint32_t encrypt, uint32_t header_size, uint32_t type,
+                  uint64_t key, uint16_t subkey);
+
+void cri_free(void* p);
+
+/* Message for a return code: the reference's own strings for the ADX / PCM / HCA domains
+ * (adx.cpp:11-30, pcm.cpp:22-33, hca.cpp:3255-3264). */
+const char* cri_strerror(int code);
+
+/* 1 when a gfx950 device is usable, 0 otherwise. */
+int cri_device_available(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Batch jobs, device resident.  A job is built on the host from the items' headers only, then run any number
+ * of times on device buffers (inputs already in HBM, outputs stay in HBM); nothing in cri_job_run allocates
+ * or synchronises, so it can be captured in a hipGraph.
+ *
+ * Items are described AFS2-style: one blob + offsets[n+1]; item i = blob[offsets[i], offsets[i+1]).
+ * The device input handed to cri_job_run must be a byte-identical copy of that blob.
+ * Output: one blob, item i at [out_offsets[i], out_offsets[i+1]) -- exactly the bytes the single-file call
+ * would return (WAV incl. header for decodes, ADX / HCA files for encodes, the rewritten HCA for crypt).
+ * Items whose header is rejected on the host get their reference error code in host_status and zero output.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct cri_job cri_job;
+
+enum { CRI_JOB_ADX_DECODE = 1, CRI_JOB_ADX_ENCODE = 2, CRI_JOB_HCA_DECODE = 3, CRI_JOB_HCA_ENCODE = 4, CRI_JOB_HCA_CRYPT = 5 };
+
+typedef struct cri_adx_encode_params {
+    uint32_t bitdepth, blocksize, encoding_mode, highpass_frequency, filter, adx_version, force_no_looping;
+} cri_adx_encode_params;
+
+/* keys / subkeys: per-item arrays, or NULL for all-zero. */
+int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
+                              const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
+int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** job);
+int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
+                              const cri_adx_encode_params* params /* one for all items */, cri_job** job);
+int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
+                              uint32_t force_no_looping, uint32_t quality, cri_job** job);
+int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,
+                             const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
+
+uint32_t cri_job_kind(const cri_job* job);
+uint32_t cri_job_items(const cri_job* job);
+uint64_t cri_job_input_bytes(const cri_job* job);
+uint64_t cri_job_output_bytes(const cri_job* job);
+const uint64_t* cri_job_output_offsets(const cri_job* job); /* n+1 entries */
+const int32_t* cri_job_host_status(const cri_job* job);     /* n entries, header-stage result per item */
+uint64_t cri_job_scratch_bytes(const cri_job* job);         /* device scratch the run needs (may be 0) */
+/* Work units of the job in the metric's unit: HCA frames (1024 samples x all channels) or ADX frames
+ * (one block per channel); cri_job_units2 = ADX blocks (0 for HCA jobs). */
+uint64_t cri_job_units(const cri_job* job);
+uint64_t cri_job_units2(const cri_job* job);
+/* Algorithmic bytes one run moves (compressed bytes + PCM bytes of the units, headers excluded): the
+ * numerator of the roofline figure. */
+uint64_t cri_job_algorithmic_bytes(const cri_job* job);
+
+/* Enqueue the job on `hip_stream` (a hipStream_t, NULL = default stream).  d_status: int32[n] on the device,
+ * receives 0 or the first failing frame's code per item (may be NULL).  d_scratch: cri_job_scratch_bytes()
+ * bytes (may be NULL when 0). */
+int cri_job_run(cri_job* job, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, void* hip_stream);
+
+/* Name and launch count of the job's dominant kernel (for profiling cross-checks). */
+const char* cri_job_dominant_kernel(const cri_job* job);
+
+void cri_job_destroy(cri_job* job);
+
+/* Host-buffer convenience wrapper over a job: upload, run, download.  out_blob/out_offsets are malloc'ed
+ * (cri_free); status[n] is caller-provided.  kind-specific arguments are passed through `job`. */
+int cri_job_run_host(cri_job* job, const uint8_t* blob, uint8_t** out_blob, int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRICODECS_HIP_H */

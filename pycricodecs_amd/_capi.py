@@ -1,0 +1,104 @@
+"""ctypes binding of lib/libcricodecs_hip.so (C ABI: include/cricodecs_hip.h).
+
+The library is the only implementation of the codec work; if it is missing or no gfx950 device is present the
+calls fail loudly (CriCodecsError / OSError) -- there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+try:  # load torch's bundled HIP runtime first so both sides share one libamdhip64 (same soname)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libcricodecs_hip.so")
+
+SYMBOLS = [
+    "cri_adx_decode", "cri_adx_encode", "cri_hca_decode", "cri_hca_encode", "cri_hca_crypt", "cri_free", "cri_strerror",
+    "cri_device_available", "cri_job_create_hca_decode", "cri_job_create_adx_decode", "cri_job_create_adx_encode",
+    "cri_job_create_hca_encode", "cri_job_create_hca_crypt", "cri_job_kind", "cri_job_items", "cri_job_input_bytes",
+    "cri_job_output_bytes", "cri_job_output_offsets", "cri_job_host_status", "cri_job_scratch_bytes", "cri_job_units",
+    "cri_job_units2", "cri_job_algorithmic_bytes", "cri_job_run", "cri_job_dominant_kernel", "cri_job_destroy", "cri_job_run_host",
+]
+
+
+class AdxEncodeParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("bitdepth", "blocksize", "encoding_mode", "highpass_frequency", "filter",
+                                           "adx_version", "force_no_looping")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s not built: run `python -m pycricodecs_amd.build` (hipcc, gfx950)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    u8p, u64p, i32p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)
+    vp = C.c_void_p
+    L.cri_adx_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(u8p), szp]
+    L.cri_adx_encode.argtypes = [C.c_char_p, C.c_size_t] + [C.c_uint32] * 6 + [C.c_int, C.POINTER(u8p), szp]
+    L.cri_hca_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint16, C.POINTER(u8p), szp]
+    L.cri_hca_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(u8p), szp]
+    L.cri_hca_crypt.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint16]
+    L.cri_free.argtypes = [vp]
+    L.cri_free.restype = None
+    L.cri_strerror.argtypes = [C.c_int]
+    L.cri_strerror.restype = C.c_char_p
+    L.cri_job_create_hca_decode.argtypes = [vp, u64p, C.c_uint32, u64p, C.POINTER(C.c_uint16), C.POINTER(vp)]
+    L.cri_job_create_adx_decode.argtypes = [vp, u64p, C.c_uint32, C.POINTER(vp)]
+    L.cri_job_create_adx_encode.argtypes = [vp, u64p, C.c_uint32, C.POINTER(AdxEncodeParams), C.POINTER(vp)]
+    L.cri_job_create_hca_encode.argtypes = [vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.cri_job_create_hca_crypt.argtypes = [vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.POINTER(C.c_uint16), C.POINTER(vp)]
+    for name in ("cri_job_kind", "cri_job_items"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_uint32
+    for name in ("cri_job_input_bytes", "cri_job_output_bytes", "cri_job_scratch_bytes", "cri_job_units", "cri_job_units2",
+                 "cri_job_algorithmic_bytes"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_uint64
+    L.cri_job_output_offsets.argtypes = [vp]
+    L.cri_job_output_offsets.restype = u64p
+    L.cri_job_host_status.argtypes = [vp]
+    L.cri_job_host_status.restype = i32p
+    L.cri_job_dominant_kernel.argtypes = [vp]
+    L.cri_job_dominant_kernel.restype = C.c_char_p
+    L.cri_job_run.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.cri_job_run_host.argtypes = [vp, vp, C.POINTER(u8p), i32p]
+    L.cri_job_destroy.argtypes = [vp]
+    L.cri_job_destroy.restype = None
+    _lib = L
+    return L
+
+
+class CriCodecsError(Exception):
+    """Library-domain failure (no device, HIP error, unsupported-on-device input)."""
+    def __init__(self, code):
+        self.code = code
+        super().__init__("%s (code %d)" % (strerror(code), code))
+
+
+def strerror(code):
+    return lib().cri_strerror(code).decode()
+
+
+def raise_for(code):
+    """Map a return code to the exception type + message the reference extension raises
+    (adx.cpp:32-38, pcm.cpp:35-38, hca.cpp:3252-3268)."""
+    if code == 0:
+        return
+    if code == -3:
+        raise NotImplementedError(strerror(code))
+    if -18 <= code <= -1 or -110 <= code <= -101 or -216 <= code <= -201:
+        raise ValueError(strerror(code))
+    raise CriCodecsError(code)
+
+
+def take(out, n):
+    data = C.string_at(out, n.value)
+    lib().cri_free(out)
+    return data

@@ -1,0 +1,171 @@
+"""Batch jobs on device-resident buffers (AFS2-style blob + offsets), the path bench.py measures.
+
+PyTorch is used only as the owner of device memory and streams; pointers are handed to the C ABI as integers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+KIND_NAMES = {1: "adx_decode", 2: "adx_encode", 3: "hca_decode", 4: "hca_encode", 5: "hca_crypt"}
+
+
+def pack(items):
+    """list of bytes -> (blob bytes, offsets uint64[n+1])."""
+    offs = np.zeros(len(items) + 1, dtype=np.uint64)
+    if items:
+        offs[1:] = np.cumsum([len(b) for b in items], dtype=np.uint64)
+    return b"".join(items), offs
+
+
+class Job:
+    """Owns a cri_job.  Create with one of the classmethods; `run()` enqueues it on torch's current stream."""
+
+    def __init__(self, handle, blob, offsets):
+        self._h = handle
+        self.blob, self.offsets = blob, offsets
+        L = _capi.lib()
+        self.n = L.cri_job_items(handle)
+        self.kind = KIND_NAMES[L.cri_job_kind(handle)]
+        self.input_bytes = L.cri_job_input_bytes(handle)
+        self.output_bytes = L.cri_job_output_bytes(handle)
+        self.scratch_bytes = L.cri_job_scratch_bytes(handle)
+        self.units = L.cri_job_units(handle)
+        self.units2 = L.cri_job_units2(handle)
+        self.algorithmic_bytes = L.cri_job_algorithmic_bytes(handle)
+        self.dominant_kernel = L.cri_job_dominant_kernel(handle).decode()
+        self.output_offsets = np.ctypeslib.as_array(L.cri_job_output_offsets(handle), shape=(self.n + 1,)).copy()
+        self.host_status = np.ctypeslib.as_array(L.cri_job_host_status(handle), shape=(max(self.n, 1),)).copy()[:self.n]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _capi.lib().cri_job_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- constructors
+    @staticmethod
+    def _blob_args(items):
+        blob, offs = pack(items)
+        buf = C.create_string_buffer(blob, len(blob)) if blob else C.create_string_buffer(1)
+        return blob, offs, buf
+
+    @classmethod
+    def _finish(cls, rc, h, blob, offs):
+        if rc:
+            _capi.raise_for(rc)
+        return cls(h, blob, offs)
+
+    @classmethod
+    def hca_decode(cls, items, keys=None, subkeys=None):
+        blob, offs, buf = cls._blob_args(items)
+        k = None if keys is None else (C.c_uint64 * len(items))(*[x & 0xFFFFFFFFFFFFFFFF for x in keys])
+        s = None if subkeys is None else (C.c_uint16 * len(items))(*subkeys)
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_hca_decode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), k, s, C.byref(h))
+        return cls._finish(rc, h, blob, offs)
+
+    @classmethod
+    def adx_decode(cls, items):
+        blob, offs, buf = cls._blob_args(items)
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_adx_decode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), C.byref(h))
+        return cls._finish(rc, h, blob, offs)
+
+    @classmethod
+    def adx_encode(cls, items, bitdepth=4, blocksize=18, mode=3, highpass=500, filt=0, version=4, force_no_loop=False):
+        blob, offs, buf = cls._blob_args(items)
+        p = _capi.AdxEncodeParams(bitdepth, blocksize, mode, highpass, filt, version, int(force_no_loop))
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_adx_encode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), C.byref(p), C.byref(h))
+        return cls._finish(rc, h, blob, offs)
+
+    @classmethod
+    def hca_encode(cls, items, quality=1, force_no_loop=False):
+        blob, offs, buf = cls._blob_args(items)
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_hca_encode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), int(force_no_loop), quality, C.byref(h))
+        return cls._finish(rc, h, blob, offs)
+
+    @classmethod
+    def hca_crypt(cls, items, encrypt, ctype, keys=None, subkeys=None):
+        blob, offs, buf = cls._blob_args(items)
+        k = None if keys is None else (C.c_uint64 * len(items))(*[x & 0xFFFFFFFFFFFFFFFF for x in keys])
+        s = None if subkeys is None else (C.c_uint16 * len(items))(*subkeys)
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_hca_crypt(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), int(encrypt), ctype, k, s, C.byref(h))
+        return cls._finish(rc, h, blob, offs)
+
+    # ---- device execution (torch tensors are only buffers here)
+    def alloc(self, device="cuda:0", upload=True):
+        import torch
+        d_in = torch.empty(max(self.input_bytes, 1), dtype=torch.uint8, device=device)
+        if upload and self.input_bytes:
+            d_in[:self.input_bytes].copy_(torch.frombuffer(bytearray(self.blob), dtype=torch.uint8))
+        d_out = torch.zeros(max(self.output_bytes, 1), dtype=torch.uint8, device=device)
+        d_scratch = torch.empty(max(self.scratch_bytes, 1), dtype=torch.uint8, device=device)
+        d_status = torch.zeros(max(self.n, 1), dtype=torch.int32, device=device)
+        return d_in, d_out, d_scratch, d_status
+
+    def run(self, d_in, d_out, d_scratch, d_status, stream=None):
+        import torch
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        rc = _capi.lib().cri_job_run(self._h, d_in.data_ptr(), d_out.data_ptr(), d_scratch.data_ptr(),
+                                     d_status.data_ptr() if d_status is not None else None, st)
+        if rc:
+            _capi.raise_for(rc)
+
+    def run_host(self):
+        """Upload, run, download: returns (list of output bytes per item, status int32[n])."""
+        out = C.POINTER(C.c_uint8)()
+        status = (C.c_int32 * max(self.n, 1))()
+        buf = C.create_string_buffer(self.blob, len(self.blob)) if self.blob else C.create_string_buffer(1)
+        rc = _capi.lib().cri_job_run_host(self._h, buf, C.byref(out), status)
+        if rc:
+            _capi.raise_for(rc)
+        blob = C.string_at(out, self.output_bytes)
+        _capi.lib().cri_free(out)
+        return self.split(blob), np.array(status[:self.n], dtype=np.int32)
+
+    def item_length(self, blob, i):
+        """True byte length of output item i (offsets are 64-byte aligned, so the item carries its own size)."""
+        o = int(self.output_offsets[i])
+        if self.kind in ("adx_decode", "hca_decode"):
+            return int.from_bytes(blob[o + 4:o + 8], "little") + 8 if blob[o:o + 4] == b"RIFF" else 0
+        if self.kind == "hca_crypt":
+            return int(self.offsets[i + 1] - self.offsets[i])
+        return None
+
+    def split(self, blob):
+        outs = []
+        for i in range(self.n):
+            o = int(self.output_offsets[i])
+            if self.host_status[i]:
+                outs.append(b"")
+                continue
+            n = self.item_length(blob, i)
+            if n is None:    # encoders: length is implied by the format
+                n = self._encoded_length(blob, i)
+            outs.append(blob[o:o + n])
+        return outs
+
+    def _encoded_length(self, blob, i):
+        o = int(self.output_offsets[i])
+        if self.kind == "adx_encode":
+            hs = int.from_bytes(blob[o + 2:o + 4], "big") + 4
+            bs, bd, ch = blob[o + 5], blob[o + 6], blob[o + 7]
+            e = int(self.output_offsets[i + 1])
+            # the file ends with the 80 01 trailer block; find it from the aligned end
+            k = e
+            while k - bs >= o + hs and not (blob[k - bs] == 0x80 and blob[k - bs + 1] == 0x01 and ((k - bs - o - hs) % bs) == 0):
+                k -= 1
+            return k - o
+        if self.kind == "hca_encode":
+            hs = int.from_bytes(blob[o + 6:o + 8], "big")
+            fc = int.from_bytes(blob[o + 16:o + 20], "big")
+            fs = int.from_bytes(blob[o + 28:o + 30], "big")
+            return hs + fc * fs
+        raise AssertionError

@@ -1,0 +1,50 @@
+"""Builds pycricodecs_amd/lib/libcricodecs_hip.so (the C-ABI library, include/cricodecs_hip.h) with hipcc for gfx950.
+
+    python -m pycricodecs_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is load-bearing: the reference's float work is single
+rounded multiplies/adds (x86-64 SSE2 build, no FMA), and bit-exact HCA output depends on not fusing them.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcricodecs_hip.so")
+SOURCES = ["cri_host.cpp", "cri_kernels.hip", "cri_capi.cpp"]
+HEADERS = ["cri_host.h", "cri_kernels.h", "cri_types.h", "cri_tables.h", "../../include/cricodecs_hip.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,569 @@
+// cri_capi.cpp -- job planner + the extern "C" boundary declared in include/cricodecs_hip.h.
+//
+// A job is planned on the host from the items' headers (cri_host.cpp), its small metadata (stream descriptors,
+// cipher / ATH tables, header images) is uploaded once, and cri_job_run only enqueues kernels on the caller's
+// stream.  There is no CPU implementation of the per-frame / per-block work in this library.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "../../include/cricodecs_hip.h"
+#include "cri_host.h"
+#include "cri_kernels.h"
+
+using namespace cri;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const void* src, size_t bytes) {
+        n = bytes;
+        if (!bytes) return 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return CRI_ERR_HIP; }
+        if (hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CRI_ERR_HIP;
+        return 0;
+    }
+    template <class T> int upload(const std::vector<T>& v) { return upload(v.data(), v.size() * sizeof(T)); }
+};
+
+struct Image { uint64_t dst; std::vector<uint8_t> bytes; };
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct cri_job {
+    uint32_t kind = 0, n = 0;
+    std::vector<uint64_t> in_offsets, out_offsets;
+    std::vector<int32_t> host_status;
+    uint64_t in_bytes = 0, out_bytes = 0, scratch_bytes = 0, units = 0, units2 = 0, alg_bytes = 0;
+    std::string dominant;
+    // device metadata
+    DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
+        d_frame_sizes, d_first_frame, d_adx_streams;
+    uint32_t n_images = 0;
+    std::vector<Image> images;
+    // launch plans (device pointers for in/out/scratch/status are filled at run time)
+    std::vector<HcaDecArgs> hca_dec;
+    AdxArgs adx{};
+    CryptArgs crypt{};
+    struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
+    std::vector<EncLaunch> hca_enc;
+    uint32_t n_cipher = 0;
+
+    int upload_images() {
+        std::vector<uint8_t> blob; std::vector<uint64_t> off{0}, dst;
+        for (auto& im : images) { blob.insert(blob.end(), im.bytes.begin(), im.bytes.end()); off.push_back(blob.size()); dst.push_back(im.dst); }
+        n_images = (uint32_t)images.size();
+        if (!n_images) return 0;
+        if (blob.empty()) blob.push_back(0);
+        int rc = d_img.upload(blob); if (rc) return rc;
+        rc = d_img_off.upload(off); if (rc) return rc;
+        return d_img_dst.upload(dst);
+    }
+};
+
+static bool g_dev_checked = false, g_dev_ok = false;
+extern "C" int cri_device_available(void) {
+    if (!g_dev_checked) {
+        int n = 0;
+        g_dev_ok = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+        g_dev_checked = true;
+    }
+    return g_dev_ok ? 1 : 0;
+}
+
+extern "C" void cri_free(void* p) { free(p); }
+
+extern "C" const char* cri_strerror(int code) {
+    static const char* adx[] = {                      // adx.cpp:11-30
+        "Invalid ADX file header.", "AHX file provided, unsopported.", "Encrypted ADX detected, unsupported.",
+        "Invalid/Unknown encoding mode found.", "Unknown ADX version provided.", "Invalid Bitdepth found on the provided ADX.",
+        "ADX does not contain any channels info.", "Invalid ADX header, loop information size is bigger than the header.",
+        "Inavlid ADX header, Criware copyright string not found.", "Numbers of Channel cannot exceed 255 or go below 0.",
+        "Bitdepth must be between 2 and 15 inclusive.", "Blocksize must be between 3 and 255 inclusive.",
+        "EncodingMode must be either 2, 3, or 4.", "HighpassFrequency must be between 0 and 65535 inclusive.",
+        "Filter is used with EncodingMode == 2 and must be between 0 and 4 inclusive.", "AdxVersion must be either 3, 4 or 5.",
+        "Provided Bitdepth does not fit correctly with the provided BlockSize", "Given WAVE file is not valid for ADX encoding."};
+    static const char* pcm[] = {                      // pcm.cpp:22-33
+        "Invalid WAVE file header.", "Invalid WAVE file header. Format info is not present.",
+        "Unsupported/Unknown WAVE compression mode.", "Invalid looping sample info data.",
+        "Invalid looping sample info data, Number of loops/loop data is larger than the available size.",
+        "Data tag is not present.", "Header is not valid.", "PCM Bitdepth does not match compression type.",
+        "Filesize exceeds 2GB use python to load in with buffer.", "Filesize is too low to be viable for loading."};
+    if (code == 0) return "OK";
+    if (code <= -1 && code >= -18) return adx[-code - 1];
+    if (code <= -101 && code >= -110) return pcm[-code - 101];
+    switch (code) {                                   // hca.cpp:3255-3264
+        case CRI_ERR_HCA_HEADER: return "Header decoding error, the header is not a valid HCA header.";
+        case CRI_ERR_HCA_DECODE: return "Decoding error, either an incorrect key or an unknown exception.";
+        case CRI_ERR_HCA_CHANNEL_CONFIG: return "Error setting up channel configuration.";
+        case CRI_ERR_HCA_ENCODE: return "Unknown Encoding error.";
+        case CRI_ERR_INVALID_ARG: return "Invalid argument.";
+        case CRI_ERR_NOMEM: return "Out of memory.";
+        case CRI_ERR_HIP: return "HIP runtime error or no gfx950 device available (this library has no CPU fallback).";
+        case CRI_ERR_UNSUPPORTED: return "Input is valid for the reference but not yet supported by the device path.";
+    }
+    if (code <= -211 && code >= -216) return "Decoding error, either an incorrect key or an unknown exception.";
+    return "Unknown error.";
+}
+
+// ------------------------------------------------------------------------------------------------ accessors
+extern "C" uint32_t cri_job_kind(const cri_job* j) { return j ? j->kind : 0; }
+extern "C" uint32_t cri_job_items(const cri_job* j) { return j ? j->n : 0; }
+extern "C" uint64_t cri_job_input_bytes(const cri_job* j) { return j ? j->in_bytes : 0; }
+extern "C" uint64_t cri_job_output_bytes(const cri_job* j) { return j ? j->out_bytes : 0; }
+extern "C" const uint64_t* cri_job_output_offsets(const cri_job* j) { return j ? j->out_offsets.data() : nullptr; }
+extern "C" const int32_t* cri_job_host_status(const cri_job* j) { return j ? j->host_status.data() : nullptr; }
+extern "C" uint64_t cri_job_scratch_bytes(const cri_job* j) { return j ? j->scratch_bytes : 0; }
+extern "C" uint64_t cri_job_units(const cri_job* j) { return j ? j->units : 0; }
+extern "C" uint64_t cri_job_units2(const cri_job* j) { return j ? j->units2 : 0; }
+extern "C" uint64_t cri_job_algorithmic_bytes(const cri_job* j) { return j ? j->alg_bytes : 0; }
+extern "C" const char* cri_job_dominant_kernel(const cri_job* j) { return j ? j->dominant.c_str() : ""; }
+extern "C" void cri_job_destroy(cri_job* j) { delete j; }
+
+static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
+    cri_job* j = new cri_job();
+    j->kind = kind; j->n = n;
+    j->in_offsets.assign(offsets, offsets + n + 1);
+    j->in_bytes = offsets[n];
+    j->host_status.assign(n, 0);
+    j->out_offsets.assign(n + 1, 0);
+    return j;
+}
+
+// ------------------------------------------------------------------------------------------------ HCA decode
+static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const uint64_t* keys, const uint16_t* subkeys,
+                             const uint32_t* header_sizes, cri_job** out) {
+    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    cri_job* j = new_job(CRI_JOB_HCA_DECODE, offsets, n);
+    j->dominant = "k_hca_transform";
+    std::vector<HcaFormat> formats; std::vector<HcaStream> streams;
+    std::vector<uint8_t> cipher, ath(128, 0);
+    std::map<std::vector<uint32_t>, uint32_t> fmt_index;
+    std::map<std::pair<uint32_t, uint64_t>, uint32_t> cipher_index;
+    std::map<std::vector<uint8_t>, uint32_t> ath_index;
+    ath_index[std::vector<uint8_t>(128, 0)] = 0;
+    uint64_t out_pos = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        j->out_offsets[i] = out_pos;
+        const uint8_t* d = blob + offsets[i];
+        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        HcaHeader h;
+        uint32_t hs_arg = header_sizes ? header_sizes[i] : (len >= 8 ? be16(d + 6) : 0);
+        int rc = hca_parse_header(d, len, hs_arg, h);
+        if (rc) { j->host_status[i] = rc; continue; }
+        uint64_t total = (uint64_t)h.frame_count * 1024;
+        if (total < (uint64_t)h.delay + h.padding || total > 0xFFFFFFFFull) { j->host_status[i] = CRI_ERR_HCA_HEADER; continue; }
+        uint32_t spc = (uint32_t)(total - h.delay - h.padding);
+        uint32_t frames = spc == 0 ? 0 : (uint32_t)std::min<uint64_t>(h.frame_count, ((uint64_t)h.delay + spc + 1023) / 1024);
+        if ((uint64_t)hs_arg + (uint64_t)frames * h.frame_size > len) { j->host_status[i] = CRI_ERR_HCA_DECODE; continue; }
+        if (h.min_res == 0) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // v3.0 noise fill: not on the device path yet
+        // format
+        std::vector<uint32_t> key = {h.channels, h.version, h.frame_size, h.min_res, h.max_res, h.total_bands, h.base_bands, h.stereo_bands,
+                                     h.bands_per_hfr_group, h.hfr_group_count, h.track_count, h.channel_config};
+        std::vector<uint8_t> athv(h.ath, h.ath + 128);
+        auto ai = ath_index.find(athv);
+        uint32_t aidx;
+        if (ai == ath_index.end()) { aidx = (uint32_t)(ath.size() / 128); ath.insert(ath.end(), athv.begin(), athv.end()); ath_index[athv] = aidx; } else aidx = ai->second;
+        key.push_back(aidx);
+        auto fi = fmt_index.find(key);
+        uint32_t fidx;
+        if (fi == fmt_index.end()) {
+            HcaFormat F; memset(&F, 0, sizeof F);
+            F.channels = h.channels; F.version = h.version; F.frame_size = h.frame_size; F.min_res = h.min_res; F.max_res = h.max_res;
+            F.total_bands = h.total_bands; F.base_bands = h.base_bands; F.stereo_bands = h.stereo_bands;
+            F.bands_per_hfr_group = h.bands_per_hfr_group; F.hfr_group_count = h.hfr_group_count; F.ath_index = aidx;
+            F.record_bytes = hca_record_bytes(h.channels);
+            for (uint32_t c = 0; c < 16; c++) { F.type[c] = h.type[c]; F.coded[c] = (uint8_t)h.coded[c]; }
+            fidx = (uint32_t)formats.size(); formats.push_back(F); fmt_index[key] = fidx;
+        } else fidx = fi->second;
+        // cipher
+        uint64_t mixed = hca_mix_key(keys ? keys[i] : 0, subkeys ? subkeys[i] : 0);
+        uint32_t ctype = h.ciph_type;
+        if (ctype == 56 && !mixed) ctype = 0;
+        if (ctype != 56) mixed = 0;
+        auto ck = std::make_pair(ctype, mixed);
+        auto ci = cipher_index.find(ck);
+        uint32_t cidx;
+        if (ci == cipher_index.end()) {
+            uint8_t t[256]; hca_cipher_table(ctype, mixed, t);
+            cidx = (uint32_t)(cipher.size() / 256); cipher.insert(cipher.end(), t, t + 256); cipher_index[ck] = cidx;
+        } else cidx = ci->second;
+        // output WAV
+        uint32_t ls = h.loop_start_frame * 1024 + h.loop_start_delay - h.delay;
+        uint32_t le = h.loop_end_frame * 1024 + (1024 - h.loop_end_padding) - h.delay;
+        Image im; im.dst = out_pos; im.bytes.assign(h.loop_flag ? 0x70 : 0x2C, 0);
+        uint32_t wh = wav_write_header(im.bytes.data(), h.channels, h.rate, spc, h.loop_flag != 0, ls, le);
+        j->images.push_back(std::move(im));
+        HcaStream S; memset(&S, 0, sizeof S);
+        S.src_offset = offsets[i] + hs_arg; S.dst_offset = out_pos + wh; S.format = fidx; S.cipher = cidx; S.frames = frames;
+        S.delay = h.delay; S.samples = spc; S.item = i;
+        streams.push_back(S);
+        out_pos = align_up(out_pos + wh + (uint64_t)spc * h.channels * 2, 64);
+        j->units += frames;
+        j->alg_bytes += (uint64_t)frames * (h.frame_size + 2048ull * h.channels);
+    }
+    j->out_offsets[n] = out_pos;
+    // true (unaligned) end of each item for consumers: offsets[i+1] is the aligned start of the next item, so the
+    // item length is carried by the WAV header itself (RIFF size + 8).
+    j->out_bytes = out_pos;
+    std::stable_sort(streams.begin(), streams.end(), [](const HcaStream& a, const HcaStream& b) { return a.format < b.format; });
+    uint64_t scratch = 0;
+    j->n_cipher = (uint32_t)(cipher.size() / 256);
+    for (size_t b = 0; b < streams.size();) {
+        size_t e = b; uint32_t frames = 0;
+        const HcaFormat& F = formats[streams[b].format];
+        while (e < streams.size() && streams[e].format == streams[b].format) {
+            streams[e].first_frame = frames; streams[e].scratch_offset = scratch;
+            frames += streams[e].frames; scratch += (uint64_t)streams[e].frames * F.record_bytes;
+            e++;
+        }
+        HcaDecArgs a; memset(&a, 0, sizeof a);
+        a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
+        a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
+        uint32_t fpw = 64;
+        while (fpw > 1 && hca_unpack_lds_bytes(F.frame_size, F.channels, j->n_cipher, fpw) > 80 * 1024) fpw >>= 1;
+        if (hca_unpack_lds_bytes(F.frame_size, F.channels, j->n_cipher, fpw) > 160 * 1024) {
+            for (size_t s = b; s < e; s++) j->host_status[streams[s].item] = CRI_ERR_UNSUPPORTED;
+            a.frames = 0;
+        }
+        a.fpw = fpw; a.unpack_lds = (uint32_t)hca_unpack_lds_bytes(F.frame_size, F.channels, j->n_cipher, fpw);
+        j->hca_dec.push_back(a);
+        b = e;
+    }
+    j->scratch_bytes = scratch;
+    int rc = 0;
+    if (formats.empty()) { HcaFormat F; memset(&F, 0, sizeof F); formats.push_back(F); }
+    if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
+    if (cipher.empty()) cipher.assign(256, 0);
+    if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_cipher.upload(cipher)) ||
+        (rc = j->d_ath.upload(ath)) || (rc = j->upload_images())) { delete j; return rc; }
+    *out = j;
+    return 0;
+}
+
+extern "C" int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const uint64_t* keys,
+                                         const uint16_t* subkeys, cri_job** job) {
+    return create_hca_decode(blob, offsets, n, keys, subkeys, nullptr, job);
+}
+
+// ------------------------------------------------------------------------------------------------ ADX decode
+extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out) {
+    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    cri_job* j = new_job(CRI_JOB_ADX_DECODE, offsets, n);
+    j->dominant = "k_adx_decode";
+    std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history;
+    uint64_t out_pos = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        j->out_offsets[i] = out_pos;
+        const uint8_t* d = blob + offsets[i];
+        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        AdxHeader h;
+        int rc = adx_parse_header(d, len, h);
+        if (rc) { j->host_status[i] = rc; continue; }
+        if ((uint64_t)h.sample_count * h.channels * 2 > 0x7FFFFF00ull) { j->host_status[i] = CRI_ERR_INVALID_ARG; continue; }
+        Image im; im.dst = out_pos; im.bytes.assign(h.looping ? 0x70 : 0x2C, 0);
+        uint32_t wh = wav_write_header(im.bytes.data(), h.channels, h.rate, h.sample_count, h.looping, h.loop_start, h.loop_end);
+        j->images.push_back(std::move(im));
+        AdxStream S; memset(&S, 0, sizeof S);
+        S.src_offset = offsets[i] + h.data_offset + 4; S.src_end = offsets[i + 1]; S.dst_offset = out_pos + wh;
+        if (S.src_offset > S.src_end) S.src_offset = S.src_end;
+        S.frames = h.blocks; S.channels = h.channels; S.blocksize = h.blocksize; S.bitdepth = h.bitdepth; S.mode = h.mode;
+        S.samples_per_block = h.samples_per_block; S.coef0 = h.coef[0]; S.coef1 = h.coef[1]; S.samples = h.sample_count;
+        S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
+        for (uint32_t c = 0; c < h.channels; c++) {
+            chain_stream.push_back((uint32_t)streams.size());
+            history.push_back(h.history[2 * c]); history.push_back(h.history[2 * c + 1]);
+        }
+        streams.push_back(S);
+        out_pos = align_up(out_pos + wh + (uint64_t)h.sample_count * h.channels * 2, 64);
+        j->units += h.blocks; j->units2 += (uint64_t)h.blocks * h.channels;
+        j->alg_bytes += (uint64_t)h.blocks * h.channels * (h.blocksize + 2ull * h.samples_per_block);
+    }
+    j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    j->adx.chains = (uint32_t)chain_stream.size();
+    if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
+    if (chain_stream.empty()) { chain_stream.push_back(0); history.assign(2, 0); }
+    int rc = 0;
+    if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
+        (rc = j->upload_images())) { delete j; return rc; }
+    *out = j;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ADX encode
+extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const cri_adx_encode_params* p, cri_job** out) {
+    if (!blob || !offsets || !out || !p) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    cri_job* j = new_job(CRI_JOB_ADX_ENCODE, offsets, n);
+    j->dominant = "k_adx_encode";
+    std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history; std::vector<uint8_t> stale;
+    uint64_t out_pos = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        j->out_offsets[i] = out_pos;
+        const uint8_t* d = blob + offsets[i];
+        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        WavInfo w;
+        int rc = wav_parse(d, len, w);
+        if (rc) { j->host_status[i] = rc; continue; }
+        AdxEncodePlan pl;
+        rc = adx_plan_encode(d, len, w, p->bitdepth, p->blocksize, p->encoding_mode, p->highpass_frequency, p->filter, p->adx_version,
+                             p->force_no_looping != 0, pl);
+        if (rc) { j->host_status[i] = rc; continue; }
+        if (!wav_is_pcm16(w)) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // device-side sample conversion: next
+        uint32_t bs = p->blocksize, hs = pl.header_size;
+        Image head; head.dst = out_pos; head.bytes.assign(pl.image.begin(), pl.image.begin() + std::min<size_t>(hs, pl.image.size()));
+        j->images.push_back(std::move(head));
+        Image tail; tail.dst = out_pos + hs + (uint64_t)pl.frames * pl.channels * bs; tail.bytes.assign(bs, 0);   // adx.cpp:499-502
+        { uint32_t v = (bs - 4) & 0xFFFF; uint8_t t4[4] = {0x80, 0x01, (uint8_t)(v >> 8), (uint8_t)v};
+          for (uint32_t k = 0; k < 4 && k < bs; k++) tail.bytes[k] = t4[k]; }
+        j->images.push_back(std::move(tail));
+        AdxStream S; memset(&S, 0, sizeof S);
+        S.src_offset = offsets[i] + w.data_offset; S.src_end = offsets[i + 1]; S.dst_offset = out_pos + hs;
+        S.frames = pl.frames; S.channels = pl.channels; S.blocksize = bs; S.bitdepth = p->bitdepth; S.mode = p->encoding_mode;
+        S.samples_per_block = pl.samples_per_block; S.coef0 = pl.coef[0]; S.coef1 = pl.coef[1]; S.samples = pl.samples_per_channel;
+        S.filter_bits = p->filter << 13; S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
+        if (pl.image.size() > hs) { S.stale_offset = (uint32_t)stale.size(); S.stale_len = (uint32_t)(pl.image.size() - hs);
+                                    stale.insert(stale.end(), pl.image.begin() + hs, pl.image.end()); }
+        for (uint32_t c = 0; c < pl.channels; c++) {
+            chain_stream.push_back((uint32_t)streams.size());
+            history.push_back(pl.history[2 * c]); history.push_back(pl.history[2 * c + 1]);
+        }
+        streams.push_back(S);
+        out_pos = align_up(out_pos + pl.total_size, 64);
+        j->units += pl.frames; j->units2 += (uint64_t)pl.frames * pl.channels;
+        j->alg_bytes += (uint64_t)pl.frames * pl.channels * (bs + 2ull * pl.samples_per_block);
+    }
+    j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    j->adx.chains = (uint32_t)chain_stream.size();
+    if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
+    if (chain_stream.empty()) { chain_stream.push_back(0); history.assign(2, 0); }
+    if (stale.empty()) stale.push_back(0);
+    int rc = 0;
+    if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
+        (rc = j->d_stale.upload(stale)) || (rc = j->upload_images())) { delete j; return rc; }
+    *out = j;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ HCA crypt
+static int create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type, const uint64_t* keys,
+                            const uint16_t* subkeys, const uint32_t* header_sizes, cri_job** out) {
+    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    cri_job* j = new_job(CRI_JOB_HCA_CRYPT, offsets, n);
+    j->dominant = "k_hca_crypt";
+    std::vector<HcaStream> streams; std::vector<uint32_t> frame_sizes, first_frame{0}; std::vector<uint8_t> cipher;
+    std::map<std::tuple<uint32_t, uint64_t, uint32_t>, uint32_t> cipher_index;
+    uint64_t out_pos = 0; uint32_t frames_total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        j->out_offsets[i] = out_pos;
+        const uint8_t* d = blob + offsets[i];
+        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        HcaHeader h;
+        uint32_t hs = header_sizes ? header_sizes[i] : (len >= 8 ? be16(d + 6) : 0);
+        int rc = hca_parse_header(d, len, hs, h);
+        if (rc) { j->host_status[i] = CRI_ERR_HCA_HEADER; continue; }
+        if ((uint64_t)hs + (uint64_t)h.frame_count * h.frame_size > len || hs < 8) { j->host_status[i] = CRI_ERR_HCA_HEADER; continue; }
+        uint32_t ctype = encrypt == 1 ? type : h.ciph_type;
+        uint64_t mixed = hca_mix_key(keys ? keys[i] : 0, subkeys ? subkeys[i] : 0);
+        if (ctype == 56 && !mixed) ctype = 0;
+        if (ctype != 56) mixed = 0;
+        uint8_t t[256];
+        if (hca_cipher_table(ctype, mixed, t)) { j->host_status[i] = CRI_ERR_HCA_HEADER; continue; }
+        auto ck = std::make_tuple(ctype, mixed, encrypt ? 1u : 0u);
+        auto ci = cipher_index.find(ck);
+        uint32_t cidx;
+        if (ci == cipher_index.end()) {
+            if (encrypt) { uint8_t inv[256]; for (int k = 0; k < 256; k++) inv[t[k]] = (uint8_t)k; memcpy(t, inv, 256); }   // hca.cpp:3315-3320
+            cidx = (uint32_t)(cipher.size() / 256); cipher.insert(cipher.end(), t, t + 256); cipher_index[ck] = cidx;
+        } else cidx = ci->second;
+        Image head; head.dst = out_pos; head.bytes.assign(d, d + hs);
+        hca_crypt_header(head.bytes.data(), hs, encrypt, type);
+        j->images.push_back(std::move(head));
+        uint64_t body_end = (uint64_t)hs + (uint64_t)h.frame_count * h.frame_size;
+        if (body_end < len) { Image tail; tail.dst = out_pos + body_end; tail.bytes.assign(d + body_end, d + len); j->images.push_back(std::move(tail)); }
+        HcaStream S; memset(&S, 0, sizeof S);
+        S.src_offset = offsets[i] + hs; S.dst_offset = out_pos + hs; S.cipher = cidx; S.frames = h.frame_count; S.item = i;
+        streams.push_back(S); frame_sizes.push_back(h.frame_size);
+        frames_total += h.frame_count; first_frame.push_back(frames_total);
+        out_pos = align_up(out_pos + len, 64);
+        j->units += h.frame_count; j->alg_bytes += 2ull * h.frame_count * h.frame_size;
+    }
+    j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    j->crypt.n_streams = (uint32_t)streams.size(); j->crypt.frames = frames_total;
+    if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); frame_sizes.push_back(8); }
+    if (cipher.empty()) cipher.assign(256, 0);
+    int rc = 0;
+    if ((rc = j->d_streams.upload(streams)) || (rc = j->d_frame_sizes.upload(frame_sizes)) || (rc = j->d_first_frame.upload(first_frame)) ||
+        (rc = j->d_cipher.upload(cipher)) || (rc = j->upload_images())) { delete j; return rc; }
+    *out = j;
+    return 0;
+}
+extern "C" int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,
+                                        const uint64_t* keys, const uint16_t* subkeys, cri_job** job) {
+    return create_hca_crypt(blob, offsets, n, encrypt, type, keys, subkeys, nullptr, job);
+}
+
+extern "C" int cri_job_create_hca_encode(const uint8_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, cri_job**) {
+    return CRI_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------ run
+extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, void* hip_stream) {
+    if (!j || !d_in || (!d_out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
+    if (j->scratch_bytes && !d_scratch) return CRI_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (d_status) launch_fill_i32(d_status, 0, j->n, s);
+    if (j->n_images)
+        launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, (uint8_t*)d_out, s);
+    switch (j->kind) {
+        case CRI_JOB_HCA_DECODE:
+            for (auto a : j->hca_dec) {
+                a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.scratch = (uint8_t*)d_scratch; a.status = d_status;
+                a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
+                a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p;
+                launch_hca_unpack(a, s);
+                launch_hca_transform(a, s);
+            }
+            break;
+        case CRI_JOB_ADX_DECODE:
+        case CRI_JOB_ADX_ENCODE: {
+            AdxArgs a = j->adx;
+            a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status;
+            a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
+            a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p;
+            if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode(a, s); else launch_adx_encode(a, s);
+            break;
+        }
+        case CRI_JOB_HCA_CRYPT: {
+            CryptArgs a = j->crypt;
+            a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.streams = (const HcaStream*)j->d_streams.p;
+            a.frame_sizes = (const uint32_t*)j->d_frame_sizes.p; a.cipher_tables = (const uint8_t*)j->d_cipher.p;
+            a.first_frame = (const uint32_t*)j->d_first_frame.p;
+            launch_hca_crypt(a, s);
+            break;
+        }
+        default: return CRI_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : CRI_ERR_HIP;
+}
+
+extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_blob, int32_t* status) {
+    if (!j || !blob || !out_blob) return CRI_ERR_INVALID_ARG;
+    void *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr; int32_t* d_st = nullptr;
+    int rc = 0;
+    uint8_t* host_out = nullptr;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = CRI_ERR_HIP; return e == hipSuccess; };
+    if (ok(hipMalloc(&d_in, j->in_bytes ? j->in_bytes : 1)) && ok(hipMalloc(&d_out, j->out_bytes ? j->out_bytes : 1)) &&
+        ok(hipMalloc(&d_scr, j->scratch_bytes ? j->scratch_bytes : 1)) && ok(hipMalloc((void**)&d_st, (j->n ? j->n : 1) * sizeof(int32_t)))) {
+        ok(hipMemcpy(d_in, blob, j->in_bytes, hipMemcpyHostToDevice));
+        // bytes no kernel writes (alignment gaps, undecoded tails) are defined as zero
+        ok(hipMemsetAsync(d_out, 0, j->out_bytes ? j->out_bytes : 1, nullptr));
+        if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, nullptr);
+        ok(hipDeviceSynchronize());
+        host_out = (uint8_t*)malloc(j->out_bytes ? j->out_bytes : 1);
+        if (!host_out) rc = rc ? rc : CRI_ERR_NOMEM;
+        else ok(hipMemcpy(host_out, d_out, j->out_bytes, hipMemcpyDeviceToHost));
+        if (status) {
+            std::vector<int32_t> st(j->n ? j->n : 1, 0);
+            ok(hipMemcpy(st.data(), d_st, j->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < j->n; i++) status[i] = j->host_status[i] ? j->host_status[i] : st[i];
+        }
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_scr) (void)hipFree(d_scr);
+    if (d_st) (void)hipFree(d_st);
+    if (rc) { free(host_out); return rc; }
+    *out_blob = host_out;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ single-file entry points
+static int run_single(cri_job* j, const uint8_t* in, uint8_t** out, size_t* out_len, size_t item_len) {
+    int32_t st = 0;
+    uint8_t* blob = nullptr;
+    int rc = j->host_status[0];
+    if (!rc) rc = cri_job_run_host(j, in, &blob, &st);
+    if (!rc) rc = st;
+    if (rc) { free(blob); cri_job_destroy(j); return rc; }
+    uint8_t* res = (uint8_t*)malloc(item_len ? item_len : 1);
+    if (!res) { free(blob); cri_job_destroy(j); return CRI_ERR_NOMEM; }
+    memcpy(res, blob, item_len);
+    free(blob);
+    cri_job_destroy(j);
+    *out = res; *out_len = item_len;
+    return 0;
+}
+
+extern "C" int cri_adx_decode(const uint8_t* adx, size_t len, uint8_t** out, size_t* out_len) {
+    if (!adx || !out || !out_len) return CRI_ERR_INVALID_ARG;
+    uint64_t offs[2] = {0, len};
+    cri_job* j = nullptr;
+    int rc = cri_job_create_adx_decode(adx, offs, 1, &j);
+    if (rc) return rc;
+    size_t item = 0;
+    if (!j->host_status[0]) item = (size_t)(le32(j->images[0].bytes.data() + 4) + 8);   // RIFF size + 8
+    return run_single(j, adx, out, out_len, item);
+}
+
+extern "C" int cri_adx_encode(const uint8_t* wav, size_t len, uint32_t bitdepth, uint32_t blocksize, uint32_t mode, uint32_t highpass,
+                              uint32_t filter, uint32_t version, int force_no_looping, uint8_t** out, size_t* out_len) {
+    if (!wav || !out || !out_len) return CRI_ERR_INVALID_ARG;
+    uint64_t offs[2] = {0, len};
+    cri_adx_encode_params p = {bitdepth, blocksize, mode, highpass, filter, version, (uint32_t)(force_no_looping != 0)};
+    cri_job* j = nullptr;
+    int rc = cri_job_create_adx_encode(wav, offs, 1, &p, &j);
+    if (rc) return rc;
+    size_t item = 0;
+    if (!j->host_status[0]) item = (size_t)(j->images[1].dst + blocksize);             // tail block ends the file
+    return run_single(j, wav, out, out_len, item);
+}
+
+extern "C" int cri_hca_decode(const uint8_t* hca, size_t len, uint32_t header_size, uint64_t key, uint16_t subkey, uint8_t** out, size_t* out_len) {
+    if (!hca || !out || !out_len) return CRI_ERR_INVALID_ARG;
+    uint64_t offs[2] = {0, len};
+    cri_job* j = nullptr;
+    int rc = create_hca_decode(hca, offs, 1, &key, &subkey, &header_size, &j);
+    if (rc) return rc;
+    size_t item = 0;
+    if (!j->host_status[0]) item = (size_t)(le32(j->images[0].bytes.data() + 4) + 8);
+    rc = run_single(j, hca, out, out_len, item);
+    if (rc <= -211 && rc >= -216) rc = CRI_ERR_HCA_DECODE;                             // hca.cpp:3441-3444
+    return rc;
+}
+
+extern "C" int cri_hca_crypt(uint8_t* hca, size_t len, uint32_t encrypt, uint32_t header_size, uint32_t type, uint64_t key, uint16_t subkey) {
+    if (!hca) return CRI_ERR_INVALID_ARG;
+    uint64_t offs[2] = {0, len};
+    cri_job* j = nullptr;
+    int rc = create_hca_crypt(hca, offs, 1, encrypt, type, &key, &subkey, &header_size, &j);
+    if (rc) return rc;
+    uint8_t* res = nullptr; size_t n = 0;
+    rc = run_single(j, hca, &res, &n, len);
+    if (rc) return rc;
+    memcpy(hca, res, len);
+    free(res);
+    return 0;
+}
+
+extern "C" int cri_hca_encode(const uint8_t* wav, size_t len, uint32_t force_no_looping, uint32_t quality, uint8_t** out, size_t* out_len) {
+    if (!wav || !out || !out_len) return CRI_ERR_INVALID_ARG;
+    uint64_t offs[2] = {0, len};
+    cri_job* j = nullptr;
+    int rc = cri_job_create_hca_encode(wav, offs, 1, force_no_looping, quality, &j);
+    if (rc) return rc;
+    size_t item = (size_t)j->out_bytes;
+    return run_single(j, wav, out, out_len, item);
+}

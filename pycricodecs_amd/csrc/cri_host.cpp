@@ -1,0 +1,467 @@
+// cri_host.cpp -- per-file host logic of the ADX / HCA path (headers, WAV glue, parameter derivation).
+// Nothing here touches sample data; all per-frame / per-block work is in cri_kernels.hip.
+// Citations are to /root/reference/CriCodecs/<file>:<lines>.
+#include "cri_host.h"
+#include <math.h>
+#include <string.h>
+#include "../../include/cricodecs_hip.h"
+#define CRI_TABLE_QUAL static const
+#include "cri_tables.h"
+
+namespace cri {
+
+static int next_multiple(int value, int multiple) {   // IO.hpp:26-32
+    if (multiple <= 0) return value;
+    if (value % multiple == 0) return value;
+    return value + multiple - value % multiple;
+}
+
+uint16_t crc16(const uint8_t* p, size_t n) {           // hca.cpp:205-211
+    uint16_t s = 0;
+    for (size_t i = 0; i < n; i++) s = (uint16_t)((s << 8) ^ CRI_CRC16_TAB[(s >> 8) ^ p[i]]);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ WAV
+// RIFF chunk walk: pcm.cpp:335-342 (riff), 291-327 (chunks), 177-201 (fmt), 243-261 (smpl), 276-283 (data),
+// 419-444 (sample layout).  Every access is bounds-checked against `len` (the reference trusts the RIFF size).
+int wav_parse(const uint8_t* w, size_t len, WavInfo& o) {
+    o = WavInfo();
+    if (len < 12) return CRI_ERR_PCM(1);
+    if (le32(w) != 0x46464952u || le32(w + 8) != 0x45564157u) return CRI_ERR_PCM(1);
+    uint32_t fullsize = le32(w + 4), sum = 4, raw_mode = 0, ext_bits = 0, subfmt = 0;
+    bool have_fmt = false, have_data = false;
+    size_t cur = 12;
+    while (sum < fullsize) {
+        if (cur + 8 > len) return CRI_ERR_PCM(7);
+        uint32_t sig = le32(w + cur), size = le32(w + cur + 4) + 8;
+        size += ((size & 1) && size + sum + (size & 1) <= fullsize);
+        if (sig == 0x20746D66u) {
+            uint32_t fsz = le32(w + cur + 4);
+            if (fsz < 16) return CRI_ERR_PCM(2);
+            if (cur + 24 > len) return CRI_ERR_PCM(7);
+            raw_mode = le16(w + cur + 8);
+            o.channels = le16(w + cur + 10);
+            o.rate = le32(w + cur + 12);
+            o.block_align = le16(w + cur + 20);
+            o.bitdepth = le16(w + cur + 22);
+            if (fsz > 18 && raw_mode == 0xFFFE) {
+                if (cur + 48 > len) return CRI_ERR_PCM(7);
+                ext_bits = le16(w + cur + 26);
+                subfmt = le32(w + cur + 32);
+                if (subfmt != 1 && subfmt != 0xFFFE && subfmt != 3) return CRI_ERR_PCM(3);
+            }
+            if (raw_mode != 1 && raw_mode != 0xFFFE && raw_mode != 3) return CRI_ERR_PCM(3);
+            have_fmt = true;
+        } else if (sig == 0x6C706D73u) {
+            uint32_t ssz = le32(w + cur + 4);
+            if (ssz < 36) return CRI_ERR_PCM(4);
+            if (cur + 44 > len) return CRI_ERR_PCM(7);
+            uint32_t nl = le32(w + cur + 36), sd = le32(w + cur + 40);
+            if ((uint64_t)ssz < (uint64_t)nl * 24 + sd + 36) return CRI_ERR_PCM(5);
+            if (cur + 44 + (uint64_t)nl * 24 > len) return CRI_ERR_PCM(7);
+            o.num_loops = nl;
+            o.loop_start.clear(); o.loop_end.clear();
+            for (uint32_t i = 0; i < nl; i++) {
+                o.loop_start.push_back(le32(w + cur + 44 + 24 * (size_t)i + 8));
+                o.loop_end.push_back(le32(w + cur + 44 + 24 * (size_t)i + 12));
+            }
+            o.looping = true;
+        } else if (sig == 0x61746164u) {
+            o.data_offset = cur + 8;
+            o.data_size = le32(w + cur + 4);
+            have_data = true;
+        }
+        cur += size;
+        sum += size;
+        if (sum > fullsize) return CRI_ERR_PCM(7);
+    }
+    if (!have_fmt) return CRI_ERR_PCM(2);
+    if (!have_data) return CRI_ERR_PCM(6);
+    if (o.data_offset + o.data_size > len) return CRI_ERR_PCM(7);
+    if (raw_mode == 0xFFFE) { o.bitdepth = ext_bits; o.mode = subfmt; } else o.mode = raw_mode;
+    if (o.channels == 0 || o.block_align / o.channels == 0) return CRI_ERR_PCM(8);
+    o.sample_size = o.block_align / o.channels;
+    o.column_size = o.data_size / o.sample_size;
+    if (o.mode == 3) { if (o.bitdepth != 32 && o.bitdepth != 64) return CRI_ERR_PCM(8); }
+    else if (o.bitdepth < 1 || o.bitdepth > 32 || o.sample_size > 4 || o.sample_size < 1) return CRI_ERR_PCM(8);
+    return 0;
+}
+
+bool wav_is_pcm16(const WavInfo& w) { return w.mode != 3 && w.bitdepth > 8 && w.bitdepth <= 16 && w.sample_size == 2; }
+
+// pcm.cpp:350-375 (riff header), 262-269 (smpl), 547-556 (sizes)
+uint32_t wav_write_header(uint8_t* d, uint32_t channels, uint32_t rate, uint32_t spc, bool looping, uint32_t ls, uint32_t le) {
+    uint32_t hs = looping ? 0x70 : 0x2C, pos = 36, datasize = spc * channels * 2;
+    put_le32(d, 0x46464952u); put_le32(d + 4, hs + datasize - 8); put_le32(d + 8, 0x45564157u);
+    put_le32(d + 12, 0x20746D66u); put_le32(d + 16, 16); put_le16(d + 20, 1); put_le16(d + 22, channels);
+    put_le32(d + 24, rate); put_le32(d + 28, 2 * channels * rate); put_le16(d + 32, 2 * channels); put_le16(d + 34, 16);
+    if (looping) {
+        put_le32(d + 36, 0x6C706D73u); put_le32(d + 40, 0x3C);
+        memset(d + 44, 0, 0x3C);
+        put_le32(d + 36 + 0x24, 1); put_le32(d + 36 + 0x34, ls); put_le32(d + 36 + 0x38, le);
+        pos = 104;
+    }
+    put_le32(d + pos, 0x61746164u); put_le32(d + pos + 4, datasize);
+    return hs;
+}
+
+// ------------------------------------------------------------------------------------------------ ADX
+void adx_coefficients(uint32_t highpass, uint32_t rate, int32_t coef[2]) {   // adx.cpp:58-64 (+ macros 6-7)
+    double a = 1.414213562373095 - cos(2.0 * 3.141592653589793 * (uint16_t)highpass / rate);
+    double b = 1.414213562373095 - 1;
+    double c = (a - sqrt((a + b) * (a - b))) / b;
+    coef[0] = (int32_t)(c * 8192);
+    coef[1] = (int32_t)(c * c * -4096);
+}
+
+// adx.cpp:298-358 (ADX::loadHeader) + 145-183 (field layout) + 117-129 (loop table) + 385-391
+int adx_parse_header(const uint8_t* d, size_t len, AdxHeader& h) {
+    if (!d || len < 20) return CRI_ERR_ADX(1);
+    uint32_t sig = be16(d), flag = d[19];
+    h.data_offset = be16(d + 2); h.mode = d[4]; h.blocksize = d[5]; h.bitdepth = d[6]; h.channels = d[7];
+    h.rate = be32(d + 8); h.sample_count = be32(d + 12); h.highpass = be16(d + 16); h.version = d[18];
+    h.looping = false; h.loop_start = h.loop_end = 0;
+    if (sig != 0x8000) return CRI_ERR_ADX(1);
+    if (h.mode == 0x11 || h.mode == 0x10 || h.version == 6 || h.blocksize == 0 || h.bitdepth == 0) return CRI_ERR_ADX(2);
+    if (flag == 8 || flag == 9) return CRI_ERR_ADX(3);
+    if (h.mode != 2 && h.mode != 3 && h.mode != 4) return CRI_ERR_ADX(4);
+    if (h.version != 3 && h.version != 4 && h.version != 5) return CRI_ERR_ADX(5);
+    if (((int)(h.blocksize - 2) * 8) % (int)h.bitdepth != 0 || h.bitdepth >= 16) return CRI_ERR_ADX(6);
+    if (h.channels == 0) return CRI_ERR_ADX(7);
+    h.history.assign((size_t)h.channels * 2, 0);
+    uint32_t base = 20;
+    bool looping = false;
+    if (h.version == 4) {
+        base += 4;
+        for (uint32_t i = 0; i < h.channels; i++) {
+            size_t p = base + 4 * (size_t)i;
+            if (p + 4 <= len) { h.history[2 * i] = (int16_t)be16(d + p); h.history[2 * i + 1] = (int16_t)be16(d + p + 2); }
+        }
+        base += 4 * (h.channels > 1 ? h.channels : 2);
+        if (base + 24 <= (uint32_t)((int32_t)h.data_offset - 2)) looping = true;
+    } else if (h.version == 3) {
+        if (base + 24 <= (uint32_t)((int32_t)h.data_offset - 2)) looping = true;
+    }
+    if (looping) {
+        if ((size_t)base + 4 > len) return CRI_ERR_ADX(1);
+        uint32_t lc = be16(d + base + 2);
+        if (!lc) looping = false;
+        else {
+            if ((uint64_t)base + 4 + (uint64_t)lc * 20 >= (uint64_t)(int64_t)((int32_t)h.data_offset - 2)) return CRI_ERR_ADX(8);
+            if ((size_t)base + 24 > len) return CRI_ERR_ADX(1);
+            h.loop_start = be32(d + base + 8);
+            h.loop_end = be32(d + base + 16);
+        }
+    }
+    h.looping = looping;
+    static const char cri_str[7] = "(c)CRI";
+    for (uint32_t i = 0; i < 7; i++) {                        // 7 bytes incl. NUL: adx.cpp:345-348
+        size_t p = (size_t)h.data_offset - 2 + i;
+        if (h.data_offset < 2 || p >= len || (char)d[p] != cri_str[i]) return CRI_ERR_ADX(9);
+    }
+    h.samples_per_block = (h.blocksize - 2) * 8 / h.bitdepth;
+    adx_coefficients(h.highpass, h.rate, h.coef);
+    h.blocks = (uint32_t)ceilf((float)h.sample_count / (float)h.samples_per_block);
+    return 0;
+}
+
+// adx.cpp:416-489 (validation, padding rule, header size, initial history) + 359-379 (header bytes) +
+// 131-142 / 94-105 (loop table).  `image` holds every byte the reference writes before the block loop starts:
+// the 16-aligned header, plus -- for more than 6 channels -- the per-channel history entries that spill past
+// it into the first blocks (the block writer ORs into the first byte of a block, IO.cpp:139).
+int adx_plan_encode(const uint8_t* wav, size_t len, const WavInfo& w, uint32_t bd, uint32_t bs, uint32_t mode, uint32_t highpass,
+                    uint32_t filter, uint32_t ver, bool force_no_loop, AdxEncodePlan& p) {
+    (void)len;
+    uint32_t ch = w.channels & 0xFF;
+    bool looping = (force_no_loop && ver == 5) ? false : w.looping;
+    if (ch < 1) return CRI_ERR_ADX(10);
+    if (bd <= 1 || bd >= 16) return CRI_ERR_ADX(11);
+    if (bs <= 2 || bs > 255) return CRI_ERR_ADX(12);
+    if (mode != 2 && mode != 3 && mode != 4) return CRI_ERR_ADX(13);
+    if (filter > 3) return CRI_ERR_ADX(15);
+    if (ver != 3 && ver != 4 && ver != 5) return CRI_ERR_ADX(16);
+    if ((8 * (bs - 2)) % bd != 0) return CRI_ERR_ADX(17);
+    if (w.column_size < ch || w.column_size % ch != 0) return CRI_ERR_ADX(18);
+    if (looping && w.num_loops == 0) return CRI_ERR_UNSUPPORTED;
+    uint32_t dbs = bs - 2, spb = dbs * 8 / bd, spc = w.column_size / ch, frames;
+    if (spc % spb != 0) frames = ((uint32_t)next_multiple((int)spc, (int)dbs)) / spb;   // adx.cpp:450-452
+    else frames = spc / spb;
+    p.channels = ch; p.samples_per_channel = spc; p.samples_per_block = spb; p.frames = frames;
+    if (mode == 2) { p.coef[0] = ADX_STATIC_COEFS[filter * 2]; p.coef[1] = ADX_STATIC_COEFS[filter * 2 + 1]; }
+    else adx_coefficients((uint16_t)highpass, w.rate, p.coef);
+    p.history.assign((size_t)ch * 2, 0);
+    if (ver == 4 || ver == 5) {
+        for (uint32_t i = 0; i < ch; i++) {                    // first sample of each channel (adx.cpp:473-476); 16-bit input only
+            int16_t s = 0;
+            if (wav_is_pcm16(w) && (uint64_t)i * 2 + 2 <= w.data_size) s = (int16_t)le16(wav + w.data_offset + 2 * (size_t)i);
+            p.history[2 * i] = p.history[2 * i + 1] = s;
+        }
+    }
+    uint32_t hs = 20 + 6;
+    if (ver == 4 || ver == 5) hs += 8;                          // adx.cpp:482 with a zeroed Header.Channels
+    if (looping) hs += 4 + w.num_loops * 20;
+    hs = hs % 16 == 0 ? hs : hs + (16 - hs % 16);
+    p.header_size = hs;
+    p.total_size = (uint64_t)hs + (uint64_t)frames * ch * bs + bs;
+    size_t img = hs + 1;
+    if (ver == 4 || ver == 5) { size_t e = 24 + 4 * (size_t)ch; if (e > img) img = e; }
+    if (img > p.total_size) img = (size_t)p.total_size;
+    p.image.assign(img, 0);
+    uint8_t* o = p.image.data();
+    auto P8 = [&](size_t pos, uint32_t v) { if (pos < img) o[pos] = (uint8_t)v; };
+    auto P16 = [&](size_t pos, uint32_t v) { P8(pos, v >> 8); P8(pos + 1, v); };
+    auto P32 = [&](size_t pos, uint32_t v) { P16(pos, v >> 16); P16(pos + 2, v & 0xFFFF); };
+    P16(0, 0x8000); P16(2, hs - 4); P8(4, mode); P8(5, bs); P8(6, bd); P8(7, w.channels);
+    P32(8, w.rate); P32(12, spc); P16(16, mode == 2 ? 0 : (uint16_t)highpass); P8(18, ver); P8(19, 0);
+    size_t off = 20;
+    if (ver == 4 || ver == 5) {
+        P32(off, 0);
+        for (uint32_t i = 0; i < ch; i++) { P16(off + 4 + 4 * (size_t)i, (uint16_t)p.history[2 * i]); P16(off + 6 + 4 * (size_t)i, (uint16_t)p.history[2 * i + 1]); }
+        off += 4 + (ch > 1 ? 4 * ch : 8);
+    }
+    if (looping) {
+        uint32_t sif = (bs - 2) * 2;
+        uint16_t align = (uint16_t)next_multiple((int)w.loop_start[0], (int)(ch == 1 ? sif * 2 : sif));
+        P16(off, align); P16(off + 2, w.num_loops);
+        for (uint32_t i = 0; i < w.num_loops; i++) {
+            uint32_t st = w.loop_start[i] + align, en = w.loop_end[i] + align;
+            uint32_t sb = hs + ((st / spb) * bs) * ch;
+            uint32_t eb = hs + (uint32_t)next_multiple((int)((en / spb) * bs + (en % spb) / bs), (int)bs) * ch;
+            size_t q = off + 4 + 20 * (size_t)i;
+            P16(q, i); P16(q + 2, 1); P32(q + 4, st); P32(q + 8, sb); P32(q + 12, en); P32(q + 16, eb);
+        }
+    }
+    static const char cri_str[7] = "(c)CRI";
+    for (uint32_t i = 0; i < 7; i++) P8((size_t)hs + i - 6, (uint8_t)cri_str[i]);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ HCA
+void hca_channel_types(uint32_t channels, uint32_t track_count, uint32_t stereo_bands, uint32_t config, uint8_t t[16]) {
+    // hca.cpp:887-958 (decoder) and 2323-2401 (encoder) build the same table
+    memset(t, CRI_CH_DISCRETE, 16);
+    if (track_count == 0) return;
+    uint32_t cpt = channels / track_count;
+    if (stereo_bands == 0 || cpt <= 1) return;
+    for (uint32_t i = 0; i + cpt <= channels && i / cpt < track_count; i += cpt) {
+        uint8_t* c = t + i;
+        if (cpt >= 2 && cpt <= 8) { c[0] = CRI_CH_PRIMARY; c[1] = CRI_CH_SECONDARY; }
+        if (cpt == 4 && config == 0) { c[2] = CRI_CH_PRIMARY; c[3] = CRI_CH_SECONDARY; }
+        if (cpt == 5 && config <= 2) { c[3] = CRI_CH_PRIMARY; c[4] = CRI_CH_SECONDARY; }
+        if (cpt >= 6 && cpt <= 8) { c[4] = CRI_CH_PRIMARY; c[5] = CRI_CH_SECONDARY; }
+        if (cpt == 8) { c[6] = CRI_CH_PRIMARY; c[7] = CRI_CH_SECONDARY; }
+    }
+}
+
+// hca.cpp:628-984 (clHCA_DecodeHeader).  Returns 0 or CRI_ERR_HCA_HEADER.
+int hca_parse_header(const uint8_t* d, size_t len, uint32_t size_arg, HcaHeader& h) {
+    memset(&h, 0, sizeof h);
+    uint32_t size = size_arg, pos = 0;
+    auto magic = [&](uint32_t at) { return be32(d + at) & 0x7F7F7F7Fu; };
+    auto have = [&](uint32_t n) { return (size_t)pos + n <= len; };
+    if (!d || size < 8 || len < 8) return CRI_ERR_HCA_HEADER;
+    if (magic(0) != 0x48434100u) return CRI_ERR_HCA_HEADER;
+    h.version = be16(d + 4); h.header_size = be16(d + 6);
+    if (h.version != 0x0101 && h.version != 0x0102 && h.version != 0x0103 && h.version != 0x0200 && h.version != 0x0300) return CRI_ERR_HCA_HEADER;
+    if (size < h.header_size || len < h.header_size) return CRI_ERR_HCA_HEADER;
+    if (crc16(d, h.header_size)) return CRI_ERR_HCA_HEADER;
+    size -= 8; pos = 8;
+    if (size >= 0x10 && have(16) && magic(pos) == 0x666D7400u) {
+        h.channels = d[pos + 4]; h.rate = be32(d + pos + 4) & 0xFFFFFF; h.frame_count = be32(d + pos + 8);
+        h.delay = be16(d + pos + 12); h.padding = be16(d + pos + 14);
+        if (!(h.channels >= 1 && h.channels <= 16) || h.frame_count == 0 || !(h.rate >= 1 && h.rate <= 0x7FFFFF)) return CRI_ERR_HCA_HEADER;
+        size -= 0x10; pos += 0x10;
+    } else return CRI_ERR_HCA_HEADER;
+    if (size >= 0x10 && have(16) && magic(pos) == 0x636F6D70u) {
+        h.frame_size = be16(d + pos + 4); h.min_res = d[pos + 6]; h.max_res = d[pos + 7]; h.track_count = d[pos + 8];
+        h.channel_config = d[pos + 9]; h.total_bands = d[pos + 10]; h.base_bands = d[pos + 11]; h.stereo_bands = d[pos + 12];
+        h.bands_per_hfr_group = d[pos + 13]; h.ms_stereo = d[pos + 14];
+        size -= 0x10; pos += 0x10;
+    } else if (size >= 0x0c && have(12) && magic(pos) == 0x64656300u) {
+        h.frame_size = be16(d + pos + 4); h.min_res = d[pos + 6]; h.max_res = d[pos + 7];
+        h.total_bands = d[pos + 8] + 1u; h.base_bands = d[pos + 9] + 1u;
+        h.track_count = d[pos + 10] >> 4; h.channel_config = d[pos + 10] & 0xF; h.stereo_type = d[pos + 11];
+        if (h.stereo_type == 0) h.base_bands = h.total_bands;
+        h.stereo_bands = h.total_bands - h.base_bands;
+        h.bands_per_hfr_group = 0;
+        size -= 0x0c; pos += 0x0c;
+    } else return CRI_ERR_HCA_HEADER;
+    if (size >= 8 && have(8) && magic(pos) == 0x76627200u) {
+        uint32_t mx = be16(d + pos + 4);
+        if (!(h.frame_size == 0 && mx > 8 && mx <= 0x1FF)) return CRI_ERR_HCA_HEADER;
+        size -= 8; pos += 8;
+    }
+    if (size >= 6 && have(6) && magic(pos) == 0x61746800u) { h.ath_type = be16(d + pos + 4); pos += 6; }
+    else h.ath_type = h.version < 0x0200 ? 1 : 0;
+    if (size >= 0x10 && have(16) && magic(pos) == 0x6C6F6F70u) {
+        h.loop_start_frame = be32(d + pos + 4); h.loop_end_frame = be32(d + pos + 8);
+        h.loop_start_delay = be16(d + pos + 12); h.loop_end_padding = be16(d + pos + 14);
+        h.loop_flag = 1;
+        if (!(h.loop_start_frame <= h.loop_end_frame && h.loop_end_frame < h.frame_count)) return CRI_ERR_HCA_HEADER;
+        size -= 0x10; pos += 0x10;
+    }
+    if (size >= 6 && have(6) && magic(pos) == 0x63697068u) {
+        h.ciph_type = be16(d + pos + 4);
+        if (!(h.ciph_type == 0 || h.ciph_type == 1 || h.ciph_type == 56)) return CRI_ERR_HCA_HEADER;
+        size -= 6; pos += 6;
+    }
+    if (size >= 8 && have(8) && magic(pos) == 0x72766100u) { size -= 8; pos += 8; }
+    if (size >= 5 && have(5) && magic(pos) == 0x636F6D6Du) {
+        h.comment_len = d[pos + 4];
+        if (h.comment_len > size) return CRI_ERR_HCA_HEADER;
+        size -= 5 + h.comment_len; pos += 5 + h.comment_len;
+    }
+    if (!(h.frame_size >= 8 && h.frame_size <= 0xFFFF)) return CRI_ERR_HCA_HEADER;
+    if (h.version <= 0x0200) { if (h.min_res != 1 || h.max_res != 15) return CRI_ERR_HCA_HEADER; }
+    else if (h.min_res > h.max_res || h.max_res > 15) return CRI_ERR_HCA_HEADER;
+    if (h.track_count == 0) h.track_count = 1;
+    if (h.track_count > h.channels) return CRI_ERR_HCA_HEADER;
+    if (h.total_bands > 128 || h.base_bands > 128 || h.stereo_bands > 128 || h.base_bands + h.stereo_bands > 128 ||
+        h.bands_per_hfr_group > 128) return CRI_ERR_HCA_HEADER;
+    {
+        uint32_t a = h.total_bands - h.base_bands - h.stereo_bands, b = h.bands_per_hfr_group;   // hca.cpp:619-623, 872-874
+        h.hfr_group_count = b < 1 ? 0 : (a / b + ((a % b) ? 1 : 0));
+    }
+    if (h.ath_type == 0) memset(h.ath, 0, 128);                                               // hca.cpp:451-485
+    else if (h.ath_type == 1) {
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < 128; i++) {
+            acc += h.rate;
+            uint32_t index = acc >> 13;
+            if (index >= 654) { memset(h.ath + i, 0xFF, 128 - i); break; }
+            h.ath[i] = HCA_ATH_BASE[index];
+        }
+    } else return CRI_ERR_HCA_HEADER;
+    hca_channel_types(h.channels, h.track_count, h.stereo_bands, h.channel_config, h.type);
+    for (uint32_t i = 0; i < h.channels; i++)
+        h.coded[i] = h.type[i] != CRI_CH_SECONDARY ? h.base_bands + h.stereo_bands : h.base_bands;
+    if (h.ms_stereo) return CRI_ERR_HCA_HEADER;
+    return 0;
+}
+
+static void cipher56_row(uint8_t* r, uint8_t key) {          // hca.cpp:524-534
+    int mul = ((key & 1) << 3) | 5, add = (key & 0xE) | 1;
+    key >>= 4;
+    for (int i = 0; i < 16; i++) { key = (uint8_t)((key * mul + add) & 0xF); r[i] = key; }
+}
+
+int hca_cipher_table(uint32_t type, uint64_t key, uint8_t t[256]) {   // hca.cpp:499-617
+    if (type == 56 && !key) type = 0;
+    if (type == 0) { for (uint32_t i = 0; i < 256; i++) t[i] = (uint8_t)i; return 0; }
+    if (type == 1) {
+        uint32_t v = 0;
+        for (uint32_t i = 1; i < 255; i++) {
+            v = (v * 13 + 11) & 0xFF;
+            if (v == 0 || v == 0xFF) v = (v * 13 + 11) & 0xFF;
+            t[i] = (uint8_t)v;
+        }
+        t[0] = 0; t[255] = 0xFF;
+        return 0;
+    }
+    if (type != 56) return CRI_ERR_HCA_HEADER;
+    uint8_t kc[8], seed[16], base[256], br[16], bc[16];
+    key--;
+    for (uint32_t r = 0; r < 7; r++) { kc[r] = (uint8_t)key; key >>= 8; }
+    const uint8_t pick[16][2] = {{1, 0}, {1, 6}, {2, 3}, {2, 0}, {2, 1}, {3, 4}, {3, 0}, {3, 2},
+                                 {4, 5}, {4, 0}, {4, 3}, {5, 6}, {5, 0}, {5, 4}, {6, 1}, {6, 0}};
+    for (uint32_t i = 0; i < 16; i++) seed[i] = (uint8_t)(kc[pick[i][0]] ^ (pick[i][1] ? kc[pick[i][1]] : 0));
+    cipher56_row(br, kc[0]);
+    for (uint32_t r = 0; r < 16; r++) {
+        cipher56_row(bc, seed[r]);
+        for (uint32_t c = 0; c < 16; c++) base[r * 16 + c] = (uint8_t)((br[r] << 4) | bc[c]);
+    }
+    uint32_t x = 0, pos = 1;
+    for (uint32_t i = 0; i < 256; i++) {
+        x = (x + 17) & 0xFF;
+        if (base[x] != 0 && base[x] != 0xFF) t[pos++] = base[x];
+    }
+    t[0] = 0; t[255] = 0xFF;
+    return 0;
+}
+
+uint64_t hca_mix_key(uint64_t key, uint16_t subkey) {        // hca.cpp:3381-3383 / 3309-3311
+    if (subkey) key = key * (((uint64_t)subkey << 16) | (uint64_t)((uint16_t)~subkey + 2u));
+    return key;
+}
+
+// hca.cpp:3166-3250: toggle bit 7 of the chunk magics, rewrite the ciph type, refresh the header CRC.
+void hca_crypt_header(uint8_t* d, uint32_t hs, uint32_t encrypt, uint32_t type) {
+    uint32_t size = hs, pos = 0;
+    auto magic = [&](uint32_t at) { return be32(d + at) & 0x7F7F7F7Fu; };
+    auto flip = [&](uint32_t at, int n) { for (int i = 0; i < n; i++) d[at + i] ^= 0x80; };
+    if (magic(pos) == 0x48434100u) { flip(pos, 3); pos += 8; size -= 8; }
+    if (size >= 0x10 && magic(pos) == 0x666D7400u) { flip(pos, 3); pos += 16; size -= 16; }
+    if (size >= 0x10 && magic(pos) == 0x636F6D70u) { flip(pos, 4); pos += 16; size -= 16; }
+    else if (size >= 0x0c && magic(pos) == 0x64656300u) { flip(pos, 3); pos += 12; size -= 12; }
+    if (size >= 8 && magic(pos) == 0x76627200u) { flip(pos, 3); pos += 8; size -= 8; }
+    if (size >= 6 && magic(pos) == 0x61746800u) { flip(pos, 3); pos += 6; }
+    if (size >= 0x10 && magic(pos) == 0x6C6F6F70u) { flip(pos, 4); pos += 16; size -= 16; }
+    if (size >= 6 && magic(pos) == 0x63697068u) { flip(pos, 4); put_be16(d + pos + 4, encrypt == 1 ? (type & 0xFFFF) : 0); pos += 6; size -= 6; }
+    if (size >= 8 && magic(pos) == 0x72766100u) { flip(pos, 3); pos += 8; size -= 8; }
+    if (size >= 5 && magic(pos) == 0x636F6D6Du) { uint32_t cl = d[pos + 4]; flip(pos, 4); pos += 5 + cl; size -= 5 + cl; }
+    if (size >= 4 && pos + 4 <= hs && magic(pos) == 0x70616400u) flip(pos, 3);
+    put_be16(d + hs - 2, crc16(d, hs - 2));
+}
+
+static int div_round_up(int v, int d) { return (int)ceilf((float)v / d); }   // hca.cpp:182-184
+static uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// hca.cpp:2206-2234 (bitrate), 2236-2270 (band counts), 2272-2277 (hfr), 2279-2290 (channel config),
+// 2307-2321 (header size), 2414-2462 (initHCAEncode), non-looping path.
+int hca_enc_setup(uint32_t channels, uint32_t rate, uint32_t spc, uint32_t quality, HcaEncSetup& e) {
+    memset(&e, 0, sizeof e);
+    if (channels == 0 || rate == 0) return CRI_ERR_HCA_CHANNEL_CONFIG;
+    uint32_t pcm_bitrate = rate * channels * 16, max_bitrate = pcm_bitrate / 4, cutoff = rate / 2;
+    int ratio = 6;
+    switch (quality) {
+        case 0: ratio = 4; break; case 1: ratio = 6; break; case 2: ratio = 8; break;
+        case 3: ratio = channels == 1 ? 10 : 12; break; case 4: ratio = channels == 1 ? 12 : 16; break;
+        default: break;
+    }
+    uint32_t bitrate = pcm_bitrate / (uint32_t)ratio;
+    if (bitrate > max_bitrate) bitrate = max_bitrate;
+    if (bitrate == 0) return CRI_ERR_HCA_CHANNEL_CONFIG;
+    e.channels = channels; e.rate = rate; e.samples_per_channel = spc; e.delay = 128;
+    e.frame_size = bitrate * 1024 / rate / 8;
+    uint32_t hfr_ratio, cutoff_ratio;
+    if (channels <= 1 || pcm_bitrate / bitrate <= 6) { hfr_ratio = 6; cutoff_ratio = 12; } else { hfr_ratio = 8; cutoff_ratio = 16; }
+    if (bitrate < pcm_bitrate / cutoff_ratio) cutoff = umin(cutoff, cutoff_ratio * bitrate / (32 * channels));
+    uint32_t total = (uint32_t)round((double)cutoff * 256.0 / rate);
+    uint32_t hfr_start = umin(total, (uint32_t)round(((double)hfr_ratio * bitrate * 128.0) / pcm_bitrate));
+    uint32_t stereo_start = hfr_ratio == 6 ? hfr_start : (hfr_start + 1) / 2;
+    uint32_t hfr_bands = total - hfr_start, groups = 0;
+    uint32_t bpg = (uint32_t)div_round_up((int)hfr_bands, 8);
+    if (bpg > 0) groups = (uint32_t)div_round_up((int)hfr_bands, (int)bpg);
+    e.total_bands = total; e.base_bands = stereo_start; e.stereo_bands = hfr_start - stereo_start;
+    e.hfr_group_count = groups; e.bands_per_hfr_group = bpg;
+    if (bpg > 0) {
+        e.hfr_band_count = e.total_bands - e.base_bands - e.stereo_bands;
+        e.hfr_group_count = (uint32_t)div_round_up((int)e.hfr_band_count, (int)bpg);
+    }
+    if (channels > 8) return CRI_ERR_HCA_CHANNEL_CONFIG;
+    e.channel_config = HCA_DEFAULT_CHANNEL_CONFIG[channels];
+    if (HCA_VALID_CHANNEL_CONFIG[channels - 1][e.channel_config] != 1) return CRI_ERR_HCA_CHANNEL_CONFIG;
+    e.header_size = 96;
+    e.frame_count = (uint32_t)div_round_up((int)(spc + e.delay), 1024);
+    e.padding = e.frame_count * 1024 - e.delay - spc;
+    hca_channel_types(channels, 1, e.stereo_bands, e.channel_config, e.type);
+    for (uint32_t i = 0; i < channels; i++)
+        e.coded[i] = e.type[i] == CRI_CH_SECONDARY ? e.base_bands : e.base_bands + e.stereo_bands;
+    return 0;
+}
+
+void hca_pack_header(const HcaEncSetup& e, uint8_t* o) {      // hca.cpp:3109-3164 (no loop chunk)
+    memset(o, 0, e.header_size);
+    put_be32(o, 0x48434100u); put_be16(o + 4, 0x0200); put_be16(o + 6, e.header_size);
+    put_be32(o + 8, 0x666D7400u); put_be32(o + 12, e.rate); o[12] = (uint8_t)e.channels;
+    put_be32(o + 16, e.frame_count); put_be16(o + 20, e.delay); put_be16(o + 22, e.padding);
+    put_be32(o + 24, 0x636F6D70u); put_be16(o + 28, e.frame_size); o[30] = 1; o[31] = 15; o[32] = 1;
+    o[33] = (uint8_t)e.channel_config; o[34] = (uint8_t)e.total_bands; o[35] = (uint8_t)e.base_bands;
+    o[36] = (uint8_t)e.stereo_bands; o[37] = (uint8_t)e.bands_per_hfr_group;
+    put_be32(o + 40, 0x63697068u); put_be16(o + 44, 0);
+    put_be32(o + 46, 0x70616400u);
+    put_be16(o + e.header_size - 2, crc16(o, e.header_size - 2));
+}
+
+}  // namespace cri

@@ -1,0 +1,57 @@
+// cri_kernels.h -- launch interface between the job planner (cri_capi.cpp) and the gfx950 kernels (cri_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cri_types.h"
+
+namespace cri {
+
+struct HcaDecArgs {
+    const uint8_t* in;             // input blob (device)
+    uint8_t* out;                  // output blob (device)
+    uint8_t* scratch;              // frame records
+    int32_t* status;               // per item, may be null
+    const HcaFormat* formats;
+    const HcaStream* streams;      // sorted by format
+    const uint8_t* cipher_tables;  // [n_cipher][256]
+    const uint8_t* ath_tables;     // [n_ath][128]
+    uint32_t format;               // format index of this launch
+    uint32_t stream_begin, stream_end;   // streams of this format
+    uint32_t frames;               // total frames of this format group
+    uint32_t n_cipher;
+    uint32_t fpw;                  // frames per wave in the unpack kernel (power of two <= 64)
+    uint32_t rows;                 // ceil(frame_size / 4)
+    uint32_t unpack_lds;           // dynamic LDS bytes of the unpack kernel (hca_unpack_lds_bytes)
+    uint32_t channels;             // channel count of this format
+};
+size_t hca_unpack_lds_bytes(uint32_t frame_size, uint32_t channels, uint32_t n_cipher, uint32_t fpw);
+void launch_hca_unpack(const HcaDecArgs& a, hipStream_t s);
+void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);
+
+struct AdxArgs {
+    const uint8_t* in; uint8_t* out; int32_t* status;
+    const AdxStream* streams;
+    const uint32_t* chain_stream;  // per chain: stream index
+    const int16_t* history;        // 2 per chain
+    const uint8_t* stale;          // encode: header-image bytes that spill into the block area
+    uint32_t chains;
+};
+void launch_adx_decode(const AdxArgs& a, hipStream_t s);
+void launch_adx_encode(const AdxArgs& a, hipStream_t s);
+
+struct CryptArgs {
+    const uint8_t* in; uint8_t* out;
+    const HcaStream* streams;      // src_offset/dst_offset = first frame, frames, cipher index; format -> frame size table
+    const uint32_t* frame_sizes;   // per stream
+    const uint8_t* cipher_tables;
+    const uint32_t* first_frame;   // prefix over streams, n_streams + 1
+    uint32_t n_streams, frames;
+};
+void launch_hca_crypt(const CryptArgs& a, hipStream_t s);
+
+// copies n small byte images (headers) into the output blob: image i = img[img_off[i], img_off[i+1]) -> out + dst_off[i]
+void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const uint64_t* dst_off, uint32_t n, uint8_t* out, hipStream_t s);
+// copies item bodies verbatim (crypt: headers are patched on the host image, frames by the kernel)
+void launch_fill_i32(int32_t* p, int32_t v, uint32_t n, hipStream_t s);
+
+}  // namespace cri

@@ -1,0 +1,60 @@
+// cri_types.h -- plain structs shared by the host planner (cri_host.cpp / cri_capi.cpp) and the HIP kernels
+// (cri_kernels.hip).  Everything here is POD and is uploaded to HBM verbatim.
+#pragma once
+#include <stdint.h>
+
+enum { CRI_CH_DISCRETE = 0, CRI_CH_PRIMARY = 1, CRI_CH_SECONDARY = 2 };
+
+// ---- HCA ---------------------------------------------------------------------------------------------------
+// A "format" is everything in an HCA header that shapes the per-frame work (hca.cpp:80-174 clHCA header config).
+// Streams of one batch that share a format are decoded/encoded by the same launches.
+struct HcaFormat {
+    uint32_t channels, version, frame_size, min_res, max_res;
+    uint32_t total_bands, base_bands, stereo_bands, bands_per_hfr_group, hfr_group_count;
+    uint32_t ath_index;            // row of the ATH table array (row 0 is all zero = ath type 0)
+    uint32_t record_bytes;         // bytes of one frame's intermediate record in scratch (decode)
+    uint32_t hfr_band_count;       // encoder only (hca.cpp:2275)
+    uint32_t pad0;
+    uint8_t type[16];              // channel types (hca.cpp:887-970)
+    uint8_t coded[16];             // coded band count per channel (<=128)
+};
+
+struct HcaStream {
+    uint64_t src_offset;           // decode: first frame byte in the input blob; encode: first PCM byte
+    uint64_t dst_offset;           // decode: first PCM byte in the output blob; encode: first frame byte
+    uint64_t scratch_offset;       // decode: first frame record of this stream in scratch
+    uint32_t format;               // index into the format array
+    uint32_t cipher;               // index into the cipher table array
+    uint32_t frames;               // frames to process
+    uint32_t delay;                // decode: leading samples to drop (encoder_delay)
+    uint32_t samples;              // decode: samples per channel to emit; encode: input samples per channel
+    uint32_t item;                 // index of the batch item (for status reporting)
+    uint32_t first_frame;          // global frame number of this stream's frame 0 within its format group
+    uint32_t pad0;
+};
+
+// Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):
+//   int16 qc[8][C][128]  | uint8 scalefactors[C][128] | uint8 intensity[C][8] | uint32 tail[4]
+//   tail = { packed_noise_level, status (0 or CRI_ERR_HCA_FRAME), flags (bit c: channel c reuses intensity[1..7]), bits_read }
+static inline uint32_t hca_record_bytes(uint32_t channels) { return ((channels * (2048u + 128u + 8u) + 16u) + 15u) & ~15u; }
+#define HCA_REC_QC(C, sf, c) ((((sf) * (C)) + (c)) * 256u)
+#define HCA_REC_SF(C, c) ((C) * 2048u + (c) * 128u)
+#define HCA_REC_INT(C, c) ((C) * 2176u + (c) * 8u)
+#define HCA_REC_TAIL(C) ((C) * 2184u)
+
+// ---- ADX ---------------------------------------------------------------------------------------------------
+struct AdxStream {
+    uint64_t src_offset;           // decode: first block byte; encode: first PCM byte
+    uint64_t dst_offset;           // decode: first PCM byte; encode: first block byte
+    uint64_t src_end;              // decode: one past the last readable input byte of this item
+    uint32_t frames;               // block rows (one block per channel each)
+    uint32_t channels, blocksize, bitdepth, mode, samples_per_block;
+    int32_t coef0, coef1;
+    uint32_t samples;              // decode: samples per channel to emit; encode: valid input samples per channel
+    uint32_t filter_bits;          // encode, mode 2: filter << 13
+    uint32_t hist_offset;          // index of this stream's first entry in the per-chain history array
+    uint32_t item;
+    uint32_t first_chain;          // global chain number of channel 0
+    uint32_t stale_offset, stale_len; // encode: header image bytes that overlap the block area (OR-ed into first block bytes)
+    uint32_t pad0;
+};

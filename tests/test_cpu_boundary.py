@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/cricodecs_hip.h
+declares, and fails loudly (no CPU fallback) when there is no device.  No compute calls."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pycricodecs_amd import _capi, build
+    build.build(verbose=False)
+    return _capi
+
+
+def test_exports_match_header(capi):
+    hdr = open(os.path.join(ROOT, "include", "cricodecs_hip.h")).read()
+    declared = set(re.findall(r"\b(cri_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cri_job"}
+    L = capi.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(capi.SYMBOLS)
+
+
+def test_strerror_matches_reference_messages(capi):
+    assert capi.strerror(-1) == "Invalid ADX file header."
+    assert capi.strerror(-3) == "Encrypted ADX detected, unsupported."
+    assert capi.strerror(-17) == "Provided Bitdepth does not fit correctly with the provided BlockSize"
+    assert capi.strerror(-102) == "Invalid WAVE file header. Format info is not present."
+    assert capi.strerror(-201) == "Header decoding error, the header is not a valid HCA header."
+    assert capi.strerror(-202) == "Decoding error, either an incorrect key or an unknown exception."
+    with pytest.raises(NotImplementedError):
+        capi.raise_for(-3)
+    with pytest.raises(ValueError):
+        capi.raise_for(-9)
+    with pytest.raises(ValueError):
+        capi.raise_for(-213)
+
+
+def test_no_cpu_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("device present")
+    from pycricodecs_amd import ADX, HCA
+    import golden_util as G
+    with pytest.raises(capi.CriCodecsError) as e:
+        ADX.decode(G.load("s0_3008_2_48000_bd4_bs18_m3_v4.adx"))
+    assert e.value.code == -303
+    h = HCA(G.load("s0_3008_2_48000_q1.hca"))
+    assert h.info()["FrameSize"] == 682 and h.info()["ChannelCount"] == 2
+    with pytest.raises(capi.CriCodecsError):
+        h.decode()
+
+
+def test_front_end_header_walk():
+    import golden_util as G
+    from pycricodecs_amd import HCA
+    h = HCA(G.load("s0_3008_2_48000_q1.hca"))
+    i = h.info()
+    assert (i["version"], i["HeaderSize"], i["SampleRate"], i["FrameCount"], i["EncoderDelay"]) == ("0x200", 96, 48000, 4, 128)
+    assert (i["TotalBandCount"], i["BaseBandCount"], i["StereoBandCount"], i["CipherType"]) == (128, 128, 0, 0)
+    assert h.filetype == "hca" and not h.encrypted
+    frames = list(h.get_frames())
+    assert len(frames) == 4 and all(len(f) == 682 and f[:2] == b"\xff\xff" for _, f in frames)
+    w = HCA(G.load("s0_3008_2_48000.wav"))
+    assert w.filetype == "wav" and w.info()["fmtChannelCount"] == 2 and w.info()["dataSize"] == 3008 * 4
+    with pytest.raises(ValueError):
+        w.decode()
+    with pytest.raises(ValueError):
+        HCA(b"nonsense-bytes-here")
+    with pytest.raises(OverflowError):
+        HCA(G.load("s0_3008_2_48000_q1.hca"), key=1 << 64)

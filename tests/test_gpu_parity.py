@@ -1,0 +1,181 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors.
+Bit-exact for everything (ADX bytes/PCM, HCA PCM16, crypt bytes)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import hca_forge
+import oracle_lib as O
+from pycricodecs_amd import synth
+
+pytestmark = pytest.mark.gpu
+KEY = G.KEY
+MAN = G.manifest()
+
+
+@pytest.fixture(scope="module")
+def cc():
+    from pycricodecs_amd import CriCodecs, _capi
+    assert _capi.lib().cri_device_available() == 1, "no HIP device: the GPU tests must run on the HIP path"
+    return CriCodecs
+
+
+def diff(a, b):
+    if a == b:
+        return None
+    n = min(len(a), len(b))
+    idx = [i for i in range(n) if a[i] != b[i]][:8]
+    return "len %d vs %d, first diffs at %s" % (len(a), len(b), idx)
+
+
+# ------------------------------------------------------------------------------------------------ golden
+@pytest.mark.parametrize("case", MAN["cases"], ids=lambda c: c["wav"])
+def test_golden_adx(cc, case):
+    w = G.load(case["wav"])
+    for a in case["adx"]:
+        ref = G.load(a["file"])
+        bd, bs, mode, hp, filt, ver = a["params"]
+        assert diff(cc.AdxEncode(w, bd, bs, mode, hp, filt, ver, False), ref) is None, a["file"]
+        assert G.sha(cc.AdxDecode(ref)) == a["decoded_sha"], a["file"]
+
+
+@pytest.mark.parametrize("case", MAN["cases"], ids=lambda c: c["wav"])
+def test_golden_hca_decode_and_crypt(cc, case):
+    for h in case["hca"]:
+        ref = G.load(h["file"])
+        hs = int.from_bytes(ref[6:8], "big")
+        assert G.sha(cc.HcaDecode(ref, hs, 0, 0)) == h["decoded_sha"], h["file"]
+        enc = cc.HcaCrypt(ref, 1, hs, 56, KEY, 0)
+        assert G.sha(enc) == h["enc56_sha"]
+        assert G.sha(cc.HcaDecode(enc, hs, KEY, 0)) == h["enc56_decoded_sha"]
+        assert G.sha(cc.HcaCrypt(ref, 1, hs, 56, 0x1234567, 0x4321)) == h["enc56_sub_sha"]
+        assert G.sha(cc.HcaCrypt(ref, 1, hs, 1, 0, 0)) == h["enc1_sha"]
+        assert G.sha(cc.HcaCrypt(enc, 0, hs, 0, KEY, 0)) == h["dec_of_enc56_sha"]
+
+
+def test_golden_stored_decodes(cc):
+    h = G.load("s0_3008_2_48000_q1.hca")
+    assert diff(cc.HcaDecode(h, 96, 0, 0), G.load("s0_3008_2_48000_q1.decoded.wav")) is None
+    a = G.load("s0_3008_2_48000_bd4_bs18_m3_v4.adx")
+    assert diff(cc.AdxDecode(a), G.load("s0_3008_2_48000_bd4_bs18_m3_v4.decoded.wav")) is None
+
+
+# ------------------------------------------------------------------------------------------------ vs oracle, seeded
+@pytest.mark.parametrize("seed,n,ch,sr", [(0, 4800, 2, 48000), (1, 9600, 1, 44100), (3, 32, 2, 48000), (4, 48000, 2, 48000),
+                                            (5, 2048, 1, 8000), (6, 5000, 4, 48000), (7, 999, 2, 48000)])
+@pytest.mark.parametrize("bd,bs,mode,ver", [(4, 18, 3, 4), (4, 18, 4, 4), (4, 18, 2, 3), (8, 18, 3, 5), (2, 18, 3, 4), (6, 26, 3, 4),
+                                             (12, 26, 4, 4)])
+def test_adx_vs_oracle(cc, seed, n, ch, sr, bd, bs, mode, ver):
+    w = synth.wav(seed, n, ch, sr)
+    ref = O.adx_encode(w, bd, bs, mode, 500, 0, ver)
+    got = cc.AdxEncode(w, bd, bs, mode, 500, 0, ver, False)
+    assert diff(got, ref) is None
+    assert diff(cc.AdxDecode(ref), O.adx_decode(ref)) is None
+
+
+def test_adx_silence_clipping_truncation(cc):
+    z = np.zeros((3200, 2), dtype=np.int16)
+    z[1000:1100] = 32767
+    z[1100:1200] = -32768
+    z[2000:2032, 0] = np.arange(32) * 1000
+    w = synth.wav_bytes(z, 48000)
+    for mode in (2, 3, 4):
+        ref = O.adx_encode(w, 4, 18, mode)
+        assert diff(cc.AdxEncode(w, 4, 18, mode, 500, 0, 4, False), ref) is None
+        assert diff(cc.AdxDecode(ref), O.adx_decode(ref)) is None
+        cut = ref[:len(ref) // 2]                                  # truncated input: remaining rows decode to silence
+        assert diff(cc.AdxDecode(cut), O.adx_decode(cut)) is None
+
+
+@pytest.mark.parametrize("seed,n,ch,sr", [(0, 4800, 2, 48000), (1, 9600, 1, 44100), (2, 3008, 2, 22050), (3, 100, 2, 48000),
+                                            (4, 30000, 2, 32000), (6, 4096, 4, 48000), (7, 2500, 6, 48000)])
+@pytest.mark.parametrize("q", [0, 1, 2, 3])
+def test_hca_decode_vs_oracle(cc, seed, n, ch, sr, q):
+    w = synth.wav(seed, n, ch, sr)
+    hca = O.hca_encode(w, q)
+    hs = int.from_bytes(hca[6:8], "big")
+    assert diff(cc.HcaDecode(hca, hs, 0, 0), O.hca_decode(hca)) is None
+    enc = O.hca_crypt(hca, 1, 56, KEY)
+    assert diff(cc.HcaCrypt(hca, 1, hs, 56, KEY, 0), enc) is None
+    assert diff(cc.HcaDecode(enc, hs, KEY, 0), O.hca_decode(enc, KEY)) is None
+    assert diff(cc.HcaCrypt(enc, 0, hs, 0, KEY, 0), O.hca_crypt(enc, 0, 0, KEY)) is None
+
+
+def test_hca_decode_errors(cc):
+    hca = G.load("s0_3008_2_48000_q1.hca")
+    bad = bytearray(hca)
+    bad[300] ^= 0x55
+    with pytest.raises(ValueError, match="Decoding error"):
+        cc.HcaDecode(bytes(bad), 96, 0, 0)
+    enc = O.hca_crypt(hca, 1, 56, KEY)
+    with pytest.raises(ValueError, match="Decoding error"):
+        cc.HcaDecode(enc, 96, KEY + 2, 0)
+    with pytest.raises(ValueError, match="not a valid HCA header"):
+        cc.HcaDecode(b"HCA\x00" + bytes(200), 96, 0, 0)
+    with pytest.raises(ValueError, match="copyright"):
+        cc.AdxDecode(bytes([0x80, 0, 0, 0x2C, 3, 18, 4, 2]) + bytes(200))
+    with pytest.raises(ValueError, match="Bitdepth"):
+        cc.AdxEncode(synth.wav(0, 320, 2), 1, 18, 3, 500, 0, 4, False)
+
+
+@pytest.mark.parametrize("f", [x for x in MAN["forged"] if "v3min0" not in x["file"] and "fuzz_v3" not in x["file"]], ids=lambda f: f["file"])
+def test_forged_golden(cc, f):
+    data = G.load(f["file"])
+    assert G.sha(cc.HcaDecode(data, int.from_bytes(data[6:8], "big"), 0, 0)) == f["decoded_sha"]
+
+
+def test_hca_v2_random_frame_fuzz(cc):
+    """Random-byte frames: accepted/rejected exactly like the oracle, identical PCM when accepted
+    (exercises escape codes, out-of-range deltas, reads past the frame end, saturating conversions)."""
+    for q, ch in ((1, 2), (2, 2), (3, 2), (1, 1)):
+        base = O.hca_encode(synth.wav(0, 800, ch, 48000), q)
+        hs = int.from_bytes(base[6:8], "big")
+        for seed in range(24):
+            f = hca_forge.random_frames(base, seed, density=1.0 if seed % 2 else 0.35)
+            try:
+                ref = O.hca_decode(f)
+            except O.OracleError:
+                with pytest.raises(ValueError):
+                    cc.HcaDecode(f, hs, 0, 0)
+                continue
+            assert diff(cc.HcaDecode(f, hs, 0, 0), ref) is None, (q, ch, seed)
+
+
+# ------------------------------------------------------------------------------------------------ batch jobs
+def test_batch_mixed_formats(cc):
+    from pycricodecs_amd.batch import Job
+    items, keys, refs = [], [], []
+    for i, (n, ch, sr, q) in enumerate([(3000, 2, 48000, 1), (5000, 1, 44100, 1), (2048, 2, 48000, 2), (7000, 2, 48000, 3),
+                                        (1024, 2, 48000, 1), (300, 2, 22050, 0), (4000, 2, 48000, 1)]):
+        h = O.hca_encode(synth.wav(100 + i, n, ch, sr), q)
+        if i % 2:
+            h = O.hca_crypt(h, 1, 56, KEY + i)
+            keys.append(KEY + i)
+        else:
+            keys.append(0)
+        items.append(h)
+        refs.append(O.hca_decode(h, keys[-1]))
+    items.insert(3, b"garbage" * 30)
+    keys.insert(3, 0)
+    refs.insert(3, b"")
+    job = Job.hca_decode(items, keys=keys)
+    outs, status = job.run_host()
+    assert job.host_status[3] == -201 and status[3] == -201
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert diff(o, r) is None, i
+    assert job.units == sum(int.from_bytes(h[16:20], "big") for h in items if h[:3] == b"HCA" or h[:1] == b"\xc8")
+
+
+def test_batch_adx_roundtrip(cc):
+    from pycricodecs_amd.batch import Job
+    wavs = [synth.wav(200 + i, 320 * (i + 1), 1 + (i % 2), 48000) for i in range(9)]
+    enc = Job.adx_encode(wavs)
+    adx, st = enc.run_host()
+    assert not st.any()
+    for a, w in zip(adx, wavs):
+        assert diff(a, O.adx_encode(w)) is None
+    dec = Job.adx_decode(adx)
+    pcm, st = dec.run_host()
+    assert not st.any()
+    for p, a in zip(pcm, adx):
+        assert diff(p, O.adx_decode(a)) is None
