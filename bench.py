@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the ADX / HCA hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--workload hca_decode|adx_roundtrip]
+
+Default workload = BASELINE.json configs[2], the one north_star quotes its target on: HCA v2.0 decode of 10 000
+encrypted (key 0xCF222F1FE0748978) 48 kHz stereo streams of 10 s each (469 frames x 682 B per stream), inputs
+resident in HBM before the timed region.  A "step" is one pass of the decode path over the whole batch.  With
+N > 1 every rank decodes its own 10 000 streams (file-sharded, no data-path collective: weak scaling).
+
+The 10 000 streams are a tiling of `--unique` (default 64) distinct seeded streams produced by the CPU oracle
+(encode + encrypt); every copy occupies its own HBM, so the traffic is real.  Says so in "data".
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the launch stream
+inside the timed steps; `cpu_baseline` is the real reference (oracle/_ref/criref, single thread) when that binary
+travelled with the repo, else the C restatement ("port").
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+KEY = 0xCF222F1FE0748978
+HBM_PEAK_GBPS = 8000.0
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_hca_streams(unique, seconds, rank):
+    import oracle_lib as O
+    from pycricodecs_amd import synth
+    out = []
+    for u in range(unique):
+        w = synth.wav(1000 * rank + u, int(48000 * seconds) // 32 * 32, 2, 48000)
+        out.append(O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY))
+    return out
+
+
+def cpu_baseline_hca_decode(stream, seconds=10.0):
+    """Single-thread CPU decode of one of the workload's streams, repeated for ~`seconds`."""
+    frames = int.from_bytes(stream[16:20], "big")
+    tool = os.path.join(ROOT, "oracle", "_ref", "criref")
+    if os.path.exists(tool) and os.access(tool, os.X_OK):
+        with tempfile.NamedTemporaryFile(suffix=".hca", delete=False) as f:
+            f.write(stream)
+            path = f.name
+        try:
+            p = subprocess.run([tool, "bench", "hcadec", path, str(seconds), hex(KEY)], capture_output=True, text=True, timeout=seconds * 6 + 60)
+            reps, secs = p.stdout.split()
+            return {"value": round(int(reps) * frames / float(secs), 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+                    "sample": "%d x decode of one 10 s stream (%d frames) of this workload, reference C++ built from /root/reference (oracle/_ref/criref), single thread" % (int(reps), frames)}
+        except Exception as e:  # fall through to the port
+            log("criref bench failed:", e)
+        finally:
+            os.unlink(path)
+    import oracle_lib as O
+    t0 = time.time()
+    reps = 0
+    while time.time() - t0 < seconds:
+        O.hca_decode(stream, KEY)
+        reps += 1
+    secs = time.time() - t0
+    return {"value": round(reps * frames / secs, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d x decode of one 10 s stream (%d frames), oracle/cri_oracle.c, single thread" % (reps, frames)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=10000)
+    ap.add_argument("--unique", type=int, default=64)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "adx_roundtrip"])
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from pycricodecs_amd.batch import Job
+    from pycricodecs_amd import synth
+
+    t_setup = time.time()
+    extra = {}
+    if args.workload == "hca_decode":
+        uniq = make_hca_streams(args.unique, args.seconds, rank)
+        items = [uniq[i % len(uniq)] for i in range(args.streams)]
+        job = Job.hca_decode(items, keys=[KEY] * len(items))
+        metric_cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality High, frame 682 B, key 0xCF222F1FE0748978) per GPU"
+                      % (args.streams, args.seconds), "streams_per_gpu": args.streams, "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
+                      "unique_streams": len(uniq), "parallelism": "file-sharded x%d, no collective" % world}
+        unit_bytes = "frame_size + 2*1024*channels = 682 + 4096 = 4778 B per frame"
+    else:
+        import oracle_lib as O
+        wavs_u = [synth.wav(1000 * rank + u, int(48000 * args.seconds) // 32 * 32, 2, 48000) for u in range(args.unique)]
+        wavs = [wavs_u[i % len(wavs_u)] for i in range(args.streams)]
+        job = Job.adx_encode(wavs)
+        metric_cfg = {"workload": "BASELINE configs[1]: ADX encode (bs18/bd4/mode3/v4), %d 48 kHz stereo WAVs x %.0f s per GPU" % (args.streams, args.seconds),
+                      "chains": 2 * args.streams, "parallelism": "file-sharded x%d, no collective" % world}
+        unit_bytes = "blocksize + 2*samples_per_block = 18 + 64 = 82 B per block"
+    assert not job.host_status.any(), "synthetic inputs rejected at the header stage"
+    d_in, d_out, d_scratch, d_status = job.alloc(dev)
+    job.enable_events(True)
+    torch.cuda.synchronize()
+    log("setup %.1fs: %d items, %.2f GB in, %.2f GB out, %.2f GB scratch, %d units" %
+        (time.time() - t_setup, job.n, job.input_bytes / 1e9, job.output_bytes / 1e9, job.scratch_bytes / 1e9, job.units))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.run(d_in, d_out, d_scratch, d_status)
+    barrier()
+    kernel_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.run(d_in, d_out, d_scratch, d_status)
+        # event read-out waits only for this step's own kernels; it is part of the measured time
+        for k, v in job.event_ms().items():
+            kernel_ms[k] = kernel_ms.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    bad = int((d_status != 0).sum().item())
+    assert bad == 0, "%d items failed on the device" % bad
+
+    # cheap end-to-end check outside the timed region: item 0 equals the oracle's decode
+    if args.workload == "hca_decode":
+        import oracle_lib as O
+        n0 = int(job.output_offsets[1])
+        got = bytes(d_out[:n0].cpu().numpy())
+        ref = O.hca_decode(items[0], KEY)
+        assert got[:len(ref)] == ref, "GPU output differs from the oracle"
+
+    units = job.units
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = units * world / (elapsed / args.steps)
+    dom = max(kernel_ms, key=kernel_ms.get)
+    dom_ms = kernel_ms[dom] / args.steps
+    achieved = job.algorithmic_bytes / (dom_ms * 1e-3) / 1e9
+    out = {
+        "metric": "audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.workload == "hca_decode" else "int32", "data": "synthetic (seeded sines+noise; %d unique streams tiled to %d, each copy in its own HBM)" % (args.unique, args.streams),
+        "config": metric_cfg,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "algorithmic_bytes_per_launch": job.algorithmic_bytes, "bytes_per_unit": unit_bytes,
+                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kernel_ms.items()}},
+    }
+    if rank == 0 and not args.no_cpu:
+        if args.workload == "hca_decode":
+            out["cpu_baseline"] = cpu_baseline_hca_decode(items[0])
+        else:
+            out["cpu_baseline"] = None
+    if rank == 0:
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,8 +50,7 @@ class Job:
     @staticmethod
     def _blob_args(items):
         blob, offs = pack(items)
-        buf = C.create_string_buffer(blob, len(blob)) if blob else C.create_string_buffer(1)
-        return blob, offs, buf
+        return blob, offs, (blob if blob else b"\0")      # bytes are passed by pointer, no copy
 
     @classmethod
     def _finish(cls, rc, h, blob, offs):
@@ -118,12 +117,21 @@ class Job:
         if rc:
             _capi.raise_for(rc)
 
+    def enable_events(self, on=True):
+        _capi.lib().cri_job_enable_events(self._h, 1 if on else 0)
+
+    def event_ms(self):
+        """{kernel class name: milliseconds of the last run} (waits for that run)."""
+        ms = (C.c_float * 4)()
+        names = (C.c_char_p * 4)()
+        n = _capi.lib().cri_job_event_ms(self._h, ms, names, 4)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
     def run_host(self):
         """Upload, run, download: returns (list of output bytes per item, status int32[n])."""
         out = C.POINTER(C.c_uint8)()
         status = (C.c_int32 * max(self.n, 1))()
-        buf = C.create_string_buffer(self.blob, len(self.blob)) if self.blob else C.create_string_buffer(1)
-        rc = _capi.lib().cri_job_run_host(self._h, buf, C.byref(out), status)
+        rc = _capi.lib().cri_job_run_host(self._h, self.blob if self.blob else b"\0", C.byref(out), status)
         if rc:
             _capi.raise_for(rc)
         blob = C.string_at(out, self.output_bytes)

@@ -57,6 +57,25 @@ struct cri_job {
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
     std::vector<EncLaunch> hca_enc;
     uint32_t n_cipher = 0;
+    // optional per-kernel-class event timing
+    bool events_on = false;
+    std::vector<std::string> class_names;
+    std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> class_events;   // [class][launch]
+    std::vector<size_t> class_used;
+    void begin_run() { class_used.assign(class_names.size(), 0); }
+    hipEvent_t mark(size_t cls, bool start, hipStream_t s) {
+        if (!events_on) return nullptr;
+        auto& v = class_events[cls];
+        if (start) {
+            if (class_used[cls] == v.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); v.push_back({a, b}); }
+            (void)hipEventRecord(v[class_used[cls]].first, s);
+            return v[class_used[cls]].first;
+        }
+        (void)hipEventRecord(v[class_used[cls]].second, s);
+        class_used[cls]++;
+        return nullptr;
+    }
+    ~cri_job() { for (auto& v : class_events) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
 
     int upload_images() {
         std::vector<uint8_t> blob; std::vector<uint64_t> off{0}, dst;
@@ -424,6 +443,7 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
     if (!j || !d_in || (!d_out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
     if (j->scratch_bytes && !d_scratch) return CRI_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)hip_stream;
+    if (j->events_on) j->begin_run();
     if (d_status) launch_fill_i32(d_status, 0, j->n, s);
     if (j->n_images)
         launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, (uint8_t*)d_out, s);
@@ -433,8 +453,8 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
                 a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.scratch = (uint8_t*)d_scratch; a.status = d_status;
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p;
-                launch_hca_unpack(a, s);
-                launch_hca_transform(a, s);
+                j->mark(0, true, s); launch_hca_unpack(a, s); j->mark(0, false, s);
+                j->mark(1, true, s); launch_hca_transform(a, s); j->mark(1, false, s);
             }
             break;
         case CRI_JOB_ADX_DECODE:
@@ -443,7 +463,9 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status;
             a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
             a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p;
+            j->mark(0, true, s);
             if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode(a, s); else launch_adx_encode(a, s);
+            j->mark(0, false, s);
             break;
         }
         case CRI_JOB_HCA_CRYPT: {
@@ -451,12 +473,40 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.streams = (const HcaStream*)j->d_streams.p;
             a.frame_sizes = (const uint32_t*)j->d_frame_sizes.p; a.cipher_tables = (const uint8_t*)j->d_cipher.p;
             a.first_frame = (const uint32_t*)j->d_first_frame.p;
-            launch_hca_crypt(a, s);
+            j->mark(0, true, s); launch_hca_crypt(a, s); j->mark(0, false, s);
             break;
         }
         default: return CRI_ERR_UNSUPPORTED;
     }
     return hipGetLastError() == hipSuccess ? 0 : CRI_ERR_HIP;
+}
+
+extern "C" int cri_job_enable_events(cri_job* j, int on) {
+    if (!j) return CRI_ERR_INVALID_ARG;
+    if (j->class_names.empty()) {
+        if (j->kind == CRI_JOB_HCA_DECODE) j->class_names = {"k_hca_unpack", "k_hca_transform"};
+        else j->class_names = {j->dominant};
+        j->class_events.resize(j->class_names.size());
+        j->class_used.assign(j->class_names.size(), 0);
+    }
+    j->events_on = on != 0;
+    return 0;
+}
+
+extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int max_classes) {
+    if (!j || !ms) return CRI_ERR_INVALID_ARG;
+    int n = (int)j->class_names.size();
+    for (int c = 0; c < n && c < max_classes; c++) {
+        float total = 0.f;
+        for (size_t k = 0; k < j->class_used[c]; k++) {
+            float t = 0.f;
+            (void)hipEventSynchronize(j->class_events[c][k].second);
+            if (hipEventElapsedTime(&t, j->class_events[c][k].first, j->class_events[c][k].second) == hipSuccess) total += t;
+        }
+        ms[c] = total;
+        if (names) names[c] = j->class_names[c].c_str();
+    }
+    return n;
 }
 
 extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_blob, int32_t* status) {

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64) void k_hca_unpack(HcaDecArgs a) {
 
     // which frame does this lane own
     const uint32_t g = blockIdx.x * W + lane;
-    const bool valid = lane < W && g < a.frames;
+    const bool active = lane < W;          // lanes beyond the frames-per-wave count only help with staging / flushing
+    const bool valid = active && g < a.frames;
     uint32_t si = a.stream_begin, f = 0;
     if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
     const HcaStream st = a.streams[si];
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64) void k_hca_unpack(HcaDecArgs a) {
         uint32_t cs = coded, extra = 0;
         if (!(type == CRI_CH_SECONDARY || groups == 0 || F.version <= 0x0200)) { extra = groups; cs += extra; }
         // zero the scalefactor staging rows (32 words per lane)
-        for (uint32_t r = 0; r < 32; r++) ostage[r * (W + 1) + lane] = 0;
+        if (active) for (uint32_t r = 0; r < 32; r++) ostage[r * (W + 1) + lane] = 0;
         uint8_t* sfst = (uint8_t*)ostage;
         const bool live = valid && status == 0;
         uint32_t db = 0, value = 0;
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(64) void k_hca_unpack(HcaDecArgs a) {
                 }
                 value = v;
             }
-            sfst[((i >> 2) * (W + 1) + lane) * 4 + (i & 3)] = (uint8_t)v;
-            if (i < coded) {                                      // calculate_resolution, hca.cpp:1450-1488
+            if (active) sfst[((i >> 2) * (W + 1) + lane) * 4 + (i & 3)] = (uint8_t)v;
+            if (i < coded && active) {                                      // calculate_resolution, hca.cpp:1450-1488
                 uint32_t res = 0;
                 if (v > 0) {
                     int noise = (int)ath[i] + (int)((packed + i) >> 8);
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(64) void k_hca_unpack(HcaDecArgs a) {
         // derived HFR scales of v3.0 (hca.cpp:1353-1355); the entry one past the coded+extra range reads as 0
         for (uint32_t i = 0; i < extra; i++) {
             uint32_t srci = cs - i;
-            uint8_t sv = srci < cs ? sfst[((srci >> 2) * (W + 1) + lane) * 4 + (srci & 3)] : 0;
+            uint8_t sv = (srci < cs && active) ? sfst[((srci >> 2) * (W + 1) + lane) * 4 + (srci & 3)] : 0;
             uint32_t di = 127 - i;
-            sfst[((di >> 2) * (W + 1) + lane) * 4 + (di & 3)] = sv;
+            if (active) sfst[((di >> 2) * (W + 1) + lane) * 4 + (di & 3)] = sv;
         }
         // unpack_intensity, hca.cpp:1361-1441
         uint32_t inten_lo = 0, inten_hi = 0;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(64) void k_hca_unpack(HcaDecArgs a) {
                 uint32_t v = 0;
                 if (valid && status == 0) { v = hca_peek(rows, W, lane, pos, 6, size_bits); pos += 6; }
                 uint32_t di = 128 - groups + k;
-                sfst[((di >> 2) * (W + 1) + lane) * 4 + (di & 3)] = (uint8_t)v;
+                if (active) sfst[((di >> 2) * (W + 1) + lane) * 4 + (di & 3)] = (uint8_t)v;
             }
         }
         if (valid) { uint32_t* ip = (uint32_t*)(rec + HCA_REC_INT(C, c)); ip[0] = inten_lo; ip[1] = inten_hi; }
@@ -304,10 +305,10 @@ __global__ __launch_bounds__(64) void k_hca_unpack(HcaDecArgs a) {
                         val = cval[idx];
                     }
                 }
-                if (i & 1) { word |= (uint32_t)(uint16_t)(int16_t)val << 16; ostage[(i >> 1) * (W + 1) + lane] = word; }
+                if (i & 1) { word |= (uint32_t)(uint16_t)(int16_t)val << 16; if (active) ostage[(i >> 1) * (W + 1) + lane] = word; }
                 else word = (uint32_t)(uint16_t)(int16_t)val;
             }
-            if (coded & 1) ostage[(coded >> 1) * (W + 1) + lane] = word;
+            if ((coded & 1) && active) ostage[(coded >> 1) * (W + 1) + lane] = word;
             const uint32_t nwords = (coded + 1) >> 1;
             __syncthreads();
             for (uint32_t fr = 0; fr < W; fr++) {

@@ -70,7 +70,14 @@ def test_adx_vs_oracle(cc, seed, n, ch, sr, bd, bs, mode, ver):
     ref = O.adx_encode(w, bd, bs, mode, 500, 0, ver)
     got = cc.AdxEncode(w, bd, bs, mode, 500, 0, ver, False)
     assert diff(got, ref) is None
-    assert diff(cc.AdxDecode(ref), O.adx_decode(ref)) is None
+    try:
+        want = O.adx_decode(ref)
+    except O.OracleError as e:             # e.g. zero-frame files: the 7-byte "(c)CRI" check hits the 80 01 trailer
+        with pytest.raises(ValueError):
+            cc.AdxDecode(ref)
+        assert e.code == -9
+        return
+    assert diff(cc.AdxDecode(ref), want) is None
 
 
 def test_adx_silence_clipping_truncation(cc):
@@ -113,7 +120,7 @@ def test_hca_decode_errors(cc):
     with pytest.raises(ValueError, match="not a valid HCA header"):
         cc.HcaDecode(b"HCA\x00" + bytes(200), 96, 0, 0)
     with pytest.raises(ValueError, match="copyright"):
-        cc.AdxDecode(bytes([0x80, 0, 0, 0x2C, 3, 18, 4, 2]) + bytes(200))
+        cc.AdxDecode(bytes([0x80, 0, 0, 0x2C, 3, 18, 4, 2, 0, 0, 0xBB, 0x80, 0, 0, 0, 64, 1, 0xF4, 4, 0]) + bytes(200))
     with pytest.raises(ValueError, match="Bitdepth"):
         cc.AdxEncode(synth.wav(0, 320, 2), 1, 18, 3, 500, 0, 4, False)
 
