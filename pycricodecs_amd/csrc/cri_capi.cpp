@@ -249,15 +249,17 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         HcaDecArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
         a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
-        uint32_t fpw = 64;
-        while (fpw > 1 && hca_unpack_lds_bytes(F.frame_size, F.channels, j->n_cipher, fpw) > 80 * 1024) fpw >>= 1;
-        if (hca_unpack_lds_bytes(F.frame_size, F.channels, j->n_cipher, fpw) > 160 * 1024) {
-            for (size_t s = b; s < e; s++) j->host_status[streams[s].item] = CRI_ERR_UNSUPPORTED;
-            a.frames = 0;
-        }
-        a.fpw = fpw; a.unpack_lds = (uint32_t)hca_unpack_lds_bytes(F.frame_size, F.channels, j->n_cipher, fpw);
+        a.prep_chunk_rows = std::min<uint32_t>(a.rows, 176);          // <= 44 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
         b = e;
+    }
+    // word tiles and per-frame prepare status of every format group follow the frame records
+    for (auto& a : j->hca_dec) {
+        scratch = align_up(scratch, 256);
+        a.tile_offset = scratch;
+        scratch += (uint64_t)((a.frames + 63) / 64) * (a.rows + 1) * 256;
+        a.fstat_offset = scratch;
+        scratch += align_up((uint64_t)a.frames * 4, 256);
     }
     j->scratch_bytes = scratch;
     int rc = 0;
@@ -453,8 +455,9 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
                 a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.scratch = (uint8_t*)d_scratch; a.status = d_status;
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p;
-                j->mark(0, true, s); launch_hca_unpack(a, s); j->mark(0, false, s);
-                j->mark(1, true, s); launch_hca_transform(a, s); j->mark(1, false, s);
+                j->mark(0, true, s); launch_hca_prepare(a, s); j->mark(0, false, s);
+                j->mark(1, true, s); launch_hca_parse(a, s); j->mark(1, false, s);
+                j->mark(2, true, s); launch_hca_transform(a, s); j->mark(2, false, s);
             }
             break;
         case CRI_JOB_ADX_DECODE:
@@ -484,7 +487,7 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
 extern "C" int cri_job_enable_events(cri_job* j, int on) {
     if (!j) return CRI_ERR_INVALID_ARG;
     if (j->class_names.empty()) {
-        if (j->kind == CRI_JOB_HCA_DECODE) j->class_names = {"k_hca_unpack", "k_hca_transform"};
+        if (j->kind == CRI_JOB_HCA_DECODE) j->class_names = {"k_hca_prepare", "k_hca_parse", "k_hca_transform"};
         else j->class_names = {j->dominant};
         j->class_events.resize(j->class_names.size());
         j->class_used.assign(j->class_names.size(), 0);

@@ -19,13 +19,16 @@ struct HcaDecArgs {
     uint32_t stream_begin, stream_end;   // streams of this format
     uint32_t frames;               // total frames of this format group
     uint32_t n_cipher;
-    uint32_t fpw;                  // frames per wave in the unpack kernel (power of two <= 64)
-    uint32_t rows;                 // ceil(frame_size / 4)
-    uint32_t unpack_lds;           // dynamic LDS bytes of the unpack kernel (hca_unpack_lds_bytes)
+    uint32_t rows;                 // R = ceil(frame_size / 4): words per frame
+    uint32_t prep_chunk_rows;      // rows staged per pass in k_hca_prepare
     uint32_t channels;             // channel count of this format
+    uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][R+1][64] uint32 (big-endian words)
+    uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
 };
-size_t hca_unpack_lds_bytes(uint32_t frame_size, uint32_t channels, uint32_t n_cipher, uint32_t fpw);
-void launch_hca_unpack(const HcaDecArgs& a, hipStream_t s);
+size_t hca_prepare_lds_bytes(uint32_t chunk_rows, uint32_t n_cipher);
+size_t hca_parse_lds_bytes(uint32_t channels);
+void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s);
+void launch_hca_parse(const HcaDecArgs& a, hipStream_t s);
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);
 
 struct AdxArgs {
