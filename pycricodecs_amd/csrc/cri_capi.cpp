@@ -249,7 +249,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         HcaDecArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
         a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
-        a.prep_chunk_rows = std::min<uint32_t>(a.rows, 176);          // <= 44 KB of LDS per prepare wave
+        a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
         b = e;
     }
@@ -260,6 +260,8 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         scratch += (uint64_t)((a.frames + 63) / 64) * (a.rows + 1) * 256;
         a.fstat_offset = scratch;
         scratch += align_up((uint64_t)a.frames * 4, 256);
+        a.resg_offset = scratch;
+        scratch += (uint64_t)((a.frames + 63) / 64) * a.channels * 8 * 64 * 8;
     }
     j->scratch_bytes = scratch;
     int rc = 0;

@@ -112,62 +112,115 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 // k_hca_parse: one lane per frame
 // ------------------------------------------------------------------------------------------------------------
-// LDS per wave: ostage uint32[32][65] (per-lane output words, transposed on flush), resb uint8[C*64][64]
-// (two 4-bit resolutions per byte), recptr uint64[64], curve->resolution table.
-size_t hca_parse_lds_bytes(uint32_t channels) { return (size_t)32 * 65 * 4 + (size_t)channels * 64 * 64 + 64 * 8 + 80 + 16; }
+// LDS per wave (8.9 KB): ostage uint32[16][65] (per-lane output words, transposed on flush), recoff uint64[64],
+// curve->resolution table, bit-feed ring uint32[RING_WORDS][64].  The per-band resolutions (4 bits each) live in the
+// tile's `resg` area of scratch: one uint64 (16 bands) per lane and 16-band block, written once by the scalefactor pass
+// and re-read (coalesced, L2-resident) by each of the 8 subframes.
+//
+// Bit feed.  HBM latency under load is microseconds and the parse is an in-order serial chain, so words travel
+//   tile (global) --bulk request at a checkpoint--> VGPRs --landed at the NEXT checkpoint--> per-lane LDS ring
+//   --one word prefetched per symbol--> 64-bit shift register.
+// Checkpoints sit every 16 symbols (at most 16*12 bits = 6 words consumed in between); a checkpoint requests up to
+// FEED_MAX = 6 words to refill the ring to RING_WORDS = 16, so after landing the ring always holds >= 10 words.
+#define RING_WORDS 16
+#define FEED_MAX 6
+size_t hca_parse_lds_bytes(uint32_t channels) { (void)channels; return (size_t)16 * 65 * 4 + 64 * 8 + 96 + (size_t)RING_WORDS * 256; }
 
+struct BitFeed {
+    const uint32_t* next;    // next word of this lane in the tile (stride 64 words)
+    int rows_left;           // words not yet requested from the tile
+    uint32_t* ring;          // LDS ring base of this lane (slot stride 64 words)
+    uint32_t wr;             // words landed in the ring
+    uint32_t nfl;            // words in flight
+    uint32_t fl[FEED_MAX];
+};
 struct BitBuf {
     uint64_t buf;            // next bits, MSB aligned
     int avail;               // valid bits in buf
     int pos;                 // absolute bit position in the frame (hca.cpp clData.bit)
     int size;                // frame size in bits
-    const uint32_t* next;    // next word of this lane in the tile (stride 64 words)
-    uint32_t pw;             // prefetched word
-    int rows_left;
+    uint32_t rd;             // index of the next ring word to move into pw
+    uint32_t pw, nw;         // w[rd-1] (not yet merged), w[rd] (LDS read issued one step earlier)
 };
-__device__ __forceinline__ void bb_refill(BitBuf& b) {
-    if (b.avail <= 32) {
-        b.buf |= (uint64_t)b.pw << (32 - b.avail);
-        b.avail += 32;
-        if (b.rows_left > 0) { b.pw = *b.next; b.next += 64; b.rows_left--; } else b.pw = 0;
-    }
+
+__device__ __forceinline__ void feed_checkpoint(BitFeed& f, const BitBuf& b) {
+#pragma unroll
+    for (uint32_t k = 0; k < FEED_MAX; k++) if (k < f.nfl) f.ring[((f.wr + k) & (RING_WORDS - 1)) * 64] = f.fl[k];
+    f.wr += f.nfl;
+    const uint32_t room = RING_WORDS - (f.wr - b.rd);
+    const uint32_t n = room < FEED_MAX ? room : FEED_MAX;
+#pragma unroll
+    for (uint32_t k = 0; k < FEED_MAX; k++) if (k < n) f.fl[k] = (int)k < f.rows_left ? f.next[k * 64] : 0u;
+    const int adv = (int)n < f.rows_left ? (int)n : f.rows_left;
+    f.next += (size_t)adv * 64; f.rows_left -= adv;
+    f.nfl = n;
 }
-// MSB-first peek of n (0..12) bits with the reference reader's end-of-frame behaviour (hca.cpp:225-281): 0 when the
-// read crosses the frame end; and 0 when fewer than 24 (16) bits are left but the read spans more than 16 (8) bits
+// one refill opportunity per symbol; branch-free, the LDS read issued here is consumed by the NEXT call
+__device__ __forceinline__ void bb_refill(BitBuf& b, const uint32_t* ring) {
+    const bool need = b.avail <= 32;
+    const uint64_t add = (uint64_t)b.pw << (need ? 32 - b.avail : 0);
+    b.buf |= need ? add : 0ull;
+    b.avail += need ? 32 : 0;
+    b.pw = need ? b.nw : b.pw;
+    b.rd += need ? 1u : 0u;
+    b.nw = ring[(b.rd & (RING_WORDS - 1)) * 64];
+}
+// MSB-first peek of n (0..12) bits.  CHECKED = the reference reader's end-of-frame behaviour (hca.cpp:225-281): 0 when
+// the read crosses the frame end; and 0 when fewer than 24 (16) bits are left but the read spans more than 16 (8) bits
 // from its byte start -- the reference then serves it from a window that is too narrow (its shift count wraps).
+template <bool CHECKED>
 __device__ __forceinline__ uint32_t bb_peek(const BitBuf& b, int n) {
+    const uint32_t v = ((uint32_t)(b.buf >> 32) >> 1) >> (31 - n);          // n == 0 gives 0
+    if (!CHECKED) return v;
     const int left = b.size - b.pos;
-    uint32_t v = n ? (uint32_t)(b.buf >> (64 - n)) : 0u;
-    if (n > left) v = 0;
-    else if (left < 24) {
-        const int off = n + (b.pos & 7);
-        if (off >= 17 || (off >= 9 && left < 16)) v = 0;
-    }
-    return v;
+    const int off = n + (b.pos & 7);
+    const bool zero = (n > left) | ((left < 24) & ((off >= 17) | ((off >= 9) & (left < 16))));
+    return zero ? 0u : v;
 }
 __device__ __forceinline__ void bb_skip(BitBuf& b, int n) { b.buf <<= n; b.avail -= n; b.pos += n; }
-__device__ __forceinline__ uint32_t bb_read(BitBuf& b, int n) { bb_refill(b); uint32_t v = bb_peek(b, n); bb_skip(b, n); return v; }
+__device__ __forceinline__ uint32_t bb_read(BitBuf& b, const uint32_t* ring, int n) { bb_refill(b, ring); uint32_t v = bb_peek<true>(b, n); bb_skip(b, n); return v; }
 
-// transposed flush of the 32 staged words of every lane: frame fr's 32 words go to recptr[fr] + byte_off, 128 B per frame
-__device__ __forceinline__ void flush32(const uint32_t* ostage, const uint64_t* recptr, uint32_t lane, uint32_t byte_off, uint32_t nwords) {
+// one spectral symbol of resolution `res` (hca.cpp:1546-1563): returns the quantised value, advances the reader
+template <bool CHECKED>
+__device__ __forceinline__ int parse_symbol(BitBuf& bb, const uint32_t* ring, uint32_t res) {
+    const int bits = res > 7 ? (int)res - 3 : (int)((0x44443320u >> (res * 4)) & 15);   // hcatbdecoder_max_bit_table
+    bb_refill(bb, ring);
+    const uint32_t code = bb_peek<CHECKED>(bb, bits);
+    // res > 7: sign-magnitude (low bit = sign), a zero gives its sign bit back
+    const int mag = (int)(code >> 1);
+    const int valA = (code & 1) ? -mag : mag;
+    const int lenA = bits - (mag == 0 ? 1 : 0);
+    // res <= 7: truncated-binary prefix code over the alphabet 0,+1,-1,...,+res,-res
+    const uint32_t nshort = (1u << bits) - (2 * res + 1);
+    const bool is_short = code < 2 * nshort;
+    const uint32_t sym = is_short ? (code >> 1) : (code - nshort);
+    const int lenB = bits - ((is_short && bits) ? 1 : 0);
+    const int valB = (sym & 1) ? (int)((sym + 1) >> 1) : -(int)(sym >> 1);
+    bb_skip(bb, res > 7 ? lenA : lenB);
+    return res > 7 ? valA : valB;
+}
+
+// transposed flush of the 16 staged words of every lane: frame fr's words go to its record + byte_off, 64 B per frame
+__device__ __forceinline__ void flush16(const uint32_t* ostage, const uint64_t* recoff, uint8_t* scratch, uint32_t lane, uint32_t byte_off, uint32_t nwords) {
     __syncthreads();
-    const uint32_t w = lane & 31;
-    for (uint32_t it = 0; it < 32; it++) {
-        const uint32_t fr = it * 2 + (lane >> 5);
-        const uint64_t rp = recptr[fr];
-        if (rp && w < nwords) ((uint32_t*)(rp + byte_off))[w] = ostage[w * 65 + fr];
+    const uint32_t w = lane & 15;
+#pragma unroll 4
+    for (uint32_t it = 0; it < 16; it++) {
+        const uint32_t fr = it * 4 + (lane >> 4);
+        const uint64_t ro = recoff[fr];
+        if (ro != ~0ull && w < nwords) ((uint32_t*)(scratch + ro + byte_off))[w] = ostage[w * 65 + fr];
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void k_hca_parse(HcaDecArgs a) {
+__global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const HcaFormat& F = a.formats[a.format];
     const uint32_t R = a.rows, C = F.channels, lane = threadIdx.x, tile = blockIdx.x;
     uint32_t* ostage = (uint32_t*)smem;
-    uint8_t* resb = smem + 32 * 65 * 4;
-    uint64_t* recptr = (uint64_t*)(resb + (size_t)C * 64 * 64);
-    uint8_t* curve = (uint8_t*)(recptr + 64);
+    uint64_t* recoff = (uint64_t*)(smem + 16 * 65 * 4);
+    uint8_t* curve = (uint8_t*)(recoff + 64);          // 96 bytes reserved, the ring follows
+    uint32_t* ring = (uint32_t*)(curve + 96) + lane;
     for (uint32_t i = lane; i < 66; i += 64) curve[i] = HCA_CURVE_TO_RES[i];
 
     const uint32_t g = tile * 64 + lane;
@@ -175,20 +228,25 @@ __global__ __launch_bounds__(64) void k_hca_parse(HcaDecArgs a) {
     uint32_t si = a.stream_begin, f = 0;
     if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
     const HcaStream st = a.streams[si];
-    uint8_t* rec = a.scratch + st.scratch_offset + (uint64_t)f * F.record_bytes;
-    recptr[lane] = valid ? (uint64_t)rec : 0;
+    const uint64_t ro = st.scratch_offset + (uint64_t)f * F.record_bytes;
+    uint8_t* rec = a.scratch + ro;
+    recoff[lane] = valid ? ro : ~0ull;
     int status = valid ? ((const int32_t*)(a.scratch + a.fstat_offset))[g] : 0;
+    // every lane parses (frames that failed sync/CRC and the zero padding of the last tile parse to ignored output)
+    uint64_t* resg = (uint64_t*)(a.scratch + a.resg_offset) + (uint64_t)tile * C * 8 * 64 + lane;
 
+    BitFeed fd;
+    fd.next = (const uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64 + lane;
+    fd.rows_left = (int)R + 1; fd.ring = ring; fd.wr = 0; fd.nfl = 0;
     BitBuf bb;
-    bb.buf = 0; bb.avail = 0; bb.pos = 0; bb.size = (int)F.frame_size * 8;
-    bb.next = (const uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64 + lane;
-    bb.rows_left = (int)R + 1;
-    bb.pw = *bb.next; bb.next += 64; bb.rows_left--;
-    bb_refill(bb); bb_refill(bb);
+    bb.buf = 0; bb.avail = 0; bb.pos = 0; bb.size = (int)F.frame_size * 8; bb.rd = 0; bb.pw = 0; bb.nw = 0;
+    feed_checkpoint(fd, bb); feed_checkpoint(fd, bb); feed_checkpoint(fd, bb);   // prime: 12 words landed, 4 in flight
+    bb.pw = ring[0]; bb.rd = 1; bb.nw = ring[64];
+    bb_refill(bb, ring); bb_refill(bb, ring);
     bb_skip(bb, 16);                                             // sync word, checked by k_hca_prepare
     uint32_t packed = 0, flags = 0;
     {
-        uint32_t nl = bb_read(bb, 9), eb = bb_read(bb, 7);       // hca.cpp:1175-1178
+        const uint32_t nl = bb_read(bb, ring, 9), eb = bb_read(bb, ring, 7);   // hca.cpp:1175-1178
         packed = (nl << 8) - eb;
     }
     const uint8_t* ath = a.ath_tables + F.ath_index * 128;
@@ -198,123 +256,129 @@ __global__ __launch_bounds__(64) void k_hca_parse(HcaDecArgs a) {
         const uint32_t coded = F.coded[c], type = F.type[c], groups = F.hfr_group_count;
         uint32_t cs = coded, extra = 0;
         if (!(type == CRI_CH_SECONDARY || groups == 0 || F.version <= 0x0200)) { extra = groups; cs += extra; }
-        for (uint32_t r = 0; r < 32; r++) ostage[r * 65 + lane] = 0;
-        const bool live = valid && status == 0;
-        uint32_t db = 0, value = 0, prev_res = 0;
-        if (live) db = bb_read(bb, 3);
-        if (cs > 128) { if (live) status = CRI_ERR_HCA_FRAME(5); cs = 0; }
+        uint32_t db = bb_read(bb, ring, 3), value = 0;
+        if (cs > 128) { status = status ? status : CRI_ERR_HCA_FRAME(5); cs = 0; }
         const uint32_t expected = (1u << db) - 1;
-        for (uint32_t i = 0; i < cs; i++) {                       // hca.cpp:1310-1350, all lanes in lock step
-            uint32_t v = 0;
-            if (live && status == 0 && db > 0) {
-                const bool direct = db >= 6 || i == 0;
-                const uint32_t x = bb_read(bb, direct ? 6 : (int)db);
-                if (direct) v = x;
-                else if (x == expected) v = bb_read(bb, 6);
-                else {
+        // scalefactors + resolutions in blocks of 16 bands (the last block is padded with zeros)
+        for (uint32_t blk = 0; blk < 8; blk++) {
+            feed_checkpoint(fd, bb);
+            uint32_t sfw[4] = {0, 0, 0, 0};
+            uint64_t resw = 0;
+            if (blk * 16 < cs) {
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {               // hca.cpp:1310-1350, all lanes in lock step
+                    const uint32_t i = blk * 16 + k;
+                    const bool in = i < cs;
+                    const bool direct = db >= 6 || i == 0;
+                    const uint32_t x = bb_read(bb, ring, (!in || db == 0) ? 0 : (direct ? 6 : (int)db));
+                    const bool esc = in && !direct && db > 0 && x == expected;
+                    const uint32_t y = bb_read(bb, ring, esc ? 6 : 0);
                     const int t = (int)value + ((int)x - (int)(expected >> 1));
-                    if (t < 0 || t >= 64) status = CRI_ERR_HCA_FRAME(5);
-                    v = (value - (expected >> 1) + x) & 0x3F;
+                    if (in && db > 0 && !direct && !esc && (t < 0 || t >= 64) && status == 0) status = CRI_ERR_HCA_FRAME(5);
+                    uint32_t v = direct ? x : (esc ? y : ((value - (expected >> 1) + x) & 0x3F));
+                    if (db == 0 || !in) v = 0;
+                    value = in ? v : value;
+                    sfw[k >> 2] |= v << (8 * (k & 3));
+                    uint32_t res = 0;                             // calculate_resolution, hca.cpp:1450-1488
+                    if (i < coded && v > 0) {
+                        const int noise = (int)ath[i] + (int)((packed + i) >> 8);
+                        const int cp = noise + 1 - (int)((5 * v) >> 1);
+                        res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)curve[cp] : 0u);
+                        res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+                    }
+                    resw |= (uint64_t)res << (4 * k);
                 }
-                value = v;
             }
-            sfst[((i >> 2) * 65 + lane) * 4 + (i & 3)] = (uint8_t)v;
-            if (i < coded) {                                      // calculate_resolution, hca.cpp:1450-1488
-                uint32_t res = 0;
-                if (v > 0) {
-                    const int noise = (int)ath[i] + (int)((packed + i) >> 8);
-                    const int cp = noise + 1 - (int)((5 * v) >> 1);
-                    res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)curve[cp] : 0u);
-                    res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+            resg[(c * 8 + blk) * 64] = resw;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) ostage[((blk & 3) * 4 + q) * 65 + lane] = sfw[q];
+            if ((blk & 3) == 3) {
+                if (blk == 7) {                                   // the high end also carries the HFR scales
+                    // derived HFR scales of v3.0 (hca.cpp:1353-1355); the entry one past the decoded range reads as 0.
+                    // (v3.0 derived scales need scalefactors[cs - i]; they are re-read from the record after the flush.)
+                    // v2.0: explicit HFR scales follow the scalefactors (hca.cpp:1427-1437)
+                    if (type != CRI_CH_SECONDARY && F.version <= 0x0200) {
+                        for (uint32_t k = 0; k < groups; k++) {
+                            const uint32_t v = bb_read(bb, ring, 6);
+                            const uint32_t di = 128 - groups + k;
+                            sfst[(((di >> 2) & 15) * 65 + lane) * 4 + (di & 3)] = (uint8_t)v;
+                        }
+                    }
                 }
-                if (i & 1) resb[(c * 64 + (i >> 1)) * 64 + lane] = (uint8_t)(prev_res | (res << 4));
-                else if (i + 1 == coded) resb[(c * 64 + (i >> 1)) * 64 + lane] = (uint8_t)res;
-                prev_res = res;
+                flush16(ostage, recoff, a.scratch, lane, HCA_REC_SF(C, c) + (blk >> 2) * 64, 16);
             }
         }
-        // derived HFR scales of v3.0 (hca.cpp:1353-1355); the entry one past the decoded range reads as 0
-        for (uint32_t i = 0; i < extra; i++) {
-            const uint32_t srci = cs - i, di = 127 - i;
-            const uint8_t sv = srci < cs ? sfst[((srci >> 2) * 65 + lane) * 4 + (srci & 3)] : 0;
-            sfst[((di >> 2) * 65 + lane) * 4 + (di & 3)] = sv;
+        if (extra) {                                              // v3.0: scalefactors[127 - i] = scalefactors[cs - i]
+            __syncthreads();
+            if (valid) for (uint32_t i = 0; i < extra; i++) {
+                const uint32_t srci = cs - i;
+                rec[HCA_REC_SF(C, c) + 127 - i] = srci < cs ? rec[HCA_REC_SF(C, c) + srci] : 0;
+            }
         }
         // unpack_intensity, hca.cpp:1361-1441
         uint32_t inten_lo = 0, inten_hi = 0;
         if (type == CRI_CH_SECONDARY) {
-            if (valid && status == 0) {
-                uint8_t iv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                bb_refill(bb);
-                uint32_t v = bb_peek(bb, 4);
-                if (F.version <= 0x0200) {
-                    iv[0] = (uint8_t)v;
-                    if (v < 15) { bb_skip(bb, 4); for (int k = 1; k < 8; k++) iv[k] = (uint8_t)bb_read(bb, 4); }
-                    else flags |= 1u << c;                        // intensity[1..7] keep the previous frame's values
-                } else if (v < 15) {
-                    bb_skip(bb, 4);
-                    const uint32_t dbi = bb_read(bb, 2);
-                    iv[0] = (uint8_t)v;
-                    if (dbi == 3) { for (int k = 1; k < 8; k++) iv[k] = (uint8_t)bb_read(bb, 4); }
-                    else {
-                        const uint32_t bmax = (2u << dbi) - 1, bits = dbi + 1;
-                        bool bad = false;
-                        for (int k = 1; k < 8 && !bad; k++) {
-                            const uint32_t delta = bb_read(bb, (int)bits);
-                            if (delta == bmax) v = bb_read(bb, 4);
-                            else { v = (v - (bmax >> 1) + delta) & 0xFF; if (v > 15) { bad = true; break; } }
-                            iv[k] = (uint8_t)v;
-                        }
-                        if (bad) flags |= 1u << (16 + c);          // reference returns early here; entries stay stale
+            uint8_t iv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bb_refill(bb, ring);
+            uint32_t v = bb_peek<true>(bb, 4);
+            if (F.version <= 0x0200) {
+                iv[0] = (uint8_t)v;
+                const bool take = v < 15;
+                if (!take) flags |= 1u << c;                      // intensity[1..7] keep the previous frame's values
+                bb_skip(bb, take ? 4 : 0);
+                for (int k = 1; k < 8; k++) iv[k] = (uint8_t)bb_read(bb, ring, take ? 4 : 0);
+            } else if (v < 15) {                                  // v3.0 forms; divergent but rare
+                bb_skip(bb, 4);
+                const uint32_t dbi = bb_read(bb, ring, 2);
+                iv[0] = (uint8_t)v;
+                if (dbi == 3) { for (int k = 1; k < 8; k++) iv[k] = (uint8_t)bb_read(bb, ring, 4); }
+                else {
+                    const uint32_t bmax = (2u << dbi) - 1, bits = dbi + 1;
+                    bool bad = false;
+                    for (int k = 1; k < 8 && !bad; k++) {
+                        const uint32_t delta = bb_read(bb, ring, (int)bits);
+                        if (delta == bmax) v = bb_read(bb, ring, 4);
+                        else { v = (v - (bmax >> 1) + delta) & 0xFF; if (v > 15) { bad = true; break; } }
+                        iv[k] = (uint8_t)v;
                     }
-                } else { bb_skip(bb, 4); for (int k = 0; k < 8; k++) iv[k] = 7; }
-                inten_lo = iv[0] | (iv[1] << 8) | (iv[2] << 16) | ((uint32_t)iv[3] << 24);
-                inten_hi = iv[4] | (iv[5] << 8) | (iv[6] << 16) | ((uint32_t)iv[7] << 24);
-            }
-        } else if (F.version <= 0x0200) {
-            for (uint32_t k = 0; k < groups; k++) {
-                uint32_t v = 0;
-                if (valid && status == 0) v = bb_read(bb, 6);
-                const uint32_t di = 128 - groups + k;
-                sfst[((di >> 2) * 65 + lane) * 4 + (di & 3)] = (uint8_t)v;
-            }
+                    if (bad) flags |= 1u << (16 + c);              // reference returns early here; entries stay stale
+                }
+            } else { bb_skip(bb, 4); for (int k = 0; k < 8; k++) iv[k] = 7; }
+            inten_lo = iv[0] | (iv[1] << 8) | (iv[2] << 16) | ((uint32_t)iv[3] << 24);
+            inten_hi = iv[4] | (iv[5] << 8) | (iv[6] << 16) | ((uint32_t)iv[7] << 24);
         }
         if (valid) { uint32_t* ip = (uint32_t*)(rec + HCA_REC_INT(C, c)); ip[0] = inten_lo; ip[1] = inten_hi; }
-        flush32(ostage, recptr, lane, HCA_REC_SF(C, c), 32);
     }
-    // ---- spectra: 8 subframes x C channels x coded symbols, serial per lane (hca.cpp:1194-1199, 1540-1571)
-    const uint64_t maxbits_packed = 0xCBA9876544443320ull;
+    // ---- spectra: 8 subframes x C channels x coded symbols, serial per lane (hca.cpp:1194-1199, 1540-1571),
+    //      in blocks of 16 symbols; bands past `coded` carry resolution 0 = no bits
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
-            const uint32_t coded = F.coded[c];
-            const bool live = valid && status == 0;
-            uint32_t word = 0, rb = 0;
-            for (uint32_t i = 0; i < coded; i++) {
-                if (!(i & 1)) rb = resb[(c * 64 + (i >> 1)) * 64 + lane];
-                int val = 0;
-                if (live) {
-                    const uint32_t res = (i & 1) ? (rb >> 4) : (rb & 15);
-                    const int bits = (int)((maxbits_packed >> (res * 4)) & 15);
-                    bb_refill(bb);
-                    const uint32_t code = bb_peek(bb, bits);
-                    int len;
-                    if (res > 7) {                                 // sign-magnitude, zero gives one bit back
-                        const int mag = (int)(code >> 1);
-                        val = (code & 1) ? -mag : mag;
-                        len = bits - (mag == 0 ? 1 : 0);
-                    } else {                                       // truncated-binary prefix code over 0,+1,-1,...,+res,-res
-                        const uint32_t nshort = (1u << bits) - (2 * res + 1);
-                        uint32_t sym;
-                        if (code < 2 * nshort) { sym = code >> 1; len = bits - 1; } else { sym = code - nshort; len = bits; }
-                        if (bits == 0) len = 0;
-                        val = (sym & 1) ? (int)((sym + 1) >> 1) : -(int)(sym >> 1);
+            const uint32_t nblk = ((uint32_t)F.coded[c] + 15) >> 4;
+            for (uint32_t blk = 0; blk < nblk; blk++) {
+                feed_checkpoint(fd, bb);
+                const uint64_t resw = resg[(c * 8 + blk) * 64];
+                const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
+                uint32_t words[8];
+                if (fast) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const int v0 = parse_symbol<false>(bb, ring, (uint32_t)(resw >> (8 * k)) & 15);
+                        const int v1 = parse_symbol<false>(bb, ring, (uint32_t)(resw >> (8 * k + 4)) & 15);
+                        words[k] = (uint32_t)(uint16_t)(int16_t)v0 | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
                     }
-                    bb_skip(bb, len);
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        const int v0 = parse_symbol<true>(bb, ring, (uint32_t)(resw >> (8 * k)) & 15);
+                        const int v1 = parse_symbol<true>(bb, ring, (uint32_t)(resw >> (8 * k + 4)) & 15);
+                        words[k] = (uint32_t)(uint16_t)(int16_t)v0 | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
+                    }
                 }
-                if (i & 1) { word |= (uint32_t)(uint16_t)(int16_t)val << 16; ostage[((i >> 1) & 31) * 65 + lane] = word; }
-                else word = (uint32_t)(uint16_t)(int16_t)val;
-                if ((i & 63) == 63) flush32(ostage, recptr, lane, HCA_REC_QC(C, sf, c) + (i >> 6) * 128, 32);
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * 65 + lane] = words[k];
+                if ((blk & 1) || blk + 1 == nblk)
+                    flush16(ostage, recoff, a.scratch, lane, HCA_REC_QC(C, sf, c) + (blk >> 1) * 64, (blk & 1) ? 16 : 8);
             }
-            if (coded & 1) ostage[((coded >> 1) & 31) * 65 + lane] = word;
-            if (coded & 63) flush32(ostage, recptr, lane, HCA_REC_QC(C, sf, c) + (coded >> 6) * 128, ((coded & 63) + 1) >> 1);
         }
     }
     if (valid) {

@@ -24,6 +24,7 @@ struct HcaDecArgs {
     uint32_t channels;             // channel count of this format
     uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][R+1][64] uint32 (big-endian words)
     uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
+    uint64_t resg_offset;          // scratch byte offset of this group's resolution words: [tile][C][8 blocks][64 lanes] uint64
 };
 size_t hca_prepare_lds_bytes(uint32_t chunk_rows, uint32_t n_cipher);
 size_t hca_parse_lds_bytes(uint32_t channels);
