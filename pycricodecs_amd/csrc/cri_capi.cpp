@@ -239,16 +239,18 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
     uint64_t scratch = 0;
     j->n_cipher = (uint32_t)(cipher.size() / 256);
     for (size_t b = 0; b < streams.size();) {
-        size_t e = b; uint32_t frames = 0;
+        size_t e = b; uint32_t frames = 0, runs = 0;
         const HcaFormat& F = formats[streams[b].format];
         while (e < streams.size() && streams[e].format == streams[b].format) {
-            streams[e].first_frame = frames; streams[e].scratch_offset = scratch;
-            frames += streams[e].frames; scratch += (uint64_t)streams[e].frames * F.record_bytes;
+            streams[e].first_frame = frames; streams[e].first_run = runs; streams[e].scratch_offset = scratch;
+            frames += streams[e].frames; runs += (streams[e].frames + 7) / 8;
+            scratch += (uint64_t)streams[e].frames * F.record_bytes;
             e++;
         }
         HcaDecArgs a; memset(&a, 0, sizeof a);
-        a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
+        a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames; a.runs = runs;
         a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
+        a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
         b = e;

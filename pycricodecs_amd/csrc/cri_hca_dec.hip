@@ -37,9 +37,30 @@ __device__ __forceinline__ uint32_t crc16_step(uint32_t crc, uint32_t b) {
     return ((crc << 8) & 0xFFFF) ^ tt;
 }
 
+
+// Format parameters held in registers (scalar) for the whole kernel: reading them through the HcaFormat pointer inside the
+// loops would turn every use into a memory load.
+struct Fmt {
+    uint32_t channels, version, frame_size, min_res, max_res, total_bands, base_bands, stereo_bands, bands_per_hfr_group,
+        hfr_group_count, ath_index, record_bytes, types;                     // types: 2 bits per channel
+    __device__ __forceinline__ uint32_t type(uint32_t c) const { return (types >> (2 * c)) & 3u; }
+    __device__ __forceinline__ uint32_t coded(uint32_t c) const { return type(c) == CRI_CH_SECONDARY ? base_bands : base_bands + stereo_bands; }
+};
+__device__ __forceinline__ Fmt load_fmt(const HcaFormat* f) {
+    Fmt m;
+    m.channels = f->channels; m.version = f->version; m.frame_size = f->frame_size; m.min_res = f->min_res; m.max_res = f->max_res;
+    m.total_bands = f->total_bands; m.base_bands = f->base_bands; m.stereo_bands = f->stereo_bands;
+    m.bands_per_hfr_group = f->bands_per_hfr_group; m.hfr_group_count = f->hfr_group_count; m.ath_index = f->ath_index;
+    m.record_bytes = f->record_bytes;
+    uint32_t t = 0;
+    for (uint32_t c = 0; c < 16; c++) t |= (uint32_t)(f->type[c] & 3) << (2 * c);
+    m.types = t;
+    return m;
+}
+
 __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const HcaFormat& F = a.formats[a.format];
+    const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t R = a.rows, RC = a.prep_chunk_rows, lane = threadIdx.x, tile = blockIdx.x;
     const int fs = (int)F.frame_size;
     uint32_t* rows = (uint32_t*)smem;
@@ -215,7 +236,7 @@ __device__ __forceinline__ void flush16(const uint32_t* ostage, const uint64_t* 
 
 __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const HcaFormat& F = a.formats[a.format];
+    const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t R = a.rows, C = F.channels, lane = threadIdx.x, tile = blockIdx.x;
     uint32_t* ostage = (uint32_t*)smem;
     uint64_t* recoff = (uint64_t*)(smem + 16 * 65 * 4);
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint8_t* sfst = (uint8_t*)ostage;
     __syncthreads();
     for (uint32_t c = 0; c < C; c++) {
-        const uint32_t coded = F.coded[c], type = F.type[c], groups = F.hfr_group_count;
+        const uint32_t coded = F.coded(c), type = F.type(c), groups = F.hfr_group_count;
         uint32_t cs = coded, extra = 0;
         if (!(type == CRI_CH_SECONDARY || groups == 0 || F.version <= 0x0200)) { extra = groups; cs += extra; }
         uint32_t db = bb_read(bb, ring, 3), value = 0;
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     //      in blocks of 16 symbols; bands past `coded` carry resolution 0 = no bits
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
-            const uint32_t nblk = ((uint32_t)F.coded[c] + 15) >> 4;
+            const uint32_t nblk = (F.coded(c) + 15) >> 4;
             for (uint32_t blk = 0; blk < nblk; blk++) {
                 feed_checkpoint(fd, bb);
                 const uint64_t resw = resg[(c * 8 + blk) * 64];
@@ -427,12 +448,12 @@ __device__ __forceinline__ void imdct_dct4(float* x, float* y, uint32_t m, const
 }
 
 struct TransformCtx {
-    const HcaFormat* F; const uint8_t* ath; float* S; float* G; uint32_t C, lane;
+    const Fmt* F; const uint8_t* ath; float* S; float* G; uint32_t C, lane;
 };
 
 // gains of one frame: calculate_resolution + calculate_gain (hca.cpp:1444-1507), two bands per lane
 __device__ __forceinline__ void frame_gains(const TransformCtx& X, const uint8_t* rec) {
-    const HcaFormat& F = *X.F;
+    const Fmt& F = *X.F;
     const uint32_t packed = ((const uint32_t*)(rec + HCA_REC_TAIL(X.C)))[0];
     for (uint32_t c = 0; c < X.C; c++) {
         const uint32_t sf2 = ((const uint16_t*)(rec + HCA_REC_SF(X.C, c)))[X.lane];
@@ -440,7 +461,7 @@ __device__ __forceinline__ void frame_gains(const TransformCtx& X, const uint8_t
         for (int h = 0; h < 2; h++) {
             const uint32_t i = 2 * X.lane + h, v = (sf2 >> (8 * h)) & 0xFF;
             float gain = 0.0f;
-            if (i < F.coded[c]) {
+            if (i < F.coded(c)) {
                 uint32_t res = 0;
                 if (v > 0) {
                     int noise = (int)X.ath[i] + (int)((packed + i) >> 8);
@@ -457,14 +478,14 @@ __device__ __forceinline__ void frame_gains(const TransformCtx& X, const uint8_t
 
 // spectra of subframe sf of one frame into S: dequantise, HFR, intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
 __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8_t* rec, uint32_t sf, const uint8_t* inten /* [C][8] resolved */) {
-    const HcaFormat& F = *X.F;
+    const Fmt& F = *X.F;
     const uint32_t C = X.C, lane = X.lane;
     for (uint32_t c = 0; c < C; c++) {
         const uint32_t q2 = ((const uint32_t*)(rec + HCA_REC_QC(C, sf, c)))[lane];
         const uint32_t i0 = 2 * lane;
         float q0 = (float)(int)(int16_t)(q2 & 0xFFFF), q1 = (float)(int)(int16_t)(q2 >> 16);
-        X.S[c * 128 + i0] = i0 < F.coded[c] ? X.G[c * 128 + i0] * q0 : 0.0f;
-        X.S[c * 128 + i0 + 1] = i0 + 1 < F.coded[c] ? X.G[c * 128 + i0 + 1] * q1 : 0.0f;
+        X.S[c * 128 + i0] = i0 < F.coded(c) ? X.G[c * 128 + i0] * q0 : 0.0f;
+        X.S[c * 128 + i0 + 1] = i0 + 1 < F.coded(c) ? X.G[c * 128 + i0 + 1] * q1 : 0.0f;
     }
     __syncthreads();
     if (F.bands_per_hfr_group > 0) {
@@ -473,7 +494,7 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
         const int total = (int)F.total_bands;
         // number of processed bands: stops at the first k with start+k >= total or low(k) < 0
         for (uint32_t c = 0; c < C; c++) {
-            if (F.type[c] == CRI_CH_SECONDARY) continue;
+            if (F.type(c) == CRI_CH_SECONDARY) continue;
             const uint8_t* sfb = rec + HCA_REC_SF(C, c);
             int nproc = groups * bpg;
             if (nproc > total - start) nproc = total - start;
@@ -505,7 +526,7 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
     }
     if (F.stereo_bands > 0) {
         for (uint32_t c = 0; c + 1 < C; c++) {
-            if (F.type[c] != CRI_CH_PRIMARY) continue;
+            if (F.type(c) != CRI_CH_PRIMARY) continue;
             const float rl = HCA_INTENSITY_RATIO[inten[(c + 1) * 8 + sf] & 15];
             const float rr = 2.0f - rl;
 #pragma unroll
@@ -524,7 +545,7 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
 
 // intensity indexes of frame f with the "nibble 15 keeps intensity[1..7]" rule resolved (hca.cpp:1367-1375):
 // a flagged frame takes entries 1..7 from the nearest earlier unflagged frame of the stream (zeros if none).
-__device__ __forceinline__ void resolve_intensity(const HcaFormat& F, const uint8_t* rec_stream0, uint32_t f, uint32_t C, uint32_t lane, uint8_t* inten) {
+__device__ __forceinline__ void resolve_intensity(const Fmt& F, const uint8_t* rec_stream0, uint32_t f, uint32_t C, uint32_t lane, uint8_t* inten) {
     if (lane < C * 8) {
         const uint32_t c = lane >> 3, k = lane & 7;
         const uint8_t* rec = rec_stream0 + (uint64_t)f * F.record_bytes;
@@ -541,9 +562,9 @@ __device__ __forceinline__ void resolve_intensity(const HcaFormat& F, const uint
     }
 }
 
-__global__ __launch_bounds__(64) void k_hca_transform(HcaDecArgs a) {
+__global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
-    const HcaFormat& F = a.formats[a.format];
+    const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t C = F.channels, lane = threadIdx.x, g = blockIdx.x;
     float* S = fsm; float* G = S + C * 128; float* P = G + C * 128; float* T = P + C * 128;
     uint8_t* inten = (uint8_t*)(T + 128);           // [C][8]
@@ -608,10 +629,322 @@ __global__ __launch_bounds__(64) void k_hca_transform(HcaDecArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k_hca_transform: register-resident IMDCT, wavefront shuffles for the butterflies (1, 2 or 4 channels)
+// ------------------------------------------------------------------------------------------------------------
+// A wave owns a run of up to HCA_RUN consecutive frames of one stream and walks its 8*C transforms per frame four at a
+// time: transform slot j = lane >> 4, and the 16 lanes of a slot hold the 128 spectral lines of that transform, 8
+// consecutive bands per lane (physical position p = lane16 * 8 + reg).  The 128-point DCT-IV of hca.cpp:1898-1980 is run
+// in its in-place form (tools/gen_tables.py, imdct_inplace_maps): 14 butterfly stages between positions differing in one
+// bit of p -- bits 0..2 are register pairs, bits 3..6 are lane16 ^ 1, 2, 4, 8 exchanged with DPP (quad_perm, row_shl/shr,
+// row_ror) -- with exactly the reference's multiplies and adds (no FMA).  Window + overlap-add (hca.cpp:1987-1992) gathers
+// the DCT outputs of a transform and of its predecessor (same channel, previous subframe) from a small LDS ring; the
+// predecessor of a run's first subframe is recomputed from the previous frame's last subframe (a halo pass), so frames
+// stay independent.  PCM16 is assembled in LDS and stored 256 contiguous bytes per wave instruction.
+#undef CRI_TABLE_QUAL
+#define CRI_TABLE_QUAL static __device__ const
+#include "cri_imdct_tables.h"
+#define HCA_RUN 8
+
+template <int CTRL, int BANK> __device__ __forceinline__ float dpp_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK, false));
+}
+template <int X> __device__ __forceinline__ float lane16_xor(float v) {
+    if (X == 1) return dpp_f<0xB1, 0xF>(v, v);            // quad_perm [1,0,3,2]
+    if (X == 2) return dpp_f<0x4E, 0xF>(v, v);            // quad_perm [2,3,0,1]
+    if (X == 8) return dpp_f<0x128, 0xF>(v, v);           // row_ror:8
+    float t = dpp_f<0x104, 0x5>(v, v);                    // row_shl:4 into banks 0,2
+    return dpp_f<0x114, 0xA>(t, v);                       // row_shr:4 into banks 1,3
+}
+__device__ __forceinline__ float fneg_if(float v, bool n) { return n ? -v : v; }
+
+struct DctLane {
+    float s[11], c[11];        // per-lane twiddles (stages 0-4: one each, stage 5: two, stage 6: four); c of stages 0-3 is role-folded
+    uint32_t l16;              // lane16: bit k set -> this lane is `b` of the cross-lane sum/difference stage k
+};
+
+template <int X, int K> __device__ __forceinline__ void sumdiff_cross(float x[8], const DctLane& L) {
+    const uint32_t m = (L.l16 << (31 - K)) & 0x80000000u;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float partner = lane16_xor<X>(x[r]);
+        x[r] = partner + __uint_as_float(__float_as_uint(x[r]) ^ m);            // a+b in the `a` lane, a-b in the `b` lane
+    }
+}
+template <int X, int ST> __device__ __forceinline__ void rotate_cross(float x[8], const DctLane& L) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float p1 = x[r] * L.s[ST];
+        const float partner = lane16_xor<X>(x[r]);
+        const float p2 = partner * fneg_if(L.c[ST], HCA_DCT_REGSIGN(ST, r));     // -b*cos in the `a` lane, +a*cos in the `b` lane
+        x[r] = p1 + p2;
+    }
+}
+template <int BIT, int ST> __device__ __forceinline__ void rotate_regs(float x[8], const DctLane& L) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (r & BIT) continue;
+        const int ti = ST == 4 ? 4 : (ST == 5 ? 5 + (r >> 2) : 7 + (r >> 1));
+        const float sn = L.s[ti], cs = fneg_if(L.c[ti], HCA_DCT_REGSIGN(ST, r));
+        const float a = x[r], b = x[r | BIT];
+        const float as = a * sn, bc = b * cs, ac = a * cs, bs = b * sn;
+        x[r] = as - bc;
+        x[r | BIT] = ac + bs;
+    }
+}
+__device__ __forceinline__ void dct4_inplace(float x[8], const DctLane& L) {
+#pragma unroll
+    for (int bit = 1; bit <= 4; bit <<= 1)                 // sum/difference stages 0..2: register pairs
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (r & bit) continue;
+            const float a = x[r], b = x[r | bit];
+            x[r] = a + b; x[r | bit] = a - b;
+        }
+    sumdiff_cross<1, 0>(x, L); sumdiff_cross<2, 1>(x, L); sumdiff_cross<4, 2>(x, L); sumdiff_cross<8, 3>(x, L);   // stages 3..6
+    rotate_cross<8, 0>(x, L); rotate_cross<4, 1>(x, L); rotate_cross<2, 2>(x, L); rotate_cross<1, 3>(x, L);       // rotation stages 0..3
+    rotate_regs<4, 4>(x, L); rotate_regs<2, 5>(x, L); rotate_regs<1, 6>(x, L);                                    // rotation stages 4..6
+}
+
+struct TrLds {
+    float* G;          // [C][128] gains of the current frame
+    float* hconv;      // [C][128] HFR scale of a reconstructed band
+    uint8_t* hlow;     // [C][128] source band of a reconstructed band
+    uint8_t* inten;    // [C][8]
+    float* D;          // [8][128] ring of DCT outputs in logical order
+    uint16_t* pcm;     // [512] int16 staging of one pass
+    float* win;        // [128] synthesis window
+};
+
+// per-frame setup: gains (hca.cpp:1444-1507), HFR source/scale per band (1638-1683), intensity indexes (1361-1441 + stale rule)
+__device__ __forceinline__ void tr_setup_frame(const HcaDecArgs& a, const Fmt& F, const TrLds& T, const uint8_t* rec0, uint32_t f, uint32_t lane, int nproc) {
+    const uint32_t C = F.channels;
+    const uint8_t* rec = rec0 + (uint64_t)f * F.record_bytes;
+    const uint8_t* ath = a.ath_tables + F.ath_index * 128;
+    const uint32_t packed = ((const uint32_t*)(rec + HCA_REC_TAIL(C)))[0];
+    for (uint32_t c = 0; c < C; c++) {
+        const uint32_t sf2 = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t i = 2 * lane + h, v = (sf2 >> (8 * h)) & 0xFF;
+            float gain = 0.0f;
+            if (i < F.coded(c)) {
+                uint32_t res = 0;
+                if (v > 0) {
+                    const int noise = (int)ath[i] + (int)((packed + i) >> 8);
+                    const int cp = noise + 1 - (int)((5 * v) >> 1);
+                    res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)HCA_CURVE_TO_RES[cp] : 0u);
+                    res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+                }
+                gain = HCA_DEQ_SCALE[v & 63] * HCA_DEQ_RANGE[res];
+            }
+            T.G[c * 128 + i] = gain;
+        }
+        if (F.bands_per_hfr_group > 0 && F.type(c) != CRI_CH_SECONDARY) {
+            const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
+            const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
+            const uint8_t* sfb = rec + HCA_REC_SF(C, c);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = (int)lane + 64 * h;
+                if (k < nproc) {
+                    const int group = k / bpg;
+                    const int dec = k < limit * bpg ? k : limit * bpg;
+                    const int low = start - 1 - dec;
+                    int sc = (int)sfb[128 - groups + group] - (int)sfb[low] + 63;
+                    sc = sc & ~(sc >> 31);
+                    T.hconv[c * 128 + start + k] = HCA_SCALE_CONV[sc & 127];
+                    T.hlow[c * 128 + start + k] = (uint8_t)low;
+                }
+            }
+        }
+    }
+    resolve_intensity(F, rec0, f, C, lane, T.inten);
+    __syncthreads();
+}
+
+// the 8 spectral lines b = lane16*8 + r of (frame record, subframe, channel) after dequantisation, high-frequency
+// reconstruction and intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
+struct TrFetch { uint4 q, p; };      // quantised lines of (sf, c) for this lane's 8 bands, and of channel c-1 when c is a stereo secondary
+template <bool PLAIN>
+__device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* rec, uint32_t sf, uint32_t c, uint32_t l16) {
+    TrFetch t;
+    const uint32_t C = F.channels;
+    t.q = *(const uint4*)(rec + HCA_REC_QC(C, sf, c) + l16 * 16);
+    t.p = make_uint4(0, 0, 0, 0);
+    if (!PLAIN && F.type(c) == CRI_CH_SECONDARY && F.stereo_bands > 0) t.p = *(const uint4*)(rec + HCA_REC_QC(C, sf, c - 1) + l16 * 16);
+    return t;
+}
+template <bool PLAIN>
+__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const uint8_t* rec, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t l16, int nproc, float x[8]) {
+    const uint32_t C = F.channels;
+    const bool secondary = F.type(c) == CRI_CH_SECONDARY;
+    const uint32_t qw[4] = {ft.q.x, ft.q.y, ft.q.z, ft.q.w};
+    if (PLAIN) {
+        const float4 g0 = *(const float4*)(T.G + c * 128 + l16 * 8), g1 = *(const float4*)(T.G + c * 128 + l16 * 8 + 4);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t b = l16 * 8 + r;
+            const float q = (float)(int)(int16_t)(qw[r >> 1] >> (16 * (r & 1)));
+            const float v = g[r] * q;
+            x[r] = b < F.coded(c) ? v : 0.0f;
+        }
+        return;
+    }
+    const uint32_t pw[4] = {ft.p.x, ft.p.y, ft.p.z, ft.p.w};
+    const int start = (int)(F.stereo_bands + F.base_bands);
+    const float rl = (F.stereo_bands > 0 && (secondary || F.type(c) == CRI_CH_PRIMARY))
+                         ? HCA_INTENSITY_RATIO[T.inten[(secondary ? c : c + 1) * 8 + sf] & 15] : 1.0f;
+    const float rr = 2.0f - rl;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t b = l16 * 8 + r;
+        const bool from_prev = secondary && b >= F.base_bands;           // intensity: R takes L's line (hca.cpp:1707-1711)
+        const uint32_t cs = from_prev ? c - 1 : c;
+        const uint32_t w = from_prev ? pw[r >> 1] : qw[r >> 1];
+        float v = 0.0f;
+        if (b < F.coded(cs)) v = T.G[cs * 128 + b] * (float)(int)(int16_t)(w >> (16 * (r & 1)));
+        else if (F.bands_per_hfr_group > 0 && F.type(cs) != CRI_CH_SECONDARY && (int)b >= start && (int)b < start + nproc) {
+            const uint32_t low = T.hlow[cs * 128 + b];
+            const float ql = (float)(int)*(const int16_t*)(rec + HCA_REC_QC(C, sf, cs) + low * 2);
+            v = T.hconv[cs * 128 + b] * (T.G[cs * 128 + low] * ql);
+        }
+        if (F.bands_per_hfr_group > 0 && F.type(cs) != CRI_CH_SECONDARY && (int)b == start + nproc - 1) v = 0.0f;   // hca.cpp:1681
+        if (F.stereo_bands > 0 && b >= F.base_bands && b < F.total_bands) {
+            if (from_prev) v = v * rr;
+            else if (F.type(c) == CRI_CH_PRIMARY) v = v * rl;
+        }
+        x[r] = v;
+    }
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const Fmt F = load_fmt(a.formats + a.format);
+    const uint32_t C = F.channels, lane = threadIdx.x, slot = lane >> 4, l16 = lane & 15;
+    TrLds T;
+    T.G = (float*)smem; T.hconv = T.G + C * 128; T.D = T.hconv + C * 128; T.pcm = (uint16_t*)(T.D + 8 * 128);
+    T.win = (float*)(T.pcm + 512); T.hlow = (uint8_t*)(T.win + 128); T.inten = T.hlow + C * 128;
+
+    // run -> stream, first frame
+    uint32_t lo = a.stream_begin, hi = a.stream_end;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= blockIdx.x) lo = mid; else hi = mid; }
+    const HcaStream st = a.streams[lo];
+    const uint32_t f0 = (blockIdx.x - st.first_run) * HCA_RUN;
+    const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
+    const uint8_t* rec0 = a.scratch + st.scratch_offset;
+
+    // per-lane constants
+    DctLane L;
+#pragma unroll
+    for (int i = 0; i < 11; i++) { L.s[i] = HCA_DCT_LANE_SIN[l16][i]; L.c[i] = HCA_DCT_LANE_COS[l16][i]; }
+    L.c[0] = fneg_if(L.c[0], !(l16 & 8)); L.c[1] = fneg_if(L.c[1], !(l16 & 4)); L.c[2] = fneg_if(L.c[2], !(l16 & 2)); L.c[3] = fneg_if(L.c[3], !(l16 & 1));
+    L.l16 = l16;
+    const uint2 dlogp = *(const uint2*)(HCA_DCT_LOGICAL + l16 * 8);          // 8 logical indexes, one byte each
+    T.win[lane] = HCA_WINDOW[lane]; T.win[lane + 64] = HCA_WINDOW[lane + 64];
+    // bands reconstructed by HFR (format constant): stops when the high band leaves the spectrum or the low band index hits 0
+    int nproc = 0;
+    if (F.bands_per_hfr_group > 0) {
+        const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
+        const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
+        nproc = groups * bpg;
+        if (nproc > (int)F.total_bands - start) nproc = (int)F.total_bands - start;
+        if (nproc < 0) nproc = 0;
+        if (limit * bpg > start - 1 && nproc > start) nproc = start;
+    }
+    const uint32_t per_pass_sf = 4 / C;                    // subframes completed by one pass (C = 1, 2, 4)
+    const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
+    uint32_t sglob = 8;                                    // ring position of the next pass's slot 0
+
+    // ---- halo: DCT of the previous frame's last subframe gives the overlap tail of this run's first subframe
+    if (f0 > 0) {
+        const uint8_t* prec = rec0 + (uint64_t)(f0 - 1) * F.record_bytes;
+        if ((int32_t)((const uint32_t*)(prec + HCA_REC_TAIL(C)))[1] != 0) return;        // the stream failed at an earlier frame
+        tr_setup_frame(a, F, T, rec0, f0 - 1, lane, nproc);
+        float x[8];
+        if (slot < C) { const TrFetch hf = tr_fetch<PLAIN>(F, prec, 7, slot, l16); tr_load_spectra<PLAIN>(F, T, prec, hf, 7, slot, l16, nproc, x); }
+        else { for (int r = 0; r < 8; r++) x[r] = 0.0f; }
+        dct4_inplace(x, L);
+        if (slot < C) {
+            float* d = T.D + ((sglob - C + slot) & 7) * 128;
+#pragma unroll
+            for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r];
+        }
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (uint32_t fi = 0; fi < nf; fi++) {
+        const uint32_t f = f0 + fi;
+        const uint8_t* rec = rec0 + (uint64_t)f * F.record_bytes;
+        const int32_t status = (int32_t)((const uint32_t*)(rec + HCA_REC_TAIL(C)))[1];
+        if (status != 0) { if (lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
+        tr_setup_frame(a, F, T, rec0, f, lane, nproc);
+        TrFetch ft = tr_fetch<PLAIN>(F, rec, slot / C, slot % C, l16);
+#pragma unroll 1
+        for (uint32_t pass = 0; pass < 2 * C; pass++, sglob += 4) {
+            const uint32_t t = pass * 4 + slot, sf = t / C, c = t % C;
+            const TrFetch cur = ft;
+            if (pass + 1 < 2 * C) ft = tr_fetch<PLAIN>(F, rec, (t + 4) / C, (t + 4) % C, l16);      // next pass's lines are in flight during this pass
+            float x[8];
+            tr_load_spectra<PLAIN>(F, T, rec, cur, sf, c, l16, nproc, x);
+            dct4_inplace(x, L);
+            float* d = T.D + ((sglob + slot) & 7) * 128;
+#pragma unroll
+            for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r];
+            __syncthreads();
+            // window + overlap-add (hca.cpp:1987-1992) against the predecessor (same channel, previous subframe)
+            const float* dp = T.D + ((sglob + slot - C) & 7) * 128;
+            const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
+            const uint32_t sfl = slot / C;                                             // subframe within this pass
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int i = (int)l16 + 16 * m;
+                const float p0 = have_prev ? T.win[127 - i] * dp[63 - i] : 0.0f;
+                const float p1 = have_prev ? T.win[63 - i] * dp[i] : 0.0f;
+                const float o0 = T.win[i] * d[i + 64] + p0;
+                const float o1 = T.win[i + 64] * d[127 - i] - p1;
+                int32_t q0 = cvt_trunc_x86(o0 * 32768.0f), q1 = cvt_trunc_x86(o1 * 32768.0f);     // hca.cpp:339-360
+                q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
+                q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
+                T.pcm[((sfl * 128 + i) * C) + c] = (uint16_t)(int16_t)q0;
+                T.pcm[((sfl * 128 + i + 64) * C) + c] = (uint16_t)(int16_t)q1;
+            }
+            __syncthreads();
+            // 1 KB of interleaved PCM16 per pass; delay / length trim of hca.cpp:3392-3425
+            const uint32_t n0 = f * 1024 + (pass * per_pass_sf) * 128;
+            uint8_t* dst = a.out + st.dst_offset;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
+                const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
+                const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
+                const uint32_t word = ((const uint32_t*)T.pcm)[dw];
+                const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
+                if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
+                else {
+                    if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
+                    if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+size_t hca_transform_lds_bytes(uint32_t C) { return (size_t)C * 128 * 4 * 2 + 8 * 128 * 4 + 1024 + 512 + C * 128 + 64; }
+
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
-    size_t lds = (size_t)(3 * a.channels + 1) * 128 * 4 + a.channels * 8 + 16;
-    hipLaunchKernelGGL(k_hca_transform, dim3(a.frames), dim3(64), lds, s, a);
+    if (a.channels == 1 || a.channels == 2 || a.channels == 4) {
+        if (a.plain) hipLaunchKernelGGL(k_hca_transform<true>, dim3(a.runs), dim3(64), hca_transform_lds_bytes(a.channels), s, a);
+        else hipLaunchKernelGGL(k_hca_transform<false>, dim3(a.runs), dim3(64), hca_transform_lds_bytes(a.channels), s, a);
+    } else {
+        size_t lds = (size_t)(3 * a.channels + 1) * 128 * 4 + a.channels * 8 + 16;
+        hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);
+    }
 }
 
 }  // namespace cri

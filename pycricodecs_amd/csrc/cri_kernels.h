@@ -18,10 +18,12 @@ struct HcaDecArgs {
     uint32_t format;               // format index of this launch
     uint32_t stream_begin, stream_end;   // streams of this format
     uint32_t frames;               // total frames of this format group
+    uint32_t runs;                 // total runs (8 consecutive frames of one stream) of this format group
     uint32_t n_cipher;
     uint32_t rows;                 // R = ceil(frame_size / 4): words per frame
     uint32_t prep_chunk_rows;      // rows staged per pass in k_hca_prepare
     uint32_t channels;             // channel count of this format
+    uint32_t plain;                // 1: no HFR and no joint stereo in this format (spectra need dequantisation only)
     uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][R+1][64] uint32 (big-endian words)
     uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
     uint64_t resg_offset;          // scratch byte offset of this group's resolution words: [tile][C][8 blocks][64 lanes] uint64

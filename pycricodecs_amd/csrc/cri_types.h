@@ -30,7 +30,7 @@ struct HcaStream {
     uint32_t samples;              // decode: samples per channel to emit; encode: input samples per channel
     uint32_t item;                 // index of the batch item (for status reporting)
     uint32_t first_frame;          // global frame number of this stream's frame 0 within its format group
-    uint32_t pad0;
+    uint32_t first_run;            // global number of this stream's first run of HCA_RUN (8) frames within its format group
 };
 
 // Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):

@@ -283,6 +283,142 @@ def emit(T):
     return "\n".join(out) + "\n"
 
 
+def imdct_inplace_maps(T):
+    """In-place form of the decoder's 128-point DCT-IV (hca.cpp:1898-1980) used by k_hca_transform:
+    14 butterfly stages between physical positions that differ in ONE bit (bits 0..6 for the sum/difference stages, then
+    6..0 for the rotation stages, the lower position always playing the reference's `a`).  Returns per rotation stage and
+    physical position the twiddle index, and the logical DCT index each physical position holds at the end.  The routine
+    replays both forms on random data and asserts bit-equality before returning."""
+    sin = np.asarray(T["dec_sin"][1], dtype=np.int64).astype(np.uint32).view(np.float32).reshape(7, 64)
+    cos = np.asarray(T["dec_cos"][1], dtype=np.int64).astype(np.uint32).view(np.float32).reshape(7, 64)
+    L = np.arange(128)
+    ph1, ph2 = [], []
+    for i in range(7):
+        c = 64 >> i
+        inv = {int(L[p]): p for p in range(128)}
+        new = np.zeros(128, dtype=int)
+        for m in range(64):
+            j, k = divmod(m, c)
+            pa, pb = inv[2 * m], inv[2 * m + 1]
+            assert pb == pa | (1 << i) and not pa & (1 << i)
+            ph1.append((pa, pb))
+            new[pa], new[pb] = 2 * c * j + k, 2 * c * j + c + k
+        L = new
+    tw = np.zeros((7, 128), dtype=int)
+    for i in range(7):
+        c = 1 << i
+        inv = {int(L[p]): p for p in range(128)}
+        new = np.zeros(128, dtype=int)
+        for j in range(64 >> i):
+            for k in range(c):
+                pa, pb = inv[2 * c * j + k], inv[2 * c * j + c + k]
+                assert pb == pa | (64 >> i) and not pa & (64 >> i)
+                ph2.append((i, pa, pb, c * j + k))
+                tw[i][pa] = tw[i][pb] = c * j + k
+                new[pa], new[pb] = 2 * c * j + k, 2 * c * j + 2 * c - 1 - k
+        L = new
+    rng = np.random.default_rng(7)
+    for _ in range(4):                                  # replay: ping-pong form vs in-place form
+        x0 = (rng.standard_normal(128) * rng.uniform(1e-4, 2.0)).astype(np.float32)
+        x, y = x0.copy(), np.zeros(128, np.float32)
+        for i in range(7):
+            c = 64 >> i
+            for j in range(1 << i):
+                for k in range(c):
+                    p, q = x[2 * (c * j + k)], x[2 * (c * j + k) + 1]
+                    y[2 * c * j + k], y[2 * c * j + c + k] = f32(p + q), f32(p - q)
+            x, y = y, x.copy()
+        for i in range(7):
+            c = 1 << i
+            for j in range(64 >> i):
+                for k in range(c):
+                    t = c * j + k
+                    p, q = x[2 * c * j + k], x[2 * c * j + c + k]
+                    y[2 * c * j + k] = f32(f32(p * sin[i][t]) - f32(q * cos[i][t]))
+                    y[2 * c * j + 2 * c - 1 - k] = f32(f32(p * cos[i][t]) + f32(q * sin[i][t]))
+            x, y = y, x.copy()
+        z = x0.copy()
+        for pa, pb in ph1:
+            a, b = z[pa], z[pb]
+            z[pa], z[pb] = f32(a + b), f32(a - b)
+        for i, pa, pb, t in ph2:
+            a, b = z[pa], z[pb]
+            z[pa], z[pb] = f32(f32(a * sin[i][t]) - f32(b * cos[i][t])), f32(f32(a * cos[i][t]) + f32(b * sin[i][t]))
+        out = np.zeros(128, np.float32)
+        out[L] = z
+        assert np.array_equal(out.view(np.uint32), x.view(np.uint32)), "in-place DCT-IV differs from the reference form"
+    return tw, L
+
+
+def emit_imdct(T):
+    """cri_imdct_tables.h: twiddles of the in-place DCT-IV in the register layout of k_hca_transform.
+    Physical position p = lane16 * 8 + reg (a lane owns 8 consecutive spectral bands).  For rotation stages 0..4 a lane
+    needs one (sin, |cos|) pair, for stage 5 two, for stage 6 four (selected by reg bits); the sign of cos factors into a
+    per-lane flag times a per-reg constant.  The kernel folds the lane flag and the butterfly role (a / b) into the
+    per-lane cos value."""
+    tw, L = imdct_inplace_maps(T)
+    sin = np.asarray(T["dec_sin"][1], dtype=np.int64).astype(np.uint32).view(np.float32).reshape(7, 64)
+    cos = np.asarray(T["dec_cos"][1], dtype=np.int64).astype(np.uint32).view(np.float32).reshape(7, 64)
+    S = np.zeros((7, 16, 8), np.float32)
+    C = np.zeros((7, 16, 8), np.float32)
+    for i in range(7):
+        for p in range(128):
+            S[i][p >> 3][p & 7] = sin[i][tw[i][p]]
+            C[i][p >> 3][p & 7] = cos[i][tw[i][p]]
+    nvar = [1, 1, 1, 1, 1, 2, 4]
+    regsign = np.zeros((7, 8), dtype=int)          # 1 = cos negative relative to the lane value
+    lane_s = [np.zeros((16, nvar[i]), np.float32) for i in range(7)]
+    lane_c = [np.zeros((16, nvar[i]), np.float32) for i in range(7)]
+    variant = np.zeros((7, 8), dtype=int)
+    for i in range(7):
+        # variant of a reg = which distinct |cos| it uses (same grouping for every lane)
+        groups = {}
+        for r in range(8):
+            key = tuple(np.abs(C[i][:, r]).tolist())
+            groups.setdefault(key, len(groups))
+            variant[i][r] = groups[key]
+        assert len(groups) == nvar[i], (i, len(groups))
+        for l in range(16):
+            for v in range(nvar[i]):
+                regs = [r for r in range(8) if variant[i][r] == v]
+                lane_s[i][l][v] = S[i][l][regs[0]]
+                assert all(S[i][l][r] == S[i][l][regs[0]] for r in regs)
+                lane_c[i][l][v] = C[i][l][regs[0]]               # signed as seen by the first reg of the variant
+        for r in range(8):
+            v = variant[i][r]
+            first = [q for q in range(8) if variant[i][q] == v][0]
+            flips = {bool(np.signbit(C[i][l][r]) != np.signbit(C[i][l][first])) for l in range(16)}
+            assert len(flips) == 1, "cos sign does not factor into lane x reg"
+            regsign[i][r] = int(flips.pop())
+            assert all(abs(C[i][l][r]) == abs(lane_c[i][l][v]) for l in range(16))
+    out = ["/* cri_imdct_tables.h -- GENERATED by tools/gen_tables.py (emit_imdct); do not edit.",
+           " * In-place DCT-IV of the HCA decoder in the lane/register layout of k_hca_transform (see the generator). */",
+           "#ifndef CRI_IMDCT_TABLES_H", "#define CRI_IMDCT_TABLES_H", "#include <stdint.h>", ""]
+    # per-lane twiddles: [stage][variant] flattened: stages 0..4 -> 1 each, stage 5 -> 2, stage 6 -> 4  => 11 (sin, cos) pairs
+    flat_s, flat_c = [], []
+    for l in range(16):
+        for i in range(7):
+            for v in range(nvar[i]):
+                flat_s.append(lane_s[i][l][v])
+                flat_c.append(lane_c[i][l][v])
+    def arr(name, vals, per):
+        out.append("CRI_TABLE_QUAL float %s[16][11] = {" % name)
+        for l in range(16):
+            out.append("    {" + ", ".join(fmt("f32", int(np.float32(x).view(np.uint32))) for x in vals[l * per:(l + 1) * per]) + "},")
+        out.append("};")
+    arr("HCA_DCT_LANE_SIN", flat_s, 11)
+    arr("HCA_DCT_LANE_COS", flat_c, 11)
+    out.append("/* cos sign of reg r at rotation stage i relative to the lane value (1 = negated), and the variant a reg uses */")
+    out.append("#define HCA_DCT_REGSIGN(i, r) ((0x%016xULL >> ((i) * 8 + (r))) & 1)" % sum(int(regsign[i][r]) << (i * 8 + r) for i in range(7) for r in range(8)))
+    out.append("#define HCA_DCT_VARIANT(i, r) ((0x%016xULL >> (((i) * 8 + (r)) * 2)) & 3)" % 0 if False else
+               "static const uint8_t HCA_DCT_VARIANT_TAB[7][8] = {" + ", ".join("{" + ", ".join(str(int(variant[i][r])) for r in range(8)) + "}" for i in range(7)) + "};")
+    out.append("/* logical DCT output index held by physical position p = lane16 * 8 + reg after the last stage */")
+    out.append("CRI_TABLE_QUAL uint8_t HCA_DCT_LOGICAL[128] = {" + ", ".join(str(int(v)) for v in L) + "};")
+    out.append("")
+    out.append("#endif")
+    return "\n".join(out) + "\n", variant, regsign
+
+
 def main():
     T = build()
     verify_against_reference(T)
@@ -291,6 +427,10 @@ def main():
         with open(os.path.join(ROOT, rel), "w") as f:
             f.write(text)
         print("wrote", rel)
+    imdct_text, variant, regsign = emit_imdct(T)
+    with open(os.path.join(ROOT, "pycricodecs_amd/csrc/cri_imdct_tables.h"), "w") as f:
+        f.write(imdct_text)
+    print("wrote pycricodecs_amd/csrc/cri_imdct_tables.h; variants per stage:", variant.tolist(), "reg signs:", regsign.tolist())
 
 
 if __name__ == "__main__":
