@@ -263,7 +263,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         a.fstat_offset = scratch;
         scratch += align_up((uint64_t)a.frames * 4, 256);
         a.resg_offset = scratch;
-        scratch += (uint64_t)((a.frames + 63) / 64) * a.channels * 8 * 64 * 8;
+        scratch += (uint64_t)((a.frames + 63) / 64) * a.channels * 8 * 64 * 16;
     }
     j->scratch_bytes = scratch;
     int rc = 0;

@@ -201,24 +201,40 @@ __device__ __forceinline__ uint32_t bb_peek(const BitBuf& b, int n) {
 __device__ __forceinline__ void bb_skip(BitBuf& b, int n) { b.buf <<= n; b.avail -= n; b.pos += n; }
 __device__ __forceinline__ uint32_t bb_read(BitBuf& b, const uint32_t* ring, int n) { bb_refill(b, ring); uint32_t v = bb_peek<true>(b, n); bb_skip(b, n); return v; }
 
-// one spectral symbol of resolution `res` (hca.cpp:1546-1563): returns the quantised value, advances the reader
+// One spectral symbol (hca.cpp:1546-1563).  `meta` = bits | nshort << 4 describes the band's code: `bits` = most bits a
+// symbol can take (hcatbdecoder_max_bit_table), and both code families reduce to one rule --
+//   code < 2*nshort : symbol = code >> 1, one bit is given back          (prefix codes: the short codewords;
+//   otherwise       : symbol = code - nshort                              sign-magnitude, nshort = 1: the zero)
+//   value = +ceil(symbol/2) for odd symbols, -symbol/2 for even ones
+// which reproduces read_bit/read_val for resolutions 1..7 (nshort = 2^bits - (2*res+1)) and the sign-magnitude form
+// with its "zero gives the sign bit back" rule for resolutions 8..15.  The caller refills once per two symbols.
 template <bool CHECKED>
-__device__ __forceinline__ int parse_symbol(BitBuf& bb, const uint32_t* ring, uint32_t res) {
-    const int bits = res > 7 ? (int)res - 3 : (int)((0x44443320u >> (res * 4)) & 15);   // hcatbdecoder_max_bit_table
-    bb_refill(bb, ring);
-    const uint32_t code = bb_peek<CHECKED>(bb, bits);
-    // res > 7: sign-magnitude (low bit = sign), a zero gives its sign bit back
-    const int mag = (int)(code >> 1);
-    const int valA = (code & 1) ? -mag : mag;
-    const int lenA = bits - (mag == 0 ? 1 : 0);
-    // res <= 7: truncated-binary prefix code over the alphabet 0,+1,-1,...,+res,-res
-    const uint32_t nshort = (1u << bits) - (2 * res + 1);
-    const bool is_short = code < 2 * nshort;
-    const uint32_t sym = is_short ? (code >> 1) : (code - nshort);
-    const int lenB = bits - ((is_short && bits) ? 1 : 0);
-    const int valB = (sym & 1) ? (int)((sym + 1) >> 1) : -(int)(sym >> 1);
-    bb_skip(bb, res > 7 ? lenA : lenB);
-    return res > 7 ? valA : valB;
+__device__ __forceinline__ int parse_symbol(BitBuf& bb, uint32_t meta) {
+    const uint32_t bits = meta & 15, ns = (meta >> 4) & 15;
+    const uint32_t code = bb_peek<CHECKED>(bb, (int)bits);
+    const bool is_short = code < 2 * ns;
+    const uint32_t sym = is_short ? (code >> 1) : (code - ns);
+    const uint32_t len = bits - (is_short ? 1u : 0u);
+    const uint32_t m = (sym + 1) >> 1;
+    bb.buf <<= len; bb.avail -= (int)len;
+    if (CHECKED) bb.pos += (int)len;
+    return (sym & 1) ? (int)m : -(int)m;
+}
+// refill for up to two symbols (24 bits): afterwards at least 32 bits are valid
+__device__ __forceinline__ void pair_refill(BitBuf& b, const uint32_t* ring) {
+    const bool need = b.avail <= 32;
+    const uint32_t pwm = need ? b.pw : 0u;
+    b.buf |= (uint64_t)pwm << ((32 - b.avail) & 63);
+    b.avail += need ? 32 : 0;
+    b.pw = need ? b.nw : b.pw;
+    b.rd += need ? 1u : 0u;
+    b.nw = ring[(b.rd & (RING_WORDS - 1)) * 64];
+}
+// code description of a band of resolution res (see parse_symbol)
+__device__ __forceinline__ uint32_t band_meta(uint32_t res) {
+    const uint32_t bits = res > 7 ? res - 3 : (0x44443320u >> (res * 4)) & 15;      // 0,2,3,3,4,4,4,4,5,...,12
+    const uint32_t ns = res > 7 ? 1u : (0x13571310u >> (res * 4)) & 15;             // 0,1,3,1,7,5,3,1
+    return bits | (ns << 4);
 }
 
 // transposed flush of the 16 staged words of every lane: frame fr's words go to its record + byte_off, 64 B per frame
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     recoff[lane] = valid ? ro : ~0ull;
     int status = valid ? ((const int32_t*)(a.scratch + a.fstat_offset))[g] : 0;
     // every lane parses (frames that failed sync/CRC and the zero padding of the last tile parse to ignored output)
-    uint64_t* resg = (uint64_t*)(a.scratch + a.resg_offset) + (uint64_t)tile * C * 8 * 64 + lane;
+    uint4* metag = (uint4*)(a.scratch + a.resg_offset) + (uint64_t)tile * C * 8 * 64 + lane;
 
     BitFeed fd;
     fd.next = (const uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64 + lane;
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         for (uint32_t blk = 0; blk < 8; blk++) {
             feed_checkpoint(fd, bb);
             uint32_t sfw[4] = {0, 0, 0, 0};
-            uint64_t resw = 0;
+            uint32_t mw[4] = {0, 0, 0, 0};
             if (blk * 16 < cs) {
 #pragma unroll
                 for (uint32_t k = 0; k < 16; k++) {               // hca.cpp:1310-1350, all lanes in lock step
@@ -307,10 +323,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                         res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)curve[cp] : 0u);
                         res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
                     }
-                    resw |= (uint64_t)res << (4 * k);
+                    mw[k >> 2] |= band_meta(res) << (8 * (k & 3));
                 }
             }
-            resg[(c * 8 + blk) * 64] = resw;
+            metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++) ostage[((blk & 3) * 4 + q) * 65 + lane] = sfw[q];
             if ((blk & 3) == 3) {
@@ -377,22 +393,27 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             const uint32_t nblk = (F.coded(c) + 15) >> 4;
             for (uint32_t blk = 0; blk < nblk; blk++) {
                 feed_checkpoint(fd, bb);
-                const uint64_t resw = resg[(c * 8 + blk) * 64];
+                const uint4 mv = metag[(c * 8 + blk) * 64];
+                const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
                 uint32_t words[8];
                 if (fast) {
+                    const int avail0 = bb.avail; const uint32_t rd0 = bb.rd;
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
-                        const int v0 = parse_symbol<false>(bb, ring, (uint32_t)(resw >> (8 * k)) & 15);
-                        const int v1 = parse_symbol<false>(bb, ring, (uint32_t)(resw >> (8 * k + 4)) & 15);
-                        words[k] = (uint32_t)(uint16_t)(int16_t)v0 | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
+                        pair_refill(bb, ring);
+                        const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
+                        const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
+                        words[k] = ((uint32_t)v0 & 0xFFFF) | ((uint32_t)v1 << 16);
                     }
+                    bb.pos += avail0 - bb.avail + 32 * (int)(bb.rd - rd0);
                 } else {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
-                        const int v0 = parse_symbol<true>(bb, ring, (uint32_t)(resw >> (8 * k)) & 15);
-                        const int v1 = parse_symbol<true>(bb, ring, (uint32_t)(resw >> (8 * k + 4)) & 15);
-                        words[k] = (uint32_t)(uint16_t)(int16_t)v0 | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
+                        pair_refill(bb, ring);
+                        const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
+                        const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
+                        words[k] = ((uint32_t)v0 & 0xFFFF) | ((uint32_t)v1 << 16);
                     }
                 }
 #pragma unroll

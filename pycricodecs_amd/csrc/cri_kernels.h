@@ -26,7 +26,7 @@ struct HcaDecArgs {
     uint32_t plain;                // 1: no HFR and no joint stereo in this format (spectra need dequantisation only)
     uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][R+1][64] uint32 (big-endian words)
     uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
-    uint64_t resg_offset;          // scratch byte offset of this group's resolution words: [tile][C][8 blocks][64 lanes] uint64
+    uint64_t resg_offset;          // scratch byte offset of this group's band code descriptions: [tile][C][8 blocks][64 lanes] uint4 (16 bands x 1 byte)
 };
 size_t hca_prepare_lds_bytes(uint32_t chunk_rows, uint32_t n_cipher);
 size_t hca_parse_lds_bytes(uint32_t channels);
