@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcricodecs_hip.so")
-SOURCES = ["cri_host.cpp", "cri_hca_dec.hip", "cri_adx.hip", "cri_misc.hip", "cri_capi.cpp"]
-HEADERS = ["cri_host.h", "cri_kernels.h", "cri_types.h", "cri_tables.h", "cri_device.h", "../../include/cricodecs_hip.h"]
+SOURCES = ["cri_host.cpp", "cri_hca_dec.hip", "cri_hca_enc.hip", "cri_adx.hip", "cri_misc.hip", "cri_capi.cpp"]
+HEADERS = ["cri_host.h", "cri_kernels.h", "cri_types.h", "cri_tables.h", "cri_imdct_tables.h", "cri_device.h", "../../include/cricodecs_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

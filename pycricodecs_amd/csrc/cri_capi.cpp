@@ -55,7 +55,9 @@ struct cri_job {
     AdxArgs adx{};
     CryptArgs crypt{};
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
-    std::vector<EncLaunch> hca_enc;
+    std::vector<HcaEncArgs> hca_enc;
+    std::vector<uint32_t> hca_enc_crc_off;       // per launch: offset into d_crcmul
+    DevBuf d_crcmul;
     uint32_t n_cipher = 0;
     // optional per-kernel-class event timing
     bool events_on = false;
@@ -440,8 +442,85 @@ extern "C" int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* off
     return create_hca_crypt(blob, offsets, n, encrypt, type, keys, subkeys, nullptr, job);
 }
 
-extern "C" int cri_job_create_hca_encode(const uint8_t*, const uint64_t*, uint32_t, uint32_t, uint32_t, cri_job**) {
-    return CRI_ERR_UNSUPPORTED;
+// ------------------------------------------------------------------------------------------------ HCA encode
+static uint16_t crc_xpow_bytes(uint32_t nbytes) {            // x^(8*nbytes) mod P (P = x^16 + x^15 + x^2 + 1)
+    uint32_t v = 1;
+    for (uint64_t i = 0; i < (uint64_t)nbytes * 8; i++) v = ((v << 1) ^ ((v & 0x8000) ? 0x8005u : 0u)) & 0xFFFF;
+    return (uint16_t)v;
+}
+
+extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t force_no_looping, uint32_t quality, cri_job** out) {
+    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    cri_job* j = new_job(CRI_JOB_HCA_ENCODE, offsets, n);
+    j->dominant = "k_hca_encode";
+    std::vector<HcaFormat> formats; std::vector<HcaStream> streams;
+    std::map<std::vector<uint32_t>, uint32_t> fmt_index;
+    uint64_t out_pos = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        j->out_offsets[i] = out_pos;
+        const uint8_t* d = blob + offsets[i];
+        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        WavInfo w;
+        int rc = wav_parse(d, len, w);
+        if (rc) { j->host_status[i] = rc; continue; }
+        if (w.looping && !force_no_looping) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // loop feeding path: next
+        if (!wav_is_pcm16(w)) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }
+        HcaEncSetup e;
+        rc = hca_enc_setup(w.channels, w.rate, w.column_size / w.channels, quality, e);
+        if (rc) { j->host_status[i] = rc; continue; }
+        std::vector<uint32_t> key = {e.channels, e.frame_size, e.total_bands, e.base_bands, e.stereo_bands, e.hfr_group_count,
+                                     e.bands_per_hfr_group, e.hfr_band_count, e.channel_config};
+        auto fi = fmt_index.find(key);
+        uint32_t fidx;
+        if (fi == fmt_index.end()) {
+            HcaFormat F; memset(&F, 0, sizeof F);
+            F.channels = e.channels; F.version = 0x0200; F.frame_size = e.frame_size; F.min_res = 1; F.max_res = 15;
+            F.total_bands = e.total_bands; F.base_bands = e.base_bands; F.stereo_bands = e.stereo_bands;
+            F.bands_per_hfr_group = e.bands_per_hfr_group; F.hfr_group_count = e.hfr_group_count; F.hfr_band_count = e.hfr_band_count;
+            for (uint32_t c = 0; c < 16; c++) { F.type[c] = e.type[c]; F.coded[c] = (uint8_t)e.coded[c]; }
+            fidx = (uint32_t)formats.size(); formats.push_back(F); fmt_index[key] = fidx;
+        } else fidx = fi->second;
+        Image head; head.dst = out_pos; head.bytes.assign(e.header_size, 0);
+        hca_pack_header(e, head.bytes.data());
+        j->images.push_back(std::move(head));
+        HcaStream S; memset(&S, 0, sizeof S);
+        S.src_offset = offsets[i] + w.data_offset; S.dst_offset = out_pos + e.header_size; S.format = fidx; S.frames = e.frame_count;
+        S.samples = e.samples_per_channel; S.item = i;
+        streams.push_back(S);
+        out_pos = align_up(out_pos + e.header_size + (uint64_t)e.frame_count * e.frame_size, 64);
+        j->units += e.frame_count;
+        j->alg_bytes += (uint64_t)e.frame_count * (e.frame_size + 2048ull * e.channels);
+    }
+    j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    std::stable_sort(streams.begin(), streams.end(), [](const HcaStream& a, const HcaStream& b) { return a.format < b.format; });
+    std::vector<uint16_t> crcmul;
+    for (size_t b = 0; b < streams.size();) {
+        size_t e = b; uint32_t frames = 0;
+        const HcaFormat& F = formats[streams[b].format];
+        while (e < streams.size() && streams[e].format == streams[b].format) { streams[e].first_frame = frames; frames += streams[e].frames; e++; }
+        HcaEncArgs a; memset(&a, 0, sizeof a);
+        a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
+        a.channels = F.channels; a.frame_size = F.frame_size; a.crc_chunk = (F.frame_size - 2 + 63) / 64;
+        j->hca_enc_crc_off.push_back((uint32_t)crcmul.size());
+        for (uint32_t k = 0; k < 6; k++) {
+            uint32_t v = crc_xpow_bytes(a.crc_chunk << k);
+            for (uint32_t bit = 0; bit < 16; bit++) { crcmul.push_back((uint16_t)v); v = ((v << 1) ^ ((v & 0x8000) ? 0x8005u : 0u)) & 0xFFFF; }
+        }
+        if (hca_encode_lds_bytes(F.channels, F.frame_size) > 160 * 1024) {
+            for (size_t s = b; s < e; s++) j->host_status[streams[s].item] = CRI_ERR_UNSUPPORTED;
+            a.frames = 0;
+        }
+        j->hca_enc.push_back(a);
+        b = e;
+    }
+    if (formats.empty()) { HcaFormat F; memset(&F, 0, sizeof F); formats.push_back(F); }
+    if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
+    if (crcmul.empty()) crcmul.assign(96, 0);
+    int rc = 0;
+    if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images())) { delete j; return rc; }
+    *out = j;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ run
@@ -475,6 +554,15 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
             j->mark(0, false, s);
             break;
         }
+        case CRI_JOB_HCA_ENCODE:
+            for (size_t k = 0; k < j->hca_enc.size(); k++) {
+                HcaEncArgs a = j->hca_enc[k];
+                a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status;
+                a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
+                a.crc_mul = (const uint16_t*)j->d_crcmul.p + j->hca_enc_crc_off[k];
+                j->mark(0, true, s); launch_hca_encode(a, s); j->mark(0, false, s);
+            }
+            break;
         case CRI_JOB_HCA_CRYPT: {
             CryptArgs a = j->crypt;
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.streams = (const HcaStream*)j->d_streams.p;
@@ -621,6 +709,7 @@ extern "C" int cri_hca_encode(const uint8_t* wav, size_t len, uint32_t force_no_
     cri_job* j = nullptr;
     int rc = cri_job_create_hca_encode(wav, offs, 1, force_no_looping, quality, &j);
     if (rc) return rc;
-    size_t item = (size_t)j->out_bytes;
+    size_t item = 0;
+    if (!j->host_status[0]) { const uint8_t* h = j->images[0].bytes.data(); item = (size_t)be16(h + 6) + (size_t)be32(h + 16) * be16(h + 28); }
     return run_single(j, wav, out, out_len, item);
 }

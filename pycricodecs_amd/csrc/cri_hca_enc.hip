@@ -1,0 +1,467 @@
+// cri_hca_enc.hip -- HCA encoder kernel for gfx950 (MI355X, wave64): one wave per frame, all channels.
+//
+// Replaces EncodeFrame and everything under it (/root/reference/CriCodecs/hca.cpp:2965-2988):
+//   PcmToFloat 2470-2479, mdct_transform 2529-2553 + DCT4 2481-2527, EncodeIntensityStereo 2561-2609,
+//   CalculateScaleFactors 2611-2637, ScaleSpectra 2639-2654, CalculateHfrGroupAverages 2656-2674, CalculateHfrScale
+//   2676-2706, CalculateFrameHeaderLength 2708-2750, CalculateNoiseLevel 2809-2832 / CalculateEvaluationBoundary
+//   2852-2866 (both searches over CalculateUsedBits 2763-2790), CalculateFrameResolutions 2868-2876, QuantizeSpectra
+//   2878-2892 and PackFrame 2894-2963 (incl. the frame CRC16).
+// The frame feeding of Encode/HcaEncode (hca.cpp:2990-3107, non-looping) reduces to "frame f = samples
+// [1024f, 1024f+1024), zero past the end, with the 128 samples before it as the MDCT history" and is done by indexing.
+//
+// Everything the reference evaluates in floating point is evaluated here with the same single IEEE operations in the
+// same order (sequential sums stay sequential, on one lane); bit allocation is integer work reduced across the wave;
+// the bitstream is assembled with a wave prefix sum over code lengths and LDS atomic ORs.
+#include <hip/hip_runtime.h>
+#include "cri_kernels.h"
+#include "cri_device.h"
+#include "../../include/cricodecs_hip.h"
+
+#define CRI_TABLE_QUAL static __device__ const
+#include "cri_tables.h"
+
+namespace cri {
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, uint32_t lane) {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+    return inc - v;
+}
+__device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
+    uint32_t t = (crc >> 8) ^ b;
+    uint32_t tt = (t << 1) ^ (t << 2) ^ ((__builtin_popcount(t) & 1) ? 0x8003u : 0u);
+    return ((crc << 8) & 0xFFFF) ^ tt;
+}
+__device__ __forceinline__ int enc_find_scalefactor(float v) {               // hca.cpp:2611-2623
+    uint32_t low = 0, high = 63;
+    while (low < high) { uint32_t mid = (low + high) / 2; if (HCA_DEQ_SCALE[mid] <= v) low = mid + 1; else high = mid; }
+    return (int)low;
+}
+__device__ __forceinline__ int enc_resolution(int sf, int noise) {           // hca.cpp:2752-2761
+    if (sf == 0) return 0;
+    int cp = noise - 5 * sf / 2 + 2;
+    cp = cp < 0 ? 0 : (cp > 58 ? 58 : cp);
+    return HCA_ENC_CURVE_TO_RES[cp];
+}
+__device__ __forceinline__ int enc_maxbits(int res) { return res > 7 ? res - 3 : (int)((0x44443320u >> (res * 4)) & 15); }
+
+struct EncLds {
+    float* sp;        // [C][8][128] spectra
+    float* sc;        // [C][8][128] scaled spectra
+    float* tin;       // [128] windowed MDCT input
+    float* tt;        // [128] DCT work buffer
+    uint32_t* words;  // frame as big-endian 32-bit words
+    uint8_t* sfac;    // [C][128]
+    uint8_t* res;     // [C][128]
+    uint8_t* inten;   // [C][8]
+    int* hfrs;        // [C][8] HFR scales
+    float* havg;      // [C][8]
+    float* ratio;     // [8]
+    int* hbits;       // [C] header bits
+    int* dbits;       // [C] delta bits
+};
+
+struct EncFmt {
+    uint32_t C, frame_size, total, base, stereo, groups, bpg, hfr_band_count, types;
+    __device__ __forceinline__ uint32_t type(uint32_t c) const { return (types >> (2 * c)) & 3u; }
+    __device__ __forceinline__ uint32_t coded(uint32_t c) const { return type(c) == CRI_CH_SECONDARY ? base : base + stereo; }
+};
+
+// CalculateFrameHeaderLength, hca.cpp:2708-2750
+__device__ __forceinline__ void enc_header_length(const EncFmt& F, const EncLds& L, uint32_t lane) {
+    for (uint32_t c = 0; c < F.C; c++) {
+        const int coded = (int)F.coded(c);
+        const uint8_t* sf = L.sfac + c * 128;
+        int any = 0;
+        for (int b = (int)lane; b < coded; b += 64) any |= sf[b] != 0;
+        any = wave_sum(any);
+        int min_len = 3, min_db = 0;
+        if (any) {
+            min_db = 6; min_len = 3 + 6 * coded;
+            for (int db = 1; db < 6; db++) {
+                const int maxd = (1 << (db - 1)) - 1;
+                int part = 0;
+                for (int b = (int)lane; b < coded; b += 64)
+                    if (b >= 1) { int d = (int)sf[b] - (int)sf[b - 1]; d = d < 0 ? -d : d; part += d > maxd ? db + 6 : db; }
+                const int length = 3 + 6 + wave_sum(part);
+                if (length < min_len) { min_len = length; min_db = db; }
+            }
+        }
+        if (F.type(c) == CRI_CH_SECONDARY) min_len += 32;
+        else if (F.groups > 0) min_len += 6 * (int)F.groups;
+        if (lane == 0) { L.hbits[c] = min_len; L.dbits[c] = min_db; }
+    }
+    __syncthreads();
+}
+
+// CalculateUsedBits, hca.cpp:2763-2790 (integer; reduced across the wave)
+__device__ __forceinline__ int enc_used_bits(const EncFmt& F, const EncLds& L, uint32_t lane, int noise_level, int eval_boundary) {
+    int part = 0;
+    for (uint32_t c = 0; c < F.C; c++) {
+        const int coded = (int)F.coded(c);
+        for (int i = (int)lane; i < coded; i += 64) {
+            const int noise = i < eval_boundary ? noise_level - 1 : noise_level;
+            const int res = enc_resolution(L.sfac[c * 128 + i], noise);
+            const float* x = L.sc + (c * 8) * 128 + i;
+            if (res >= 8) {
+                const int bits = enc_maxbits(res) - 1;
+                const float dz = HCA_ENC_DEAD_ZONE[res];
+                for (int j = 0; j < 8; j++) { part += bits; if (fabsf(x[j * 128]) >= dz) part++; }
+            } else {
+                const float inv = HCA_ENC_INV_STEP[res], up = inv + 1;
+                const int down = (int)((double)inv + 0.5 - 8);
+                for (int j = 0; j < 8; j++) { const int q = (int)(x[j * 128] * inv + up) - down; part += HCA_ENC_CODE_LEN[res][q & 15]; }
+            }
+        }
+    }
+    int length = 16 + 16 + 16 + wave_sum(part);
+    for (uint32_t c = 0; c < F.C; c++) length += L.hbits[c];
+    return length;
+}
+
+// MSB-first write of `len` bits of v at absolute bit position p of the frame (words are big-endian 32-bit)
+__device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v, uint32_t len) {
+    if (!len) return;
+    v &= len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1);
+    const uint32_t w = p >> 5;
+    const int shift = 32 - (int)(p & 31) - (int)len;
+    if (shift >= 0) atomicOr(&words[w], v << shift);
+    else { atomicOr(&words[w], v >> (-shift)); atomicOr(&words[w + 1], v << (32 + shift)); }
+}
+
+__global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const HcaFormat* Fp = a.formats + a.format;
+    EncFmt F;
+    F.C = Fp->channels; F.frame_size = Fp->frame_size; F.total = Fp->total_bands; F.base = Fp->base_bands; F.stereo = Fp->stereo_bands;
+    F.groups = Fp->hfr_group_count; F.bpg = Fp->bands_per_hfr_group; F.hfr_band_count = Fp->hfr_band_count;
+    { uint32_t t = 0; for (uint32_t c = 0; c < 16; c++) t |= (uint32_t)(Fp->type[c] & 3) << (2 * c); F.types = t; }
+    const uint32_t C = F.C, lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t nwords = (F.frame_size + 3) / 4 + 1;
+    EncLds L;
+    L.sp = (float*)smem; L.sc = L.sp + C * 1024; L.tin = L.sc + C * 1024; L.tt = L.tin + 128;
+    L.words = (uint32_t*)(L.tt + 128); L.havg = (float*)(L.words + nwords); L.ratio = L.havg + C * 8;
+    L.hfrs = (int*)(L.ratio + 8); L.hbits = L.hfrs + C * 8; L.dbits = L.hbits + C;
+    L.sfac = (uint8_t*)(L.dbits + C); L.res = L.sfac + C * 128; L.inten = L.res + C * 128;
+
+    // frame -> stream
+    uint32_t lo = a.stream_begin, hi = a.stream_end;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_frame <= g) lo = mid; else hi = mid; }
+    const HcaStream st = a.streams[lo];
+    const uint32_t f = g - st.first_frame;
+    const uint8_t* pcm = a.in + st.src_offset;
+    const int64_t nsamp = (int64_t)st.samples;
+    auto sample = [&](int64_t n, uint32_t c) -> float {      // PcmToFloat, hca.cpp:2470-2479 (+ zero history / zero tail)
+        if (n < 0 || n >= nsamp) return 0.0f;
+        const uint8_t* p = pcm + ((uint64_t)n * C + c) * 2;
+        const int v = (int)(int16_t)(p[0] | (p[1] << 8));
+        return (float)v * (float)(1.0f / 32768.0f);
+    };
+
+    // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553, 2481-2527
+    for (uint32_t c = 0; c < C; c++) {
+        for (uint32_t sf = 0; sf < 8; sf++) {
+            const int64_t n0 = (int64_t)f * 1024 + sf * 128;
+            {
+                const int i = (int)lane;
+                const float w_hi = sample(n0 + 64 + i, c), w_lo = sample(n0 + 63 - i, c);
+                const float p_lo = sample(n0 - 128 + i, c), p_hi = sample(n0 - 128 + 127 - i, c);
+                const float ta = HCA_WINDOW[63 - i] * -w_hi;
+                const float tb = -HCA_WINDOW[64 + i] * w_lo;
+                const float tc = HCA_WINDOW[i] * p_lo;
+                const float td = -HCA_WINDOW[127 - i] * p_hi;
+                L.tin[i] = ta - tb;
+                L.tin[64 + i] = tc - td;
+            }
+            __syncthreads();
+            {
+                const int i = (int)lane;
+                const float x = L.tin[2 * i], y = L.tin[127 - 2 * i], s = HCA_ENC_SIN[7][i], co = HCA_ENC_COS[7][i];
+                const float xc = x * co, ys = y * s, xs = x * s, yc = y * co;
+                L.tt[2 * i] = xc + ys;
+                L.tt[2 * i + 1] = xs - yc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int stage = 0; stage < 6; stage++) {
+                const int half_bits = 5 - stage, bsz = 1 << (6 - stage), bh = 1 << half_bits;
+                const int bf = (int)lane >> 1, comp = (int)lane & 1;
+                const int block = bf >> half_bits, i = bf & (bh - 1);
+                const int fp = (block * bsz + i) * 2, bp = fp + bsz;
+                const float A0 = L.tt[fp], A1 = L.tt[fp + 1], B0 = L.tt[bp], B1 = L.tt[bp + 1];
+                const float da = A0 - B0, db = A1 - B1;
+                const float s = HCA_ENC_SIN[half_bits][i], co = HCA_ENC_COS[half_bits][i];
+                float vf, vb;
+                if (comp == 0) { vf = A0 + B0; const float m1 = da * co, m2 = db * s; vb = m1 + m2; }
+                else { vf = A1 + B1; const float m1 = da * s, m2 = db * co; vb = m1 - m2; }
+                __syncthreads();
+                L.tt[fp + comp] = vf;
+                L.tt[bp + comp] = vb;
+                __syncthreads();
+            }
+            L.sp[(c * 8 + sf) * 128 + lane] = L.tt[HCA_ENC_SHUFFLE[lane]] * 0.125f;
+            L.sp[(c * 8 + sf) * 128 + 64 + lane] = L.tt[HCA_ENC_SHUFFLE[64 + lane]] * 0.125f;
+            __syncthreads();
+        }
+    }
+
+    // ---- EncodeIntensityStereo, hca.cpp:2561-2609 (sequential sums: one lane per subframe)
+    if (F.stereo > 0) {
+        for (uint32_t c = 0; c + 1 < C; c++) {
+            if (F.type(c) != CRI_CH_PRIMARY) continue;
+            float* lsp = L.sp + (c * 8) * 128; float* rsp = L.sp + ((c + 1) * 8) * 128;
+            if (lane < 8) {
+                const float* l = lsp + lane * 128; const float* r = rsp + lane * 128;
+                float el = 0, er = 0, et = 0;
+                for (uint32_t b = F.base; b < F.total; b++) { el += fabsf(l[b]); er += fabsf(r[b]); et += fabsf(l[b] + r[b]); }
+                et *= 2;
+                const float elr = er + el;
+                const float stored = 2 * el / elr;
+                float ratio = elr / et;
+                if (ratio < 0.5) ratio = 0.5f;
+                else if ((double)ratio > sqrt(2.0) / 2) ratio = (float)(sqrt(2.0) / 2);
+                int q = 1;
+                if (er > 0 || el > 0) { while (q < 13 && HCA_ENC_INTENSITY_BOUNDS[q] >= stored) q++; }
+                else { q = 0; ratio = 1; }
+                L.inten[(c + 1) * 8 + lane] = (uint8_t)q;
+                L.ratio[lane] = ratio;
+            }
+            __syncthreads();
+            for (uint32_t sf = 0; sf < 8; sf++) {
+                const float ratio = L.ratio[sf];
+                for (uint32_t b = F.base + lane; b < F.total; b += 64) {
+                    const float s = lsp[sf * 128 + b] + rsp[sf * 128 + b];
+                    lsp[sf * 128 + b] = s * ratio;
+                    rsp[sf * 128 + b] = 0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- CalculateScaleFactors + ScaleSpectra, hca.cpp:2625-2654
+    for (uint32_t c = 0; c < C; c++) {
+        const uint32_t coded = F.coded(c);
+        for (uint32_t b = lane; b < 128; b += 64) {
+            uint32_t s = 0;
+            if (b < coded) {
+                float mx = 0;
+                for (int sf = 0; sf < 8; sf++) { const float v = fabsf(L.sp[(c * 8 + sf) * 128 + b]); mx = (v < mx) ? mx : v; }
+                s = (uint32_t)enc_find_scalefactor(mx);
+            }
+            L.sfac[c * 128 + b] = (uint8_t)s;
+            for (int sf = 0; sf < 8; sf++) {
+                float v = 0;
+                if (b < coded) {
+                    v = L.sp[(c * 8 + sf) * 128 + b] * HCA_ENC_SCALE[s];
+                    if (v > 0.9999999f) v = 0.9999999f; else if (v < -0.9999999f) v = -0.9999999f;
+                    if (s == 0) v = 0;
+                }
+                L.sc[(c * 8 + sf) * 128 + b] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- CalculateHfrGroupAverages + CalculateHfrScale, hca.cpp:2656-2706 (sequential sums: one lane per group)
+    if (F.groups > 0) {
+        const int start = (int)(F.stereo + F.base), bpg = (int)F.bpg;
+        const int hb = (int)(F.hfr_band_count < F.total - F.hfr_band_count ? F.hfr_band_count : F.total - F.hfr_band_count);
+        for (uint32_t c = 0; c < C; c++) {
+            if (F.type(c) == CRI_CH_SECONDARY) continue;
+            if (lane < F.groups) {
+                const int grp = (int)lane;
+                {
+                    float sum = 0.0f; int count = 0;
+                    for (int i = 0; i < bpg; i++) {
+                        const int band = start + grp * bpg + i;
+                        if (band >= 128) break;
+                        for (int sf = 0; sf < 8; sf++) sum += fabsf(L.sp[(c * 8 + sf) * 128 + band]);
+                        count += 8;
+                    }
+                    L.havg[c * 8 + grp] = sum / (float)count;
+                }
+                {
+                    float sum = 0.0f; int count = 0;
+                    for (int i = 0; i < bpg; i++) {
+                        const int band = grp * bpg + i;
+                        if (band >= hb) break;
+                        for (int sf = 0; sf < 8; sf++) sum += fabsf(L.sc[(c * 8 + sf) * 128 + (start - band - 1)]);
+                        count += 8;
+                    }
+                    const float avg = sum / (float)count;
+                    float gs = L.havg[c * 8 + grp];
+                    if (avg > 0.0) {
+                        const double m = 1.0 / (double)avg, r2 = sqrt(2.0);
+                        gs = (float)((double)gs * (m < r2 ? m : r2));
+                    }
+                    L.havg[c * 8 + grp] = gs;
+                    L.hfrs[c * 8 + grp] = enc_find_scalefactor(gs);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- rate loop: CalculateNoiseLevel, CalculateEvaluationBoundary (hca.cpp:2792-2866)
+    enc_header_length(F, L, lane);
+    const int avail = (int)F.frame_size * 8;
+    int noise_level = -1, eval_boundary = 0, status = 0;
+    {
+        int highest = (int)(F.base + F.stereo) - 1;
+        for (;;) {
+            int low = 0, high = 255, mid_value = 0;
+            while (low != high) {
+                const int mid = (low + high) / 2;
+                mid_value = enc_used_bits(F, L, lane, mid, 0);
+                if (mid_value > avail) low = mid + 1; else high = mid;
+            }
+            noise_level = (low == 255 && mid_value > avail) ? -1 : low;
+            if (noise_level >= 0) break;
+            highest -= 2;
+            if (highest < 0) { status = CRI_ERR_HCA_ENCODE; break; }
+            __syncthreads();
+            if (lane < C) { L.sfac[lane * 128 + highest + 1] = 0; L.sfac[lane * 128 + highest + 2] = 0; }
+            __syncthreads();
+            enc_header_length(F, L, lane);
+        }
+    }
+    if (status == 0 && noise_level != 0) {
+        int low = 0, high = 127;
+        while ((high - low > 1) || (low - high > 1)) {
+            const int mid = (low + high) / 2;
+            const int v = enc_used_bits(F, L, lane, noise_level, mid);
+            if (avail < v) high = mid - 1; else low = mid;
+        }
+        int level;
+        if (low == high) level = low < 127 ? low : -1;
+        else level = enc_used_bits(F, L, lane, noise_level, high) > avail ? low : high;
+        if (level < 0) status = CRI_ERR_HCA_ENCODE; else eval_boundary = level;
+    }
+    uint8_t* dst = a.out + st.dst_offset + (uint64_t)f * F.frame_size;
+    if (status != 0) {
+        if (lane == 0 && a.status) atomicMin(a.status + st.item, status);
+        for (uint32_t i = lane; i < F.frame_size; i += 64) dst[i] = 0;
+        return;
+    }
+
+    // ---- CalculateFrameResolutions (hca.cpp:2868-2876)
+    for (uint32_t c = 0; c < C; c++)
+        for (uint32_t i = lane; i < 128; i += 64) {
+            int r = 0;
+            if (i < F.coded(c)) r = enc_resolution(L.sfac[c * 128 + i], (int)i < eval_boundary ? noise_level - 1 : noise_level);
+            L.res[c * 128 + i] = (uint8_t)r;
+        }
+    for (uint32_t i = lane; i < nwords; i += 64) L.words[i] = 0;
+    __syncthreads();
+
+    // ---- PackFrame (hca.cpp:2938-2963): sync word, 9+7 bit header, per channel scalefactors + intensity / HFR scales
+    uint32_t pos = 16;
+    if (lane == 0) { L.words[0] = 0xFFFF0000u; put_bits(L.words, 16, (uint32_t)noise_level, 9); put_bits(L.words, 25, (uint32_t)eval_boundary, 7); }
+    pos += 16;
+    for (uint32_t c = 0; c < C; c++) {
+        const int db = L.dbits[c], coded = (int)F.coded(c);
+        const uint8_t* sf = L.sfac + c * 128;
+        if (lane == 0) put_bits(L.words, pos, (uint32_t)db, 3);
+        pos += 3;
+        if (db == 6) {
+            for (int i = (int)lane; i < coded; i += 64) put_bits(L.words, pos + 6 * i, sf[i], 6);
+            pos += 6 * coded;
+        } else if (db != 0) {                                          // WriteScalesFactors, hca.cpp:2894-2918
+            const int maxd = (1 << (db - 1)) - 1, esc = (1 << db) - 1;
+            // bands 2*lane, 2*lane+1 per lane so that the prefix sum runs in band order
+            int len0 = 0, len1 = 0;
+            const int b0 = 2 * (int)lane, b1 = b0 + 1;
+            int d0 = 0, d1 = 0;
+            if (b0 < coded) { if (b0 == 0) len0 = 6; else { d0 = (int)sf[b0] - (int)sf[b0 - 1]; len0 = (d0 < 0 ? -d0 : d0) > maxd ? db + 6 : db; } }
+            if (b1 < coded) { d1 = (int)sf[b1] - (int)sf[b1 - 1]; len1 = (d1 < 0 ? -d1 : d1) > maxd ? db + 6 : db; }
+            const int off = wave_excl_scan(len0 + len1, lane);
+            if (b0 < coded) {
+                if (b0 == 0) put_bits(L.words, pos + off, sf[0], 6);
+                else if (len0 > db) { put_bits(L.words, pos + off, (uint32_t)esc, (uint32_t)db); put_bits(L.words, pos + off + db, sf[b0], 6); }
+                else put_bits(L.words, pos + off, (uint32_t)(maxd + d0), (uint32_t)db);
+            }
+            if (b1 < coded) {
+                if (len1 > db) { put_bits(L.words, pos + off + len0, (uint32_t)esc, (uint32_t)db); put_bits(L.words, pos + off + len0 + db, sf[b1], 6); }
+                else put_bits(L.words, pos + off + len0, (uint32_t)(maxd + d1), (uint32_t)db);
+            }
+            pos += (uint32_t)wave_sum(len0 + len1);
+        }
+        if (F.type(c) == CRI_CH_SECONDARY) {
+            if (lane < 8) put_bits(L.words, pos + 4 * lane, L.inten[c * 8 + lane], 4);
+            pos += 32;
+        } else if (F.groups > 0) {
+            if (lane < F.groups) put_bits(L.words, pos + 6 * lane, (uint32_t)L.hfrs[c * 8 + lane], 6);
+            pos += 6 * F.groups;
+        }
+    }
+    // spectra: QuantizeSpectra (hca.cpp:2878-2892) + WriteSpectra (2920-2936), bands 2*lane, 2*lane+1 per lane
+    for (uint32_t sf = 0; sf < 8; sf++) {
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t coded = F.coded(c);
+            uint32_t code[2] = {0, 0}, len[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t i = 2 * lane + h;
+                if (i >= coded) continue;
+                const int r = L.res[c * 128 + i];
+                if (r == 0) continue;
+                const float inv = HCA_ENC_INV_STEP[r], up = inv + 1;
+                const int down = (int)((double)inv + 0.5);
+                const int q = (int)(L.sc[(c * 8 + sf) * 128 + i] * inv + up) - down;
+                if (r < 8) { len[h] = HCA_ENC_CODE_LEN[r][(q + 8) & 15]; code[h] = HCA_ENC_CODE[r][(q + 8) & 15]; }
+                else {
+                    const uint32_t mb = (uint32_t)enc_maxbits(r) - 1, mag = (uint32_t)(q < 0 ? -q : q) & ((1u << mb) - 1);
+                    if (q != 0) { code[h] = (mag << 1) | (q > 0 ? 0u : 1u); len[h] = mb + 1; } else { code[h] = 0; len[h] = mb; }
+                }
+            }
+            const int off = wave_excl_scan((int)(len[0] + len[1]), lane);
+            // BitWriter drops writes that do not fit (IO.cpp:131-134); the rate loop guarantees they do
+            put_bits(L.words, pos + off, code[0], len[0]);
+            put_bits(L.words, pos + off + len[0], code[1], len[1]);
+            pos += (uint32_t)wave_sum((int)(len[0] + len[1]));
+        }
+    }
+    __syncthreads();
+
+    // ---- CRC16 over frame_size-2 bytes (hca.cpp:2961-2962), chunk per lane + log-step combine.
+    // The message is front-padded with zero bytes to 64*m bytes (leading zeros do not change a zero-init CRC).
+    {
+        const uint32_t n = F.frame_size - 2, m = a.crc_chunk, pad = 64 * m - n;
+        uint32_t crc = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t j = lane * m + k;
+            uint32_t b = 0;
+            if (j >= pad) { const uint32_t q = j - pad; b = (L.words[q >> 2] >> (24 - 8 * (q & 3))) & 0xFF; }
+            crc = crc16_step_enc(crc, b);
+        }
+        for (uint32_t k = 0; k < 6; k++) {
+            const uint32_t partner = (uint32_t)__shfl_down((int)crc, 1 << k);
+            uint32_t mul = 0;                                           // crc * x^(8*m*2^k) mod P
+            for (uint32_t bit = 0; bit < 16; bit++) if ((crc >> bit) & 1) mul ^= a.crc_mul[k * 16 + bit];
+            if ((lane & ((2u << k) - 1)) == 0) crc = mul ^ partner;
+        }
+        crc = (uint32_t)__shfl((int)crc, 0);
+        if (lane == 0) put_bits(L.words, (F.frame_size - 2) * 8, crc & 0xFFFF, 16);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < F.frame_size; i += 64) dst[i] = (uint8_t)(L.words[i >> 2] >> (24 - 8 * (i & 3)));
+}
+
+size_t hca_encode_lds_bytes(uint32_t C, uint32_t frame_size) {
+    const size_t nwords = (frame_size + 3) / 4 + 1;
+    return (size_t)C * 1024 * 4 * 2 + 256 * 4 + nwords * 4 + C * 8 * 4 + 8 * 4 + C * 8 * 4 + C * 4 * 2 + C * 128 * 2 + C * 8 + 64;
+}
+
+void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
+    if (!a.frames) return;
+    hipLaunchKernelGGL(k_hca_encode, dim3(a.frames), dim3(64), hca_encode_lds_bytes(a.channels, a.frame_size), s, a);
+}
+
+}  // namespace cri

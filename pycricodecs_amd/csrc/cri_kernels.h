@@ -34,6 +34,17 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s);
 void launch_hca_parse(const HcaDecArgs& a, hipStream_t s);
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);
 
+struct HcaEncArgs {
+    const uint8_t* in; uint8_t* out; int32_t* status;
+    const HcaFormat* formats;
+    const HcaStream* streams;      // sorted by format; src_offset = first PCM byte, dst_offset = first frame byte
+    const uint16_t* crc_mul;       // [6][16]: (x^bit * x^(8 * crc_chunk * 2^k)) mod P, for the log-step CRC combine
+    uint32_t format, stream_begin, stream_end, frames, channels, frame_size;
+    uint32_t crc_chunk;            // bytes of the (front-padded) frame each lane checksums
+};
+size_t hca_encode_lds_bytes(uint32_t channels, uint32_t frame_size);
+void launch_hca_encode(const HcaEncArgs& a, hipStream_t s);
+
 struct AdxArgs {
     const uint8_t* in; uint8_t* out; int32_t* status;
     const AdxStream* streams;

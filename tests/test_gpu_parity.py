@@ -148,6 +148,53 @@ def test_hca_v2_random_frame_fuzz(cc):
             assert diff(cc.HcaDecode(f, hs, 0, 0), ref) is None, (q, ch, seed)
 
 
+# ------------------------------------------------------------------------------------------------ HCA encode
+@pytest.mark.parametrize("case", MAN["cases"], ids=lambda c: c["wav"])
+def test_golden_hca_encode(cc, case):
+    w = G.load(case["wav"])
+    for h in case["hca"]:
+        assert diff(cc.HcaEncode(w, 0, h["quality"]), G.load(h["file"])) is None, h["file"]
+
+
+@pytest.mark.parametrize("seed,n,ch,sr", [(0, 4800, 2, 48000), (1, 9600, 1, 44100), (2, 3008, 2, 22050), (3, 100, 2, 48000),
+                                            (4, 30000, 2, 32000), (5, 2048, 1, 48000), (6, 4096, 4, 48000), (7, 2500, 6, 48000),
+                                            (8, 1024, 2, 48000), (9, 7000, 8, 48000), (10, 6000, 3, 48000)])
+@pytest.mark.parametrize("q", [0, 1, 2, 3, 4, 5])
+def test_hca_encode_vs_oracle(cc, seed, n, ch, sr, q):
+    w = synth.wav(seed, n, ch, sr)
+    assert diff(cc.HcaEncode(w, 0, q), O.hca_encode(w, q)) is None
+
+
+def test_hca_encode_special_signals(cc):
+    n = 4096
+    silence = synth.wav_bytes(np.zeros((n, 2), dtype=np.int16), 48000)
+    full = np.zeros((n, 2), dtype=np.int16)
+    full[::2] = 32767
+    full[1::2] = -32768
+    loud = synth.wav_bytes(full, 48000)
+    rng = np.random.default_rng(5)
+    noise = synth.wav_bytes(rng.integers(-32768, 32767, (n, 2), dtype=np.int16), 48000)
+    left_only = np.zeros((n, 2), dtype=np.int16)
+    left_only[:, 0] = synth.pcm16(3, n, 1)[:, 0]
+    for w in (silence, loud, noise, synth.wav_bytes(left_only, 48000)):
+        for q in (1, 2, 3):
+            assert diff(cc.HcaEncode(w, 0, q), O.hca_encode(w, q)) is None, q
+
+
+def test_front_end_encode_roundtrip(cc):
+    from pycricodecs_amd import HCA, CriHcaQuality
+    w = synth.wav(11, 5000, 2, 48000)
+    h = HCA(w, key=KEY)
+    enc = h.encode(encrypt=True, quality_level=CriHcaQuality.Middle)
+    ref = O.hca_crypt(O.hca_encode(w, 2), 1, 56, KEY)
+    assert diff(enc, ref) is None
+    assert h.encrypted and h.hca["CipherType"] == 0 and h.filetype == "wav"   # header re-parsed before encrypting, like the reference
+    assert diff(HCA(enc, key=KEY).decode(), O.hca_decode(ref, KEY)) is None
+    h2 = HCA(enc, key=KEY)
+    h2.decrypt(KEY)
+    assert diff(h2.get_hca(), O.hca_encode(w, 2)) is None
+
+
 # ------------------------------------------------------------------------------------------------ batch jobs
 def test_batch_mixed_formats(cc):
     from pycricodecs_amd.batch import Job
