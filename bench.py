@@ -74,6 +74,68 @@ def cpu_baseline_hca_decode(stream, seconds=10.0):
             "sample": "%d x decode of one 10 s stream (%d frames), oracle/cri_oracle.c, single thread" % (reps, frames)}
 
 
+def measure(job, dev, steps=3, warmup=1):
+    import torch
+    bufs = job.alloc(dev)
+    job.enable_events(True)
+    for _ in range(warmup):
+        job.run(*bufs)
+    torch.cuda.synchronize()
+    kms = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.run(*bufs)
+        for k, v in job.event_ms().items():
+            kms[k] = kms.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert int((bufs[3] != 0).sum().item()) == 0
+    dom = max(kms, key=kms.get)
+    return bufs, {"ms_per_step": round(dt * 1e3, 3), "units_per_s": round(job.units / dt, 1), "units2_per_s": round(job.units2 / dt, 1),
+                  "kernel_ms": {k: round(v / steps, 3) for k, v in kms.items()},
+                  "achieved_GBps": round(job.algorithmic_bytes / (kms[dom] / steps * 1e-3) / 1e9, 2)}
+
+
+def secondary_measurements(args, dev, rank):
+    """HCA encode and ADX encode/decode on `--secondary-streams` 10 s stereo WAVs (tiled from the unique set)."""
+    import torch
+    import oracle_lib as O
+    from pycricodecs_amd import synth
+    from pycricodecs_amd.batch import Job
+    n = args.secondary_streams
+    uniq = [synth.wav(5000 + 1000 * rank + u, int(48000 * args.seconds) // 32 * 32, 2, 48000) for u in range(min(args.unique, 16))]
+    wavs = [uniq[i % len(uniq)] for i in range(n)]
+    res = {}
+    job = Job.hca_encode(wavs, quality=1)
+    bufs, r = measure(job, dev)
+    blob = bytes(bufs[1][:int(job.output_offsets[1])].cpu().numpy())
+    ref = O.hca_encode(wavs[0], 1)
+    assert blob[:len(ref)] == ref, "GPU HCA encode differs from the oracle"
+    r.update(workload="HCA encode (quality High), %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), unit="frames/s", frames=job.units)
+    res["hca_encode"] = r
+    del bufs
+    torch.cuda.empty_cache()
+    job = Job.adx_encode(wavs)
+    bufs, r = measure(job, dev)
+    adx0 = bytes(bufs[1][:int(job.output_offsets[1])].cpu().numpy())
+    ref = O.adx_encode(wavs[0])
+    assert adx0[:len(ref)] == ref, "GPU ADX encode differs from the oracle"
+    r.update(workload="ADX encode bs18/bd4/mode3/v4, %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), unit="frames/s (units2 = blocks/s)",
+             chains=2 * n, blocks=job.units2)
+    res["adx_encode"] = r
+    del bufs
+    torch.cuda.empty_cache()
+    adx_u = [O.adx_encode(w) for w in uniq]
+    job = Job.adx_decode([adx_u[i % len(adx_u)] for i in range(n)])
+    bufs, r = measure(job, dev)
+    wav0 = bytes(bufs[1][:int(job.output_offsets[1])].cpu().numpy())
+    ref = O.adx_decode(adx_u[0])
+    assert wav0[:len(ref)] == ref, "GPU ADX decode differs from the oracle"
+    r.update(workload="ADX decode of the same files", unit="frames/s (units2 = blocks/s)", chains=2 * n, blocks=job.units2)
+    res["adx_decode"] = r
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +146,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "adx_roundtrip"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--secondary-streams", type=int, default=1000)
     args = ap.parse_args()
 
     import torch
@@ -174,6 +238,11 @@ def main():
                      "algorithmic_bytes_per_launch": job.algorithmic_bytes, "bytes_per_unit": unit_bytes,
                      "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kernel_ms.items()}},
     }
+    # ---- secondary figures of the same hot path (smaller batches, few steps): HCA encode, ADX encode + decode (configs[1], [3])
+    if rank == 0 and not args.no_secondary:
+        del d_in, d_out, d_scratch, d_status
+        torch.cuda.empty_cache()
+        out["secondary"] = secondary_measurements(args, dev, rank)
     if rank == 0 and not args.no_cpu:
         if args.workload == "hca_decode":
             out["cpu_baseline"] = cpu_baseline_hca_decode(items[0])

@@ -28,6 +28,10 @@ def _stale():
 
 def build(force=False, verbose=True):
     if not force and not _stale():
+        import sysconfig
+        ext = os.path.join(LIBDIR, "CriCodecs" + sysconfig.get_config_var("EXT_SUFFIX"))
+        if not os.path.exists(ext) or os.path.getmtime(os.path.join(CSRC, "pyext", "CriCodecs_ext.cpp")) > os.path.getmtime(ext):
+            build_extension(verbose)
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -43,7 +47,20 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    build_extension(verbose)
     return LIB
+
+
+def build_extension(verbose=True):
+    """The drop-in CPython module `CriCodecs` (csrc/pyext): plain g++, it only dlopen()s the HIP library."""
+    import sysconfig
+    src = os.path.join(CSRC, "pyext", "CriCodecs_ext.cpp")
+    out = os.path.join(LIBDIR, "CriCodecs" + sysconfig.get_config_var("EXT_SUFFIX"))
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], src, "-o", out, "-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
 
 
 if __name__ == "__main__":

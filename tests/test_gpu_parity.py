@@ -233,3 +233,28 @@ def test_batch_adx_roundtrip(cc):
     assert not st.any()
     for p, a in zip(pcm, adx):
         assert diff(p, O.adx_decode(a)) is None
+
+
+def test_drop_in_extension_module(cc):
+    """The CPython module `CriCodecs` built from csrc/pyext gives the same bytes as the ctypes binding."""
+    import importlib.util
+    import os
+    import sysconfig
+    from pycricodecs_amd import build
+    path = os.path.join(build.LIBDIR, "CriCodecs" + sysconfig.get_config_var("EXT_SUFFIX"))
+    spec = importlib.util.spec_from_file_location("CriCodecs", path)
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+    w = synth.wav(21, 4000, 2, 48000)
+    adx = ext.AdxEncode(w, 4, 18, 3, 500, 0, 4, False)
+    assert adx == cc.AdxEncode(w, 4, 18, 3, 500, 0, 4, False) == O.adx_encode(w)
+    assert ext.AdxDecode(adx) == O.adx_decode(adx)
+    hca = ext.HcaEncode(w, 0, 1)
+    assert hca == O.hca_encode(w, 1)
+    enc = ext.HcaCrypt(hca, 1, 96, 56, KEY, 0)
+    assert enc == O.hca_crypt(hca, 1, 56, KEY) and hca == O.hca_encode(w, 1)      # input not mutated
+    assert ext.HcaDecode(enc, 96, KEY, 0) == O.hca_decode(enc, KEY)
+    with pytest.raises(ValueError, match="Decoding error"):
+        ext.HcaDecode(enc, 96, KEY + 2, 0)
+    with pytest.raises(ValueError, match="Bitdepth"):
+        ext.AdxEncode(w, 1, 18, 3, 500, 0, 4, False)
