@@ -1,6 +1,16 @@
-// cri_adx.hip -- ADX kernels for gfx950, one lane per (file, channel) chain.
+// cri_adx.hip -- ADX kernels for gfx950, one lane per (file, channel) chain, LDS-staged.
 //   k_adx_decode     ChannelFrame::Decode /root/reference/CriCodecs/adx.cpp:189-214 + block loop 404-413
 //   k_adx_encode     ChannelFrame::Encode adx.cpp:215-273 + frame loop 492-497
+//
+// The ADPCM recurrence  s = clamp(d*scale + (c0*h1 >> 12) + (c1*h2 >> 12))  has two floor shifts and a clamp inside the
+// loop, so it is not an associative scan: the only exact parallelism is across chains.  A wave therefore owns 64 chains
+// (32 stereo files) and advances them in lock step, T block rows per round:
+//   1. the wave copies, file by file, the next T rows of compressed blocks (decode) / PCM (encode) from HBM into LDS with
+//      fully coalesced 256-byte loads (the blocks of one file are contiguous: ch0,ch1,ch0,ch1,...),
+//   2. every lane runs its chain over its T blocks out of LDS and leaves the result in LDS in the file's output layout
+//      (interleaved PCM16 / interleaved blocks),
+//   3. the wave copies the output regions to HBM, again 256 contiguous bytes per instruction.
+// File regions in LDS are padded by 4 bytes each so that the lanes of a wave fall on different banks.
 #include <hip/hip_runtime.h>
 #include "cri_kernels.h"
 #include "cri_device.h"
@@ -10,115 +20,308 @@
 #include "cri_tables.h"
 
 namespace cri {
-// ------------------------------------------------------------------------------------------------------------
-// ADX: one lane per (file, channel) chain
-// ------------------------------------------------------------------------------------------------------------
-__global__ void k_adx_decode(AdxArgs a) {
-    const uint32_t chain = blockIdx.x * blockDim.x + threadIdx.x;
-    if (chain >= a.chains) return;
-    const AdxStream S = a.streams[a.chain_stream[chain]];
-    const uint32_t ch = chain - S.first_chain, C = S.channels, bs = S.blocksize, bd = S.bitdepth, spb = S.samples_per_block;
-    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+
+// wave-cooperative copy HBM -> LDS of nbytes (LDS offset 4-byte aligned, global address arbitrary); bytes at or past
+// `limit` read as zero
+__device__ __forceinline__ void copy_in(uint8_t* lds, const uint8_t* src, const uint8_t* limit, uint32_t nbytes, uint32_t lane) {
+    const uint32_t nd = (nbytes + 3) >> 2;
+    for (uint32_t d = lane; d < nd; d += 64) {
+        const uint8_t* p = src + 4 * (uint64_t)d;
+        uint32_t v = 0;
+        if (p + 4 <= limit) v = ld_u32_unaligned(p);
+        else for (int k = 0; k < 4; k++) if (p + k < limit) v |= (uint32_t)p[k] << (8 * k);
+        ((uint32_t*)lds)[d] = v;
+    }
+}
+// wave-cooperative copy LDS -> HBM of nbytes (multiple of 2; dst 2-byte aligned at least)
+__device__ __forceinline__ void copy_out(uint8_t* dst, const uint8_t* lds, uint32_t nbytes, uint32_t lane) {
+    const uint32_t nd = nbytes >> 2;
+    const bool al4 = (((uint64_t)dst) & 3) == 0;
+    for (uint32_t d = lane; d < nd; d += 64) {
+        const uint32_t v = ((const uint32_t*)lds)[d];
+        if (al4) ((uint32_t*)dst)[d] = v;
+        else { uint8_t* q = dst + 4 * (uint64_t)d; q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); q[3] = (uint8_t)(v >> 24); }
+    }
+    for (uint32_t b = (nd << 2) + lane; b < nbytes; b += 64) dst[b] = lds[b];
+}
+
+
+// Stage-in of one round for the whole wave: the files' regions are fetched B files at a time with every load of a batch
+// issued before the first LDS store, so a round pays a handful of memory latencies instead of one per file.
+// lim_* / src_* / off_* / nb_* are per-lane values of the file LEADER lanes (read with readlane).
+template <int B, int Q>
+__device__ __forceinline__ void stage_in(uint8_t* lds_base, uint64_t leaders, uint32_t lane, uint64_t src_l, uint64_t lim_l, uint32_t off_l, uint32_t nbytes_l) {
+    while (leaders) {
+        int ls[B]; int n = 0;
+#pragma unroll
+        for (int j = 0; j < B; j++) { ls[j] = 0; if (leaders) { ls[j] = __builtin_ctzll(leaders); leaders &= leaders - 1; n = j + 1; } }
+        uint32_t v[B][Q];
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (j >= n) continue;
+            const uint8_t* p = (const uint8_t*)readlane64(src_l, ls[j]);
+            const uint8_t* lim = (const uint8_t*)readlane64(lim_l, ls[j]);
+            const uint32_t nd = (__builtin_amdgcn_readlane(nbytes_l, ls[j]) + 3) >> 2;
+            if (nd > 64 * Q) { big = true; continue; }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const uint32_t d = lane + 64 * q;
+                v[j][q] = 0;
+                if (d < nd) {
+                    const uint8_t* a = p + 4 * (uint64_t)d;
+                    if (a + 4 <= lim) v[j][q] = ld_u32_unaligned(a);
+                    else for (int k = 0; k < 4; k++) if (a + k < lim) v[j][q] |= (uint32_t)a[k] << (8 * k);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (j >= n) continue;
+            const uint32_t nb = __builtin_amdgcn_readlane(nbytes_l, ls[j]), nd = (nb + 3) >> 2;
+            uint8_t* l = lds_base + __builtin_amdgcn_readlane(off_l, ls[j]);
+            if (nd > 64 * Q) { copy_in(l, (const uint8_t*)readlane64(src_l, ls[j]), (const uint8_t*)readlane64(lim_l, ls[j]), nb, lane); continue; }
+#pragma unroll
+            for (int q = 0; q < Q; q++) { const uint32_t d = lane + 64 * q; if (d < nd) ((uint32_t*)l)[d] = v[j][q]; }
+        }
+        (void)big;
+    }
+}
+
+struct ChainCtx {
+    AdxStream S; uint32_t ch; bool valid, leader;
+    uint32_t in_off, out_off;       // LDS offsets of this chain's FILE regions
+};
+
+// LDS region offsets: prefix sums over the wave's files (leaders), +4 bytes of padding per region
+__device__ __forceinline__ void plan_regions(ChainCtx& X, uint32_t in_bytes, uint32_t out_bytes, uint32_t lane, uint32_t& in_total, uint32_t& out_total) {
+    const uint32_t ib = X.leader ? ((in_bytes + 3) & ~3u) + 4 : 0, ob = X.leader ? ((out_bytes + 3) & ~3u) + 4 : 0;
+    uint32_t ipre = ib, opre = ob;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ti = __shfl_up(ipre, o), to = __shfl_up(opre, o);
+        if ((int)lane >= o) { ipre += ti; opre += to; }
+    }
+    in_total = __shfl(ipre, 63); out_total = __shfl(opre, 63);
+    // a non-leader lane uses its file's leader offsets (leader = lane - ch)
+    const uint32_t iex = ipre - ib, oex = opre - ob;
+    X.in_off = __shfl(iex, (int)(lane - X.ch)); X.out_off = __shfl(oex, (int)(lane - X.ch));
+}
+
+__global__ __launch_bounds__(64) void k_adx_decode(AdxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x, chain = blockIdx.x * 64 + lane, T = a.rows_per_round;
+    ChainCtx X;
+    const uint32_t sidx = chain < a.chains ? a.chain_stream[chain] : 0xFFFFFFFFu;   // the planner pads so that a file never straddles waves
+    X.valid = sidx != 0xFFFFFFFFu;
+    X.S = a.streams[X.valid ? sidx : 0];
+    X.ch = X.valid ? chain - X.S.first_chain : 0;
+    X.leader = X.valid && X.ch == 0;
+    const AdxStream& S = X.S;
+    const uint32_t C = S.channels, bs = S.blocksize, bd = S.bitdepth, spb = S.samples_per_block;
+    uint32_t in_total, out_total;
+    plan_regions(X, T * C * bs, T * spb * C * 2, lane, in_total, out_total);
+    uint8_t* lin = smem;
+    uint8_t* lout = smem + a.lds_in_bytes;
+    int32_t h1 = X.valid ? a.history[2 * chain] : 0, h2 = X.valid ? a.history[2 * chain + 1] : 0;
     int32_t c0 = S.coef0, c1 = S.coef1;
     const uint8_t* src = a.in + S.src_offset;
     const uint8_t* end = a.in + S.src_end;
-    int16_t* out = (int16_t*)(a.out + S.dst_offset);
-    uint32_t done = 0;
-    for (uint32_t fr = 0; fr < S.frames; fr++) {
-        const uint8_t* fb = src + (uint64_t)fr * bs * C;
-        if (fb + 2 > end) break;
-        if (fb[0] == 0x80 && fb[1] == 0x01) break;              // EOF scale (adx.cpp:405-406)
-        if (fb + (uint64_t)bs * C > end) break;
-        const uint8_t* blk = fb + ch * bs;
-        int32_t scale = ((int32_t)blk[0] << 8) | blk[1];
-        if (S.mode == 4) scale = (int32_t)(1u << ((12 - scale) & 31));
-        else if (S.mode == 2) {
-            uint32_t pred = ((uint32_t)scale >> 13) & 7;
-            scale = (scale & 0x1FFF) + 1;
-            c0 = pred < 4 ? ADX_STATIC_COEFS[pred * 2] : 0;
-            c1 = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
-        } else scale += 1;
-        uint32_t acc = 0, have = 0, bytepos = 2;
-        for (uint32_t s = 0; s < spb; s++) {
-            while (have < bd) { acc = (acc << 8) | blk[bytepos++]; have += 8; }
-            uint32_t raw = (acc >> (have - bd)) & ((1u << bd) - 1);
-            have -= bd;
-            int32_t v = (int32_t)(raw << (32 - bd)) >> (32 - bd);
-            v = v * scale + ((c0 * h1) >> 12) + ((c1 * h2) >> 12);
-            v = clamp_sym(v, 0x7FFF);
-            const uint64_t idx = (uint64_t)fr * spb + s;
-            if (idx < S.samples) out[idx * C + ch] = (int16_t)v;
-            h2 = h1; h1 = (int32_t)(int16_t)v;
+    uint8_t* dst = a.out + S.dst_offset;
+    bool stopped = !X.valid;
+    const bool std4 = __all(!X.valid || (bs == 18 && bd == 4 && S.mode != 4));   // mode 4 scales can exceed 24 bits
+    uint32_t max_frames = X.valid ? S.frames : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(max_frames, o); max_frames = t > max_frames ? t : max_frames; }
+
+    for (uint32_t f0 = 0; f0 < max_frames; f0 += T) {
+        // 1. stage the next T rows of every file of this wave
+        {
+            const bool act = X.leader && f0 < S.frames;
+            const uint32_t nrows = act ? (S.frames - f0 < T ? S.frames - f0 : T) : 0;
+            stage_in<16, 2>(lin, __ballot(act), lane, (uint64_t)(src + (uint64_t)f0 * C * bs), (uint64_t)end, X.in_off, nrows * C * bs);
         }
-        done = fr + 1;
+        __syncthreads();
+        // 2. every lane decodes its chain's T blocks out of LDS
+        if (X.valid) {
+            const uint8_t* fin = lin + X.in_off;
+            int16_t* fo = (int16_t*)(lout + X.out_off);
+            for (uint32_t t = 0; t < T && f0 + t < S.frames; t++) {
+                const uint32_t fr = f0 + t;
+                const uint8_t* row = fin + t * C * bs;
+                const uint64_t row_global = (uint64_t)fr * C * bs;
+                if (!stopped) {
+                    // EOF scale on the row's first block, or a row the input does not fully contain (adx.cpp:405-406)
+                    if (src + row_global + (uint64_t)bs * C > end || (row[0] == 0x80 && row[1] == 0x01)) stopped = true;
+                }
+                const uint8_t* blk = row + X.ch * bs;
+                int32_t scale = ((int32_t)blk[0] << 8) | blk[1];
+                if (S.mode == 4) scale = (int32_t)(1u << ((12 - scale) & 31));
+                else if (S.mode == 2) {
+                    const uint32_t pred = ((uint32_t)scale >> 13) & 7;
+                    scale = (scale & 0x1FFF) + 1;
+                    c0 = pred < 4 ? ADX_STATIC_COEFS[pred * 2] : 0;
+                    c1 = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
+                } else scale += 1;
+                int16_t* o = fo + (uint64_t)t * spb * C + X.ch;
+                if (std4) {
+                    // blocksize 18 / bitdepth 4: 8 big-endian 16-bit words of four codes each; 24-bit multiplies are exact here
+                    // (|code| < 2^3, scale < 2^14, |coef| < 2^13, |history| < 2^15)
+#pragma unroll
+                    for (uint32_t w = 0; w < 8; w++) {
+                        const uint32_t wd = ((uint32_t)blk[2 + 2 * w] << 8) | blk[3 + 2 * w];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const int32_t code = (int32_t)(wd << (16 + 4 * k)) >> 28;
+                            int32_t v = __mul24(code, scale) + (__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12);
+                            v = clamp_sym(v, 0x7FFF);
+                            if (stopped) v = 0; else { h2 = h1; h1 = v; }
+                            o[(uint64_t)(4 * w + k) * C] = (int16_t)v;
+                        }
+                    }
+                    continue;
+                }
+                uint32_t acc = 0, have = 0, bytepos = 2;
+                for (uint32_t s = 0; s < spb; s++) {
+                    while (have < bd) { acc = (acc << 8) | blk[bytepos++]; have += 8; }
+                    const uint32_t raw = (acc >> (have - bd)) & ((1u << bd) - 1);
+                    have -= bd;
+                    int32_t v = (int32_t)(raw << (32 - bd)) >> (32 - bd);
+                    v = v * scale + ((c0 * h1) >> 12) + ((c1 * h2) >> 12);
+                    v = clamp_sym(v, 0x7FFF);
+                    if (stopped) v = 0;                                   // rows never reached decode to silence
+                    else { h2 = h1; h1 = v; }
+                    o[(uint64_t)s * C] = (int16_t)v;
+                }
+            }
+        }
+        __syncthreads();
+        // 3. copy the decoded rows out, clipped to the stream's sample count
+        for (uint32_t l = 0; l < 64; l++) {
+            if (!__builtin_amdgcn_readlane((int)X.leader, l)) continue;
+            const uint32_t frames_l = __builtin_amdgcn_readlane(S.frames, l);
+            if (f0 >= frames_l) continue;
+            const uint32_t spb_l = __builtin_amdgcn_readlane(spb, l), C_l = __builtin_amdgcn_readlane(C, l), samples_l = __builtin_amdgcn_readlane(S.samples, l);
+            const uint32_t nrows = frames_l - f0 < T ? frames_l - f0 : T;
+            uint64_t s0 = (uint64_t)f0 * spb_l, s1 = s0 + (uint64_t)nrows * spb_l;
+            if (s1 > samples_l) s1 = samples_l;
+            if (s1 <= s0) continue;
+            uint8_t* q = (uint8_t*)readlane64((uint64_t)dst, l) + s0 * C_l * 2;
+            copy_out(q, lout + __builtin_amdgcn_readlane(X.out_off, l), (uint32_t)((s1 - s0) * C_l * 2), lane);
+        }
+        __syncthreads();
     }
-    // rows never reached (EOF marker / truncated input) decode to silence (the reference leaves them uninitialised)
-    for (uint64_t idx = (uint64_t)done * spb; idx < S.samples; idx++) out[idx * C + ch] = 0;
 }
+
 void launch_adx_decode(const AdxArgs& a, hipStream_t s) {
-    if (a.chains) hipLaunchKernelGGL(k_adx_decode, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
+    if (a.chains) hipLaunchKernelGGL(k_adx_decode, dim3((a.chains + 63) / 64), dim3(64), a.lds_in_bytes + a.lds_out_bytes, s, a);
 }
 
-__device__ __forceinline__ int32_t adx_sample(const uint8_t* pcm, uint64_t idx, uint32_t C, uint32_t ch, uint32_t valid) {
-    if (idx >= valid) return 0;                                  // zero padding of the last rows (adx.cpp:453-456)
-    const uint8_t* p = pcm + (idx * C + ch) * 2;
-    return (int32_t)(int16_t)(p[0] | (p[1] << 8));
-}
-
-__global__ void k_adx_encode(AdxArgs a) {
-    const uint32_t chain = blockIdx.x * blockDim.x + threadIdx.x;
-    if (chain >= a.chains) return;
-    const AdxStream S = a.streams[a.chain_stream[chain]];
-    const uint32_t ch = chain - S.first_chain, C = S.channels, bs = S.blocksize, bd = S.bitdepth, spb = S.samples_per_block;
-    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+__global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = threadIdx.x, chain = blockIdx.x * 64 + lane, T = a.rows_per_round;
+    ChainCtx X;
+    const uint32_t sidx = chain < a.chains ? a.chain_stream[chain] : 0xFFFFFFFFu;
+    X.valid = sidx != 0xFFFFFFFFu;
+    X.S = a.streams[X.valid ? sidx : 0];
+    X.ch = X.valid ? chain - X.S.first_chain : 0;
+    X.leader = X.valid && X.ch == 0;
+    const AdxStream& S = X.S;
+    const uint32_t C = S.channels, bs = S.blocksize, bd = S.bitdepth, spb = S.samples_per_block;
+    uint32_t in_total, out_total;
+    plan_regions(X, T * spb * C * 2, T * C * bs, lane, in_total, out_total);
+    uint8_t* lin = smem;
+    uint8_t* lout = smem + a.lds_in_bytes;
+    int32_t h1 = X.valid ? a.history[2 * chain] : 0, h2 = X.valid ? a.history[2 * chain + 1] : 0;
     const int32_t c0 = S.coef0, c1 = S.coef1, limit = (1 << (bd - 1)) - 1;
     const uint8_t* pcm = a.in + S.src_offset;
+    const uint8_t* pcm_end = pcm + (uint64_t)S.samples * C * 2;       // samples past the input are zero padding (adx.cpp:453-456)
     uint8_t* dst = a.out + S.dst_offset;
-    for (uint32_t fr = 0; fr < S.frames; fr++) {
-        uint8_t* blk = dst + ((uint64_t)fr * C + ch) * bs;
-        const uint64_t s0 = (uint64_t)fr * spb;
-        // pass A: residual range with raw-sample history (adx.cpp:221-230)
-        int32_t mn = 0, mx = 0, o1 = h1, o2 = h2;
-        for (uint32_t i = 0; i < spb; i++) {
-            int32_t x = adx_sample(pcm, s0 + i, C, ch, S.samples);
-            int32_t r = ((int32_t)((uint32_t)x << 12) - c0 * h1 - c1 * h2) >> 12;
-            mn = r < mn ? r : mn; mx = r > mx ? r : mx;
-            h2 = h1; h1 = x;
+    uint32_t max_frames = X.valid ? S.frames : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(max_frames, o); max_frames = t > max_frames ? t : max_frames; }
+
+    for (uint32_t f0 = 0; f0 < max_frames; f0 += T) {
+        {
+            const bool act = X.leader && f0 < S.frames;
+            const uint32_t nrows = act ? (S.frames - f0 < T ? S.frames - f0 : T) : 0;
+            stage_in<4, 6>(lin, __ballot(act), lane, (uint64_t)(pcm + (uint64_t)f0 * spb * C * 2), (uint64_t)pcm_end, X.in_off, nrows * spb * C * 2);
         }
-        if (!mn && !mx) { for (uint32_t i = 0; i < bs; i++) blk[i] = 0; continue; }   // adx.cpp:231-234
-        int32_t qa = mx / limit, qb = mn / ~limit;
-        uint32_t scale = (uint32_t)(qa > qb ? qa : qb) & 0xFFFF;
-        if (scale > 0x1000) scale = 0x1000;
-        uint32_t word;
-        if (S.mode == 4) {
-            uint32_t power = scale ? (32 - __clz((int)scale)) : 0;       // log2 + 1 (adx.cpp:241-244)
-            scale = (1u << power) & 0xFFFF;
-            word = (uint32_t)(12 - (int32_t)power) & 0xFFFF;
-        } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
-        else word = scale;
-        // first byte of a block is OR-ed into whatever the header writer left there (IO.cpp:139)
-        uint8_t stale = 0;
-        { uint64_t rel = (uint64_t)(blk - dst); if (rel < S.stale_len) stale = a.stale[S.stale_offset + rel]; }
-        blk[0] = (uint8_t)(word >> 8) | stale; blk[1] = (uint8_t)word;
-        h1 = o1; h2 = o2;
-        uint32_t acc = 0, have = 0, bytepos = 2;
-        for (uint32_t i = 0; i < spb; i++) {                       // pass B (adx.cpp:254-271)
-            int32_t x = adx_sample(pcm, s0 + i, C, ch, S.samples);
-            int32_t delta = ((int32_t)((uint32_t)x << 12) - c0 * h1 - c1 * h2) >> 12;
-            if (!scale) scale = 1;
-            delta = delta > 0 ? delta + (int32_t)(scale >> 1) : delta - (int32_t)(scale >> 1);
-            delta /= (int32_t)scale;
-            delta = clamp_sym(delta, limit);
-            int32_t sim = (int32_t)(((uint32_t)delta << 12) * scale + (uint32_t)(c0 * h1) + (uint32_t)(c1 * h2)) >> 12;
-            sim = clamp_sym(sim, 0x7FFF);
-            h2 = h1; h1 = (int32_t)(int16_t)sim;
-            acc = (acc << bd) | ((uint32_t)delta & ((1u << bd) - 1)); have += bd;
-            while (have >= 8) { blk[bytepos++] = (uint8_t)(acc >> (have - 8)); have -= 8; }
+        __syncthreads();
+        if (X.valid) {
+            const int16_t* fin = (const int16_t*)(lin + X.in_off);
+            uint8_t* fo = lout + X.out_off;
+            for (uint32_t t = 0; t < T && f0 + t < S.frames; t++) {
+                const int16_t* x = fin + (uint64_t)t * spb * C + X.ch;
+                uint8_t* blk = fo + (t * C + X.ch) * bs;
+                // pass A: residual range with raw-sample history (adx.cpp:221-230)
+                int32_t mn = 0, mx = 0;
+                const int32_t o1 = h1, o2 = h2;
+                for (uint32_t i = 0; i < spb; i++) {
+                    const int32_t v = x[(uint64_t)i * C];
+                    const int32_t r = ((int32_t)((uint32_t)v << 12) - c0 * h1 - c1 * h2) >> 12;
+                    mn = r < mn ? r : mn; mx = r > mx ? r : mx;
+                    h2 = h1; h1 = v;
+                }
+                if (!mn && !mx) { for (uint32_t i = 0; i < bs; i++) blk[i] = 0; continue; }   // adx.cpp:231-234
+                const int32_t qa = mx / limit, qb = mn / ~limit;
+                uint32_t scale = (uint32_t)(qa > qb ? qa : qb) & 0xFFFF;
+                if (scale > 0x1000) scale = 0x1000;
+                uint32_t word;
+                if (S.mode == 4) {
+                    const uint32_t power = scale ? (32 - __clz((int)scale)) : 0;      // log2 + 1 (adx.cpp:241-244)
+                    scale = (1u << power) & 0xFFFF;
+                    word = (uint32_t)(12 - (int32_t)power) & 0xFFFF;
+                } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
+                else word = scale;
+                // first byte of a block is OR-ed into whatever the header writer left there (IO.cpp:139)
+                uint8_t stale = 0;
+                { const uint64_t rel = ((uint64_t)(f0 + t) * C + X.ch) * bs; if (rel < S.stale_len) stale = a.stale[S.stale_offset + rel]; }
+                blk[0] = (uint8_t)(word >> 8) | stale; blk[1] = (uint8_t)word;
+                h1 = o1; h2 = o2;
+                if (!scale) scale = 1;
+                const float rcp = 1.0f / (float)scale;
+                uint32_t acc = 0, have = 0, bytepos = 2;
+                for (uint32_t i = 0; i < spb; i++) {                       // pass B (adx.cpp:254-271)
+                    const int32_t v = x[(uint64_t)i * C];
+                    int32_t delta = ((int32_t)((uint32_t)v << 12) - c0 * h1 - c1 * h2) >> 12;
+                    delta = delta > 0 ? delta + (int32_t)(scale >> 1) : delta - (int32_t)(scale >> 1);
+                    {   // delta /= scale (truncating), exact: float estimate + correction; |delta| < 2^22 here
+                        const uint32_t an = (uint32_t)(delta < 0 ? -delta : delta);
+                        uint32_t q;
+                        if (an < (1u << 22)) {
+                            q = (uint32_t)((float)an * rcp);
+                            int32_t r = (int32_t)an - (int32_t)(q * scale);
+                            if (r < 0) { q--; r += (int32_t)scale; }
+                            if (r >= (int32_t)scale) q++;
+                        } else q = an / scale;
+                        delta = delta < 0 ? -(int32_t)q : (int32_t)q;
+                    }
+                    delta = clamp_sym(delta, limit);
+                    int32_t sim = (int32_t)(((uint32_t)delta << 12) * scale + (uint32_t)(c0 * h1) + (uint32_t)(c1 * h2)) >> 12;
+                    sim = clamp_sym(sim, 0x7FFF);
+                    h2 = h1; h1 = (int32_t)(int16_t)sim;
+                    acc = (acc << bd) | ((uint32_t)delta & ((1u << bd) - 1)); have += bd;
+                    while (have >= 8) { blk[bytepos++] = (uint8_t)(acc >> (have - 8)); have -= 8; }
+                }
+            }
         }
+        __syncthreads();
+        for (uint32_t l = 0; l < 64; l++) {
+            if (!__builtin_amdgcn_readlane((int)X.leader, l)) continue;
+            const uint32_t frames_l = __builtin_amdgcn_readlane(S.frames, l);
+            if (f0 >= frames_l) continue;
+            const uint32_t rowb = __builtin_amdgcn_readlane(C * bs, l);
+            const uint32_t nrows = frames_l - f0 < T ? frames_l - f0 : T;
+            uint8_t* q = (uint8_t*)readlane64((uint64_t)dst, l) + (uint64_t)f0 * rowb;
+            copy_out(q, lout + __builtin_amdgcn_readlane(X.out_off, l), nrows * rowb, lane);
+        }
+        __syncthreads();
     }
 }
+
 void launch_adx_encode(const AdxArgs& a, hipStream_t s) {
-    if (a.chains) hipLaunchKernelGGL(k_adx_encode, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
+    if (a.chains) hipLaunchKernelGGL(k_adx_encode, dim3((a.chains + 63) / 64), dim3(64), a.lds_in_bytes + a.lds_out_bytes, s, a);
 }
 
 }  // namespace cri

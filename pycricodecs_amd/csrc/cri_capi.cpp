@@ -283,6 +283,18 @@ extern "C" int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* of
     return create_hca_decode(blob, offsets, n, keys, subkeys, nullptr, job);
 }
 
+
+// rows per round and LDS bytes of the ADX kernels: 64 chains x T rows of (blocksize) + (2 * samples_per_block) bytes, +4 per file
+static void adx_lds_plan(AdxArgs& a, uint32_t max_bs, uint32_t max_spb, bool encode) {
+    const uint32_t per_row = 64 * (max_bs + 2 * max_spb);
+    uint32_t T = (56 * 1024) / per_row;
+    T = T < 1 ? 1 : (T > 16 ? 16 : T);
+    const uint32_t blk = ((T * 64 * max_bs + 3) & ~3u) + 64 * 8, pcm = ((T * 64 * 2 * max_spb + 3) & ~3u) + 64 * 8;
+    a.rows_per_round = T;
+    a.lds_in_bytes = encode ? pcm : blk;
+    a.lds_out_bytes = encode ? blk : pcm;
+}
+
 // ------------------------------------------------------------------------------------------------ ADX decode
 extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out) {
     if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
@@ -290,6 +302,7 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
     cri_job* j = new_job(CRI_JOB_ADX_DECODE, offsets, n);
     j->dominant = "k_adx_decode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history;
+    uint32_t max_bs = 3, max_spb = 1;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
@@ -307,7 +320,10 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
         if (S.src_offset > S.src_end) S.src_offset = S.src_end;
         S.frames = h.blocks; S.channels = h.channels; S.blocksize = h.blocksize; S.bitdepth = h.bitdepth; S.mode = h.mode;
         S.samples_per_block = h.samples_per_block; S.coef0 = h.coef[0]; S.coef1 = h.coef[1]; S.samples = h.sample_count;
+        if (h.channels > 64) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); continue; }
+        while ((chain_stream.size() % 64) + h.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
         S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
+        max_bs = std::max(max_bs, h.blocksize); max_spb = std::max(max_spb, h.samples_per_block);
         for (uint32_t c = 0; c < h.channels; c++) {
             chain_stream.push_back((uint32_t)streams.size());
             history.push_back(h.history[2 * c]); history.push_back(h.history[2 * c + 1]);
@@ -319,8 +335,9 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->adx.chains = (uint32_t)chain_stream.size();
+    adx_lds_plan(j->adx, max_bs, max_spb, false);
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
-    if (chain_stream.empty()) { chain_stream.push_back(0); history.assign(2, 0); }
+    if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
         (rc = j->upload_images())) { delete j; return rc; }
@@ -335,6 +352,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     cri_job* j = new_job(CRI_JOB_ADX_ENCODE, offsets, n);
     j->dominant = "k_adx_encode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history; std::vector<uint8_t> stale;
+    uint32_t max_bs = 3, max_spb = 1;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
@@ -359,6 +377,9 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
         S.src_offset = offsets[i] + w.data_offset; S.src_end = offsets[i + 1]; S.dst_offset = out_pos + hs;
         S.frames = pl.frames; S.channels = pl.channels; S.blocksize = bs; S.bitdepth = p->bitdepth; S.mode = p->encoding_mode;
         S.samples_per_block = pl.samples_per_block; S.coef0 = pl.coef[0]; S.coef1 = pl.coef[1]; S.samples = pl.samples_per_channel;
+        if (pl.channels > 64) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); j->images.pop_back(); continue; }
+        while ((chain_stream.size() % 64) + pl.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
+        max_bs = std::max(max_bs, bs); max_spb = std::max(max_spb, pl.samples_per_block);
         S.filter_bits = p->filter << 13; S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
         if (pl.image.size() > hs) { S.stale_offset = (uint32_t)stale.size(); S.stale_len = (uint32_t)(pl.image.size() - hs);
                                     stale.insert(stale.end(), pl.image.begin() + hs, pl.image.end()); }
@@ -373,8 +394,9 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->adx.chains = (uint32_t)chain_stream.size();
+    adx_lds_plan(j->adx, max_bs, max_spb, true);
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
-    if (chain_stream.empty()) { chain_stream.push_back(0); history.assign(2, 0); }
+    if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     if (stale.empty()) stale.push_back(0);
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||

@@ -803,6 +803,8 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
     const bool secondary = F.type(c) == CRI_CH_SECONDARY;
     const uint32_t qw[4] = {ft.q.x, ft.q.y, ft.q.z, ft.q.w};
     if (PLAIN) {
+        const uint32_t ncoded = F.coded(c);
+        const bool full = ncoded == 128;                  // wave-uniform: no masking needed (the usual "High" layout)
         const float4 g0 = *(const float4*)(T.G + c * 128 + l16 * 8), g1 = *(const float4*)(T.G + c * 128 + l16 * 8 + 4);
         const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
@@ -810,7 +812,7 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
             const uint32_t b = l16 * 8 + r;
             const float q = (float)(int)(int16_t)(qw[r >> 1] >> (16 * (r & 1)));
             const float v = g[r] * q;
-            x[r] = b < F.coded(c) ? v : 0.0f;
+            x[r] = (full || b < ncoded) ? v : 0.0f;
         }
         return;
     }
@@ -920,14 +922,24 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
             const float* dp = T.D + ((sglob + slot - C) & 7) * 128;
             const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
             const uint32_t sfl = slot / C;                                             // subframe within this pass
+            float o0[4], o1[4];
+            bool odd = false;                              // any product outside int32 range or NaN: x86 cvttss2si semantics needed
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const int i = (int)l16 + 16 * m;
                 const float p0 = have_prev ? T.win[127 - i] * dp[63 - i] : 0.0f;
                 const float p1 = have_prev ? T.win[63 - i] * dp[i] : 0.0f;
-                const float o0 = T.win[i] * d[i + 64] + p0;
-                const float o1 = T.win[i + 64] * d[127 - i] - p1;
-                int32_t q0 = cvt_trunc_x86(o0 * 32768.0f), q1 = cvt_trunc_x86(o1 * 32768.0f);     // hca.cpp:339-360
+                o0[m] = (T.win[i] * d[i + 64] + p0) * 32768.0f;
+                o1[m] = (T.win[i + 64] * d[127 - i] - p1) * 32768.0f;
+                odd = odd || !(fabsf(o0[m]) < 2147483648.0f) || !(fabsf(o1[m]) < 2147483648.0f);
+            }
+            const bool slow_cvt = __any(odd);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int i = (int)l16 + 16 * m;
+                int32_t q0, q1;                                                                  // hca.cpp:339-360
+                if (slow_cvt) { q0 = cvt_trunc_x86(o0[m]); q1 = cvt_trunc_x86(o1[m]); }
+                else { q0 = (int32_t)o0[m]; q1 = (int32_t)o1[m]; }
                 q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
                 q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
                 T.pcm[((sfl * 128 + i) * C) + c] = (uint16_t)(int16_t)q0;
@@ -937,17 +949,24 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
             // 1 KB of interleaved PCM16 per pass; delay / length trim of hca.cpp:3392-3425
             const uint32_t n0 = f * 1024 + (pass * per_pass_sf) * 128;
             uint8_t* dst = a.out + st.dst_offset;
+            const uint32_t span = per_pass_sf * 128;
+            if (dword_ok && n0 >= st.delay && n0 + span - st.delay <= st.samples) {            // whole pass inside the output
+                uint32_t* q = (uint32_t*)(dst + (uint64_t)(n0 - st.delay) * C * 2);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
-                const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
-                const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
-                const uint32_t word = ((const uint32_t*)T.pcm)[dw];
-                const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
-                if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
-                else {
-                    if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
-                    if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
+                for (int k = 0; k < 4; k++) q[k * 64 + lane] = ((const uint32_t*)T.pcm)[k * 64 + lane];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
+                    const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
+                    const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
+                    const uint32_t word = ((const uint32_t*)T.pcm)[dw];
+                    const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
+                    if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
+                    else {
+                        if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
+                        if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
+                    }
                 }
             }
             __syncthreads();

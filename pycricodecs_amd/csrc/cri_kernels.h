@@ -51,7 +51,9 @@ struct AdxArgs {
     const uint32_t* chain_stream;  // per chain: stream index
     const int16_t* history;        // 2 per chain
     const uint8_t* stale;          // encode: header-image bytes that spill into the block area
-    uint32_t chains;
+    uint32_t chains;               // incl. padding entries (chain_stream == 0xFFFFFFFF) that keep a file inside one wave
+    uint32_t rows_per_round;       // block rows staged in LDS per round (T)
+    uint32_t lds_in_bytes, lds_out_bytes;
 };
 void launch_adx_decode(const AdxArgs& a, hipStream_t s);
 void launch_adx_encode(const AdxArgs& a, hipStream_t s);
