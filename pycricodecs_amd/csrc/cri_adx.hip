@@ -324,4 +324,189 @@ void launch_adx_encode(const AdxArgs& a, hipStream_t s) {
     if (a.chains) hipLaunchKernelGGL(k_adx_encode, dim3((a.chains + 63) / 64), dim3(64), a.lds_in_bytes + a.lds_out_bytes, s, a);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-per-file variants for batches with few chains (BASELINE configs[1]: 1 000 files = 2 000 chains would keep 32 of
+// 1 024 SIMDs busy in the lane-per-chain mapping).  Standard layout only: blocksize 18, bitdepth 4, 1 or 2 channels, so
+// that one ADX frame is one wavefront: lanes 0-31 = the 32 samples of channel 0's block, lanes 32-63 = channel 1's.
+// The per-sample parts (nibble unpack, code*scale; encoder pass A residuals + min/max) run across the lanes; the
+// recurrence itself is walked sample by sample with v_readlane broadcasts, identically in every lane of a half.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t half_min(int32_t v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { const int32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int32_t half_max(int32_t v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { const int32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
+    const AdxStream S = a.streams[blockIdx.x];
+    const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
+    const bool act = half < C;
+    const uint32_t chain = S.first_chain + (act ? half : 0);
+    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+    int32_t c0 = S.coef0, c1 = S.coef1;
+    const uint8_t* src = a.in + S.src_offset;
+    const uint8_t* end = a.in + S.src_end;
+    uint8_t* out = a.out + S.dst_offset;
+    const uint32_t rowb = 18 * C;
+    constexpr int R = 4;
+    uint32_t nb[R], nsc[R];
+    auto fetch = [&](uint32_t fr, uint32_t& b, uint32_t& sc) {
+        b = 0; sc = 0;
+        const uint8_t* row = src + (uint64_t)fr * rowb;
+        if (fr < S.frames && row + rowb <= end && act) {
+            const uint8_t* blk = row + half * 18;
+            b = blk[2 + (s >> 1)];
+            sc = ((uint32_t)blk[0] << 8) | blk[1];
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < R; t++) fetch((uint32_t)t, nb[t], nsc[t]);
+    uint32_t done = 0;
+    bool stopped = false;
+    for (uint32_t f0 = 0; f0 < S.frames && !stopped; f0 += R) {
+        uint32_t b[R], sc[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) { b[t] = nb[t]; sc[t] = nsc[t]; }
+#pragma unroll
+        for (int t = 0; t < R; t++) fetch(f0 + R + t, nb[t], nsc[t]);           // next round in flight during this one
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const uint32_t fr = f0 + t;
+            if (fr >= S.frames || stopped) break;
+            const uint8_t* row = src + (uint64_t)fr * rowb;
+            const uint32_t sc0 = __builtin_amdgcn_readlane(sc[t], 0);            // channel 0's scale word: EOF marker check (adx.cpp:405-406)
+            if (row + rowb > end || sc0 == 0x8001) { stopped = true; break; }
+            int32_t scale = (int32_t)sc[t];
+            if (S.mode == 4) scale = (int32_t)(1u << ((12 - scale) & 31));
+            else if (S.mode == 2) {
+                const uint32_t pred = ((uint32_t)scale >> 13) & 7;
+                scale = (scale & 0x1FFF) + 1;
+                c0 = pred < 4 ? ADX_STATIC_COEFS[pred * 2] : 0;
+                c1 = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
+            } else scale += 1;
+            const int32_t code = (int32_t)((s & 1 ? b[t] << 28 : b[t] << 24) & 0xF0000000u) >> 28;
+            const int32_t ds = code * scale;
+            int32_t mine = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const int32_t d0 = __builtin_amdgcn_readlane(ds, k), d1 = __builtin_amdgcn_readlane(ds, 32 + k);
+                int32_t v = (half ? d1 : d0) + (__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12);
+                v = clamp_sym(v, 0x7FFF);
+                h2 = h1; h1 = v;
+                mine = (int)s == k ? v : mine;
+            }
+            const uint64_t idx = (uint64_t)fr * 32 + s;
+            if (C == 2) {
+                const int32_t other = __shfl_down(mine, 32);
+                if (half == 0 && idx < S.samples) ((uint32_t*)out)[idx] = ((uint32_t)mine & 0xFFFF) | ((uint32_t)other << 16);
+            } else if (half == 0 && idx < S.samples) ((int16_t*)out)[idx] = (int16_t)mine;
+            done = fr + 1;
+        }
+    }
+    // rows never reached (EOF marker / truncated input) decode to silence
+    for (uint64_t i = (uint64_t)done * 32 * C + lane; i < (uint64_t)S.samples * C; i += 64) ((int16_t*)out)[i] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
+    __shared__ uint8_t blk_img[40];
+    const AdxStream S = a.streams[blockIdx.x];
+    const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
+    const bool act = half < C;
+    const uint32_t chain = S.first_chain + (act ? half : 0);
+    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+    const int32_t c0 = S.coef0, c1 = S.coef1;
+    const uint8_t* pcm = a.in + S.src_offset;
+    uint8_t* dst = a.out + S.dst_offset;
+    constexpr int R = 4;
+    int32_t nx[R];
+    auto fetch = [&](uint32_t fr, int32_t& x) {
+        x = 0;
+        const uint64_t idx = (uint64_t)fr * 32 + s;
+        if (fr < S.frames && idx < S.samples && act) { const uint8_t* p = pcm + (idx * C + half) * 2; x = (int32_t)(int16_t)(p[0] | (p[1] << 8)); }
+    };
+#pragma unroll
+    for (int t = 0; t < R; t++) fetch((uint32_t)t, nx[t]);
+    for (uint32_t f0 = 0; f0 < S.frames; f0 += R) {
+        int32_t xr[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) xr[t] = nx[t];
+#pragma unroll
+        for (int t = 0; t < R; t++) fetch(f0 + R + t, nx[t]);
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const uint32_t fr = f0 + t;
+            if (fr >= S.frames) break;
+            const int32_t x = xr[t];
+            // pass A (adx.cpp:221-230): residual against the two previous RAW samples; lanes 0/1 of a block see the carried history
+            int32_t p1 = __shfl_up(x, 1, 32), p2 = __shfl_up(x, 2, 32);
+            if (s == 0) { p1 = h1; p2 = h2; } else if (s == 1) p2 = h1;
+            const int32_t r = ((int32_t)((uint32_t)x << 12) - c0 * p1 - c1 * p2) >> 12;
+            int32_t mn = half_min(r < 0 ? r : 0), mx = half_max(r > 0 ? r : 0);
+            const bool silent = !mn && !mx;                                            // adx.cpp:231-234
+            const int32_t raw1 = __shfl(x, (int)(half * 32 + 31)), raw2 = __shfl(x, (int)(half * 32 + 30));
+            const int32_t qa = mx / 7, qb = (int32_t)((uint32_t)(-mn) >> 3);           // Maximum/Limit, Minimum/~Limit with Limit = 7
+            uint32_t scale = (uint32_t)(qa > qb ? qa : qb) & 0xFFFF;
+            if (scale > 0x1000) scale = 0x1000;
+            uint32_t word;
+            if (S.mode == 4) {
+                const uint32_t power = scale ? (32 - __clz((int)scale)) : 0;
+                scale = (1u << power) & 0xFFFF;
+                word = (uint32_t)(12 - (int32_t)power) & 0xFFFF;
+            } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
+            else word = scale;
+            if (!scale) scale = 1;
+            const float rcp = 1.0f / (float)scale;
+            int32_t g1 = h1, g2 = h2, mine = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {                                             // pass B (adx.cpp:254-271)
+                const int32_t x0 = __builtin_amdgcn_readlane(x, k), x1 = __builtin_amdgcn_readlane(x, 32 + k);
+                const int32_t xk = half ? x1 : x0;
+                int32_t delta = ((int32_t)((uint32_t)xk << 12) - c0 * g1 - c1 * g2) >> 12;
+                delta = delta > 0 ? delta + (int32_t)(scale >> 1) : delta - (int32_t)(scale >> 1);
+                {
+                    const uint32_t an = (uint32_t)(delta < 0 ? -delta : delta);
+                    uint32_t q;
+                    if (an < (1u << 22)) {
+                        q = (uint32_t)((float)an * rcp);
+                        int32_t rem = (int32_t)an - (int32_t)(q * scale);
+                        if (rem < 0) { q--; rem += (int32_t)scale; }
+                        if (rem >= (int32_t)scale) q++;
+                    } else q = an / scale;
+                    delta = delta < 0 ? -(int32_t)q : (int32_t)q;
+                }
+                delta = clamp_sym(delta, 7);
+                int32_t sim = (int32_t)(((uint32_t)delta << 12) * scale + (uint32_t)(c0 * g1) + (uint32_t)(c1 * g2)) >> 12;
+                sim = clamp_sym(sim, 0x7FFF);
+                g2 = g1; g1 = (int32_t)(int16_t)sim;
+                mine = (int)s == k ? delta : mine;
+            }
+            h1 = silent ? raw1 : g1; h2 = silent ? raw2 : g2;
+            // two 4-bit codes per byte, first sample in the high nibble; even lanes hold the byte
+            const uint32_t nib = silent ? 0u : ((uint32_t)mine & 15);
+            const uint32_t nxt = (uint32_t)__shfl_xor((int)nib, 1);
+            __syncthreads();
+            if (act) {
+                if (!(s & 1)) blk_img[half * 18 + 2 + (s >> 1)] = (uint8_t)((nib << 4) | nxt);
+                if (s == 0) { blk_img[half * 18] = silent ? 0 : (uint8_t)(word >> 8); blk_img[half * 18 + 1] = silent ? 0 : (uint8_t)word; }
+            }
+            __syncthreads();
+            uint8_t* row = dst + (uint64_t)fr * 18 * C;
+            if (lane < 18 * C) row[lane] = blk_img[lane];
+        }
+    }
+}
+
+void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s) {
+    if (n_streams) hipLaunchKernelGGL(k_adx_decode_wpf, dim3(n_streams), dim3(64), 0, s, a);
+}
+void launch_adx_encode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s) {
+    if (n_streams) hipLaunchKernelGGL(k_adx_encode_wpf, dim3(n_streams), dim3(64), 0, s, a);
+}
+
 }  // namespace cri

@@ -53,6 +53,8 @@ struct cri_job {
     // launch plans (device pointers for in/out/scratch/status are filled at run time)
     std::vector<HcaDecArgs> hca_dec;
     AdxArgs adx{};
+    uint32_t adx_streams = 0;                    // number of valid ADX streams
+    bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
     CryptArgs crypt{};
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
     std::vector<HcaEncArgs> hca_enc;
@@ -284,6 +286,17 @@ extern "C" int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* of
 }
 
 
+// Mapping choice: wave-per-file fills the chip with ~1 k files but spends 62 of 64 lanes idle in the
+// serial section; lane-per-chain is 16x cheaper per sample but needs tens of thousands of chains.  CRICODECS_ADX_MAPPING
+// = "chain" | "file" overrides the heuristic (tests use it to cover both kernels).
+static bool adx_pick_wave_per_file(bool all_std, size_t n_streams) {
+    if (!all_std || n_streams == 0) return false;
+    const char* e = getenv("CRICODECS_ADX_MAPPING");
+    if (e && !strcmp(e, "chain")) return false;
+    if (e && !strcmp(e, "file")) return true;
+    return n_streams <= 8192;
+}
+
 // rows per round and LDS bytes of the ADX kernels: 64 chains x T rows of (blocksize) + (2 * samples_per_block) bytes, +4 per file
 static void adx_lds_plan(AdxArgs& a, uint32_t max_bs, uint32_t max_spb, bool encode) {
     const uint32_t per_row = 64 * (max_bs + 2 * max_spb);
@@ -303,6 +316,7 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
     j->dominant = "k_adx_decode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history;
     uint32_t max_bs = 3, max_spb = 1;
+    bool all_std = true;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
@@ -324,6 +338,7 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
         while ((chain_stream.size() % 64) + h.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
         S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
         max_bs = std::max(max_bs, h.blocksize); max_spb = std::max(max_spb, h.samples_per_block);
+        if (!(h.blocksize == 18 && h.bitdepth == 4 && h.channels <= 2)) all_std = false;
         for (uint32_t c = 0; c < h.channels; c++) {
             chain_stream.push_back((uint32_t)streams.size());
             history.push_back(h.history[2 * c]); history.push_back(h.history[2 * c + 1]);
@@ -336,6 +351,9 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->adx.chains = (uint32_t)chain_stream.size();
     adx_lds_plan(j->adx, max_bs, max_spb, false);
+    j->adx_streams = (uint32_t)streams.size();
+    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size());
+    if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     int rc = 0;
@@ -353,6 +371,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     j->dominant = "k_adx_encode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history; std::vector<uint8_t> stale;
     uint32_t max_bs = 3, max_spb = 1;
+    bool all_std = true;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
@@ -380,6 +399,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
         if (pl.channels > 64) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); j->images.pop_back(); continue; }
         while ((chain_stream.size() % 64) + pl.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
         max_bs = std::max(max_bs, bs); max_spb = std::max(max_spb, pl.samples_per_block);
+        if (!(bs == 18 && p->bitdepth == 4 && pl.channels <= 2 && pl.image.size() <= hs + 1)) all_std = false;
         S.filter_bits = p->filter << 13; S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
         if (pl.image.size() > hs) { S.stale_offset = (uint32_t)stale.size(); S.stale_len = (uint32_t)(pl.image.size() - hs);
                                     stale.insert(stale.end(), pl.image.begin() + hs, pl.image.end()); }
@@ -395,6 +415,9 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->adx.chains = (uint32_t)chain_stream.size();
     adx_lds_plan(j->adx, max_bs, max_spb, true);
+    j->adx_streams = (uint32_t)streams.size();
+    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size());
+    if (j->adx_wave_per_file) j->dominant = "k_adx_encode_wpf";
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     if (stale.empty()) stale.push_back(0);
@@ -572,7 +595,8 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
             a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
             a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p;
             j->mark(0, true, s);
-            if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode(a, s); else launch_adx_encode(a, s);
+            if (j->adx_wave_per_file) { if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode_wpf(a, j->adx_streams, s); else launch_adx_encode_wpf(a, j->adx_streams, s); }
+            else if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode(a, s); else launch_adx_encode(a, s);
             j->mark(0, false, s);
             break;
         }

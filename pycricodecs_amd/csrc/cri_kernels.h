@@ -57,6 +57,9 @@ struct AdxArgs {
 };
 void launch_adx_decode(const AdxArgs& a, hipStream_t s);
 void launch_adx_encode(const AdxArgs& a, hipStream_t s);
+// wave-per-file variants (blocksize 18, bitdepth 4, <= 2 channels, no header spill); one block per stream
+void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
+void launch_adx_encode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
 
 struct CryptArgs {
     const uint8_t* in; uint8_t* out;

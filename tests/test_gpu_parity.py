@@ -80,6 +80,30 @@ def test_adx_vs_oracle(cc, seed, n, ch, sr, bd, bs, mode, ver):
     assert diff(cc.AdxDecode(ref), want) is None
 
 
+@pytest.mark.parametrize("mapping", ["chain", "file"])
+def test_adx_both_mappings(cc, mapping, monkeypatch):
+    """Standard-layout files through the lane-per-chain kernels and through the wave-per-file kernels."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", mapping)
+    z = np.zeros((1600, 2), dtype=np.int16)
+    z[500:700, 0] = 20000
+    wavs = [synth.wav(400 + i, 32 * (3 + 7 * i), 1 + (i % 2), 48000) for i in range(9)] + [synth.wav_bytes(z, 44100)]
+    for mode, ver in ((3, 4), (4, 4), (2, 3)):
+        enc = Job.adx_encode(wavs, mode=mode, version=ver)
+        assert enc.dominant_kernel == ("k_adx_encode_wpf" if mapping == "file" else "k_adx_encode")
+        adx, st = enc.run_host()
+        assert not st.any()
+        for a, w in zip(adx, wavs):
+            assert diff(a, O.adx_encode(w, 4, 18, mode, 500, 0, ver)) is None
+        adx[3] = adx[3][:len(adx[3]) // 2]                    # truncated input
+        dec = Job.adx_decode(adx)
+        assert dec.dominant_kernel == ("k_adx_decode_wpf" if mapping == "file" else "k_adx_decode")
+        pcm, st = dec.run_host()
+        assert not st.any()
+        for p, a in zip(pcm, adx):
+            assert diff(p, O.adx_decode(a)) is None
+
+
 def test_adx_silence_clipping_truncation(cc):
     z = np.zeros((3200, 2), dtype=np.int16)
     z[1000:1100] = 32767
