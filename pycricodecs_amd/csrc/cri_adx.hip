@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
     uint8_t* lout = smem + a.lds_in_bytes;
     int32_t h1 = X.valid ? a.history[2 * chain] : 0, h2 = X.valid ? a.history[2 * chain + 1] : 0;
     const int32_t c0 = S.coef0, c1 = S.coef1, limit = (1 << (bd - 1)) - 1;
-    const uint8_t* pcm = a.in + S.src_offset;
+    const uint8_t* pcm = (S.src_in_scratch ? a.scratch : a.in) + S.src_offset;
     const uint8_t* pcm_end = pcm + (uint64_t)S.samples * C * 2;       // samples past the input are zero padding (adx.cpp:453-456)
     uint8_t* dst = a.out + S.dst_offset;
     uint32_t max_frames = X.valid ? S.frames : 0;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
     const uint32_t chain = S.first_chain + (act ? half : 0);
     int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
     const int32_t c0 = S.coef0, c1 = S.coef1;
-    const uint8_t* pcm = a.in + S.src_offset;
+    const uint8_t* pcm = (S.src_in_scratch ? a.scratch : a.in) + S.src_offset;
     uint8_t* dst = a.out + S.dst_offset;
     constexpr int R = 4;
     int32_t nx[R];

@@ -47,7 +47,17 @@ struct cri_job {
     std::string dominant;
     // device metadata
     DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
-        d_frame_sizes, d_first_frame, d_adx_streams;
+        d_frame_sizes, d_first_frame, d_adx_streams, d_convert;
+    std::vector<ConvertItem> convert;            // WAV items whose samples are converted to PCM16 in scratch before encoding
+    uint64_t convert_total = 0;
+    // registers item data for conversion; returns the scratch offset its PCM16 will be at
+    uint64_t add_convert(uint64_t src_offset, const WavInfo& w) {
+        ConvertItem c; c.first = convert_total; c.src_offset = src_offset; c.dst_offset = scratch_bytes;
+        c.sample_size = w.sample_size; c.bitdepth = w.bitdepth; c.mode = w.mode; c.pad = 0;
+        convert.push_back(c); convert_total += w.column_size;
+        scratch_bytes = (scratch_bytes + 2ull * w.column_size + 255) & ~255ull;
+        return c.dst_offset;
+    }
     uint32_t n_images = 0;
     std::vector<Image> images;
     // launch plans (device pointers for in/out/scratch/status are filled at run time)
@@ -91,6 +101,7 @@ struct cri_job {
         rc = d_img_off.upload(off); if (rc) return rc;
         return d_img_dst.upload(dst);
     }
+    int upload_convert() { return convert.empty() ? 0 : d_convert.upload(convert); }
 };
 
 static bool g_dev_checked = false, g_dev_ok = false;
@@ -384,7 +395,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
         rc = adx_plan_encode(d, len, w, p->bitdepth, p->blocksize, p->encoding_mode, p->highpass_frequency, p->filter, p->adx_version,
                              p->force_no_looping != 0, pl);
         if (rc) { j->host_status[i] = rc; continue; }
-        if (!wav_is_pcm16(w)) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // device-side sample conversion: next
+        if ((rc = wav_convertible(w))) { j->host_status[i] = rc; continue; }
         uint32_t bs = p->blocksize, hs = pl.header_size;
         Image head; head.dst = out_pos; head.bytes.assign(pl.image.begin(), pl.image.begin() + std::min<size_t>(hs, pl.image.size()));
         j->images.push_back(std::move(head));
@@ -397,6 +408,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
         S.frames = pl.frames; S.channels = pl.channels; S.blocksize = bs; S.bitdepth = p->bitdepth; S.mode = p->encoding_mode;
         S.samples_per_block = pl.samples_per_block; S.coef0 = pl.coef[0]; S.coef1 = pl.coef[1]; S.samples = pl.samples_per_channel;
         if (pl.channels > 64) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); j->images.pop_back(); continue; }
+        if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(offsets[i] + w.data_offset, w); S.src_end = S.src_offset + 2ull * w.column_size; S.src_in_scratch = 1; }
         while ((chain_stream.size() % 64) + pl.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
         max_bs = std::max(max_bs, bs); max_spb = std::max(max_spb, pl.samples_per_block);
         if (!(bs == 18 && p->bitdepth == 4 && pl.channels <= 2 && pl.image.size() <= hs + 1)) all_std = false;
@@ -423,7 +435,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     if (stale.empty()) stale.push_back(0);
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
-        (rc = j->d_stale.upload(stale)) || (rc = j->upload_images())) { delete j; return rc; }
+        (rc = j->d_stale.upload(stale)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -510,7 +522,7 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
         int rc = wav_parse(d, len, w);
         if (rc) { j->host_status[i] = rc; continue; }
         if (w.looping && !force_no_looping) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // loop feeding path: next
-        if (!wav_is_pcm16(w)) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }
+        if ((rc = wav_convertible(w))) { j->host_status[i] = rc; continue; }
         HcaEncSetup e;
         rc = hca_enc_setup(w.channels, w.rate, w.column_size / w.channels, quality, e);
         if (rc) { j->host_status[i] = rc; continue; }
@@ -532,6 +544,7 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
         HcaStream S; memset(&S, 0, sizeof S);
         S.src_offset = offsets[i] + w.data_offset; S.dst_offset = out_pos + e.header_size; S.format = fidx; S.frames = e.frame_count;
         S.samples = e.samples_per_channel; S.item = i;
+        if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(offsets[i] + w.data_offset, w); S.src_in_scratch = 1; }
         streams.push_back(S);
         out_pos = align_up(out_pos + e.header_size + (uint64_t)e.frame_count * e.frame_size, 64);
         j->units += e.frame_count;
@@ -563,7 +576,7 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
     if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (crcmul.empty()) crcmul.assign(96, 0);
     int rc = 0;
-    if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images())) { delete j; return rc; }
+    if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -577,6 +590,11 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
     if (d_status) launch_fill_i32(d_status, 0, j->n, s);
     if (j->n_images)
         launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, (uint8_t*)d_out, s);
+    if (j->convert_total) {
+        ConvertArgs c; c.in = (const uint8_t*)d_in; c.scratch = (uint8_t*)d_scratch; c.items = (const ConvertItem*)j->d_convert.p;
+        c.n_items = (uint32_t)j->convert.size(); c.total = j->convert_total;
+        launch_pcm_convert(c, s);
+    }
     switch (j->kind) {
         case CRI_JOB_HCA_DECODE:
             for (auto a : j->hca_dec) {
@@ -591,7 +609,7 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
         case CRI_JOB_ADX_DECODE:
         case CRI_JOB_ADX_ENCODE: {
             AdxArgs a = j->adx;
-            a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status;
+            a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
             a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
             a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p;
             j->mark(0, true, s);
@@ -603,7 +621,7 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
         case CRI_JOB_HCA_ENCODE:
             for (size_t k = 0; k < j->hca_enc.size(); k++) {
                 HcaEncArgs a = j->hca_enc[k];
-                a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status;
+                a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.crc_mul = (const uint16_t*)j->d_crcmul.p + j->hca_enc_crc_off[k];
                 j->mark(0, true, s); launch_hca_encode(a, s); j->mark(0, false, s);

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_frame <= g) lo = mid; else hi = mid; }
     const HcaStream st = a.streams[lo];
     const uint32_t f = g - st.first_frame;
-    const uint8_t* pcm = a.in + st.src_offset;
+    const uint8_t* pcm = (st.src_in_scratch ? a.scratch : a.in) + st.src_offset;
     const int64_t nsamp = (int64_t)st.samples;
     auto sample = [&](int64_t n, uint32_t c) -> float {      // PcmToFloat, hca.cpp:2470-2479 (+ zero history / zero tail)
         if (n < 0 || n >= nsamp) return 0.0f;

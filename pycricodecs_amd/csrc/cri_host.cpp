@@ -90,6 +90,34 @@ int wav_parse(const uint8_t* w, size_t len, WavInfo& o) {
 
 bool wav_is_pcm16(const WavInfo& w) { return w.mode != 3 && w.bitdepth > 8 && w.bitdepth <= 16 && w.sample_size == 2; }
 
+int wav_convertible(const WavInfo& w) {
+    if (wav_is_pcm16(w)) return 0;
+    if (w.bitdepth <= 8) return w.sample_size == 1 ? 0 : CRI_ERR_PCM(8);
+    if (w.mode == 3) return (w.sample_size == 4 && w.bitdepth == 32) || (w.sample_size == 8 && w.bitdepth == 64) ? 0 : CRI_ERR_PCM(8);
+    if (w.sample_size == 4 || w.sample_size == 3) return w.bitdepth >= 16 ? 0 : CRI_ERR_PCM(8);
+    return CRI_ERR_PCM(8);
+}
+
+static int32_t trunc_x86(double v) { return (v >= -2147483648.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN; }
+
+// pcm.cpp:455-461 (float -> PCM16, midpoint 32767), 498-504 (wide ints), 517-522 (8-bit)
+int16_t wav_sample16(const WavInfo& w, const uint8_t* file, uint64_t index) {
+    const uint8_t* p = file + w.data_offset + index * w.sample_size;
+    if (wav_is_pcm16(w)) return (int16_t)le16(p);
+    if (w.bitdepth <= 8) return (int16_t)(((int32_t)p[0] - (1 << (w.bitdepth - 1))) << 8);
+    int32_t v;
+    if (w.mode == 3) {
+        if (w.bitdepth == 32) { float f; uint32_t u = le32(p); memcpy(&f, &u, 4); f = f * 32767.0f; v = trunc_x86((double)f); }
+        else { double d; uint64_t u = (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); memcpy(&d, &u, 8); v = trunc_x86(d * 32767.0); }
+        v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+        return (int16_t)v;
+    }
+    if (w.sample_size == 4) return (int16_t)((((int32_t)le32(p)) >> (w.bitdepth - 16)) & 0xFFFF);
+    v = (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16));
+    if (v & 0x800000) v |= (int32_t)0xFF000000;
+    return (int16_t)((v >> (w.bitdepth - 16)) & 0xFFFF);
+}
+
 // pcm.cpp:350-375 (riff header), 262-269 (smpl), 547-556 (sizes)
 uint32_t wav_write_header(uint8_t* d, uint32_t channels, uint32_t rate, uint32_t spc, bool looping, uint32_t ls, uint32_t le) {
     uint32_t hs = looping ? 0x70 : 0x2C, pos = 36, datasize = spc * channels * 2;
@@ -194,7 +222,7 @@ int adx_plan_encode(const uint8_t* wav, size_t len, const WavInfo& w, uint32_t b
     if (ver == 4 || ver == 5) {
         for (uint32_t i = 0; i < ch; i++) {                    // first sample of each channel (adx.cpp:473-476); 16-bit input only
             int16_t s = 0;
-            if (wav_is_pcm16(w) && (uint64_t)i * 2 + 2 <= w.data_size) s = (int16_t)le16(wav + w.data_offset + 2 * (size_t)i);
+            if (wav_convertible(w) == 0 && (uint64_t)(i + 1) * w.sample_size <= w.data_size) s = wav_sample16(w, wav, i);
             p.history[2 * i] = p.history[2 * i + 1] = s;
         }
     }

@@ -35,6 +35,10 @@ struct WavInfo {
 int wav_parse(const uint8_t* w, size_t len, WavInfo& o);
 // true when the sample data can be consumed as-is as little-endian int16 (pcm.cpp:533-534)
 bool wav_is_pcm16(const WavInfo& w);
+// 0 when the sample format is one the reference converts to PCM16 (pcm.cpp:530-545), else the PCM error code
+int wav_convertible(const WavInfo& w);
+// one sample converted the way PCM::Get_PCM16 does (used for the ADX header's initial history only)
+int16_t wav_sample16(const WavInfo& w, const uint8_t* file, uint64_t index);
 uint32_t wav_write_header(uint8_t* d, uint32_t channels, uint32_t rate, uint32_t samples_per_channel,
                           bool looping, uint32_t loop_start, uint32_t loop_end);
 

@@ -36,6 +36,7 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);
 
 struct HcaEncArgs {
     const uint8_t* in; uint8_t* out; int32_t* status;
+    const uint8_t* scratch;        // converted PCM16 (HcaStream::pad0 != 0 -> src_offset is relative to scratch)
     const HcaFormat* formats;
     const HcaStream* streams;      // sorted by format; src_offset = first PCM byte, dst_offset = first frame byte
     const uint16_t* crc_mul;       // [6][16]: (x^bit * x^(8 * crc_chunk * 2^k)) mod P, for the log-step CRC combine
@@ -47,6 +48,7 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s);
 
 struct AdxArgs {
     const uint8_t* in; uint8_t* out; int32_t* status;
+    const uint8_t* scratch;        // converted PCM16 of items whose WAV is not 16-bit (AdxStream::src_in_scratch)
     const AdxStream* streams;
     const uint32_t* chain_stream;  // per chain: stream index
     const int16_t* history;        // 2 per chain
@@ -70,6 +72,10 @@ struct CryptArgs {
     uint32_t n_streams, frames;
 };
 void launch_hca_crypt(const CryptArgs& a, hipStream_t s);
+
+struct ConvertItem { uint64_t first, src_offset, dst_offset; uint32_t sample_size, bitdepth, mode, pad; };
+struct ConvertArgs { const uint8_t* in; uint8_t* scratch; const ConvertItem* items; uint32_t n_items; uint64_t total; };
+void launch_pcm_convert(const ConvertArgs& a, hipStream_t s);
 
 // copies n small byte images (headers) into the output blob: image i = img[img_off[i], img_off[i+1]) -> out + dst_off[i]
 void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const uint64_t* dst_off, uint32_t n, uint8_t* out, hipStream_t s);

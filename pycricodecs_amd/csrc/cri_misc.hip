@@ -29,6 +29,42 @@ void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const ui
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// PCM::Get_PCM16 for WAV data that is not already 16-bit (pcm.cpp:455-545): one thread per sample, int16 into scratch
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_pcm_convert(ConvertArgs a) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.total) return;
+    uint32_t lo = 0, hi = a.n_items;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.items[mid].first <= g) lo = mid; else hi = mid; }
+    const ConvertItem it = a.items[lo];
+    const uint64_t i = g - it.first;
+    const uint8_t* p = a.in + it.src_offset + i * it.sample_size;
+    int32_t v;
+    if (it.bitdepth <= 8) v = ((int32_t)p[0] - (1 << (it.bitdepth - 1))) << 8;
+    else if (it.mode == 3) {
+        if (it.bitdepth == 32) {
+            float f = __uint_as_float((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) * 32767.0f;
+            v = (f >= -2147483648.0f && f < 2147483648.0f) ? (int32_t)f : (int32_t)0x80000000;
+        } else {
+            uint64_t u = 0;
+            for (int k = 0; k < 8; k++) u |= (uint64_t)p[k] << (8 * k);
+            double d = __longlong_as_double((long long)u) * 32767.0;
+            v = (d >= -2147483648.0 && d < 2147483648.0) ? (int32_t)d : (int32_t)0x80000000;
+        }
+        v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+    } else if (it.sample_size == 4) v = ((int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24))) >> (it.bitdepth - 16);
+    else {
+        v = (int32_t)(p[0] | (p[1] << 8) | (p[2] << 16));
+        if (v & 0x800000) v |= (int32_t)0xFF000000;
+        v >>= (it.bitdepth - 16);
+    }
+    ((int16_t*)(a.scratch + it.dst_offset))[i] = (int16_t)(v & 0xFFFF);
+}
+void launch_pcm_convert(const ConvertArgs& a, hipStream_t s) {
+    if (a.total) hipLaunchKernelGGL(k_pcm_convert, dim3((uint32_t)((a.total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // HCA crypt: byte substitution + CRC rewrite, one lane per frame (hca.cpp:3322-3327)
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_hca_crypt(CryptArgs a) {

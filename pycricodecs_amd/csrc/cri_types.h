@@ -29,8 +29,10 @@ struct HcaStream {
     uint32_t delay;                // decode: leading samples to drop (encoder_delay)
     uint32_t samples;              // decode: samples per channel to emit; encode: input samples per channel
     uint32_t item;                 // index of the batch item (for status reporting)
+    uint32_t src_in_scratch;       // encode: src_offset is relative to the job scratch (converted PCM16)
     uint32_t first_frame;          // global frame number of this stream's frame 0 within its format group
     uint32_t first_run;            // global number of this stream's first run of HCA_RUN (8) frames within its format group
+    uint32_t pad1;
 };
 
 // Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):
@@ -56,5 +58,5 @@ struct AdxStream {
     uint32_t item;
     uint32_t first_chain;          // global chain number of channel 0
     uint32_t stale_offset, stale_len; // encode: header image bytes that overlap the block area (OR-ed into first block bytes)
-    uint32_t pad0;
+    uint32_t src_in_scratch;       // encode: src_offset is relative to the job scratch (converted PCM16), not to the input blob
 };

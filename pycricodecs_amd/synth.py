@@ -40,3 +40,27 @@ def wav_bytes(pcm: np.ndarray, sr: int = 48000, loop=None) -> bytes:
 
 def wav(seed: int, n: int, ch: int = 2, sr: int = 48000) -> bytes:
     return wav_bytes(pcm16(seed, n, ch, sr), sr)
+
+
+def wav_typed(seed: int, n: int, ch: int, sr: int, kind: str) -> bytes:
+    """Same signal as wav(), stored as 'u8' | 's24' | 's32' | 'f32' | 'f64' samples (plain fmt chunk, no extension).
+    Floats deliberately overshoot +-1.0 a little so that the converter's clamp is exercised."""
+    x = pcm16(seed, n, ch, sr).astype(np.float64)
+    if kind == "u8":
+        data, bits, ss, mode = ((x / 256.0).round().clip(-128, 127) + 128).astype(np.uint8).tobytes(), 8, 1, 1
+    elif kind == "s24":
+        v = (x * 256.0 + (np.arange(x.size).reshape(x.shape) % 251)).astype(np.int32)
+        b = v.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]
+        data, bits, ss, mode = np.ascontiguousarray(b).tobytes(), 24, 3, 1
+    elif kind == "s32":
+        v = (x * 65536.0 + (np.arange(x.size).reshape(x.shape) % 65521)).astype("<i4")
+        data, bits, ss, mode = v.tobytes(), 32, 4, 1
+    elif kind == "f32":
+        data, bits, ss, mode = (x / 32000.0).astype("<f4").tobytes(), 32, 4, 3
+    elif kind == "f64":
+        data, bits, ss, mode = (x / 32000.0).astype("<f8").tobytes(), 64, 8, 3
+    else:
+        raise ValueError(kind)
+    fmt = struct.pack("<4sIHHIIHH", b"fmt ", 16, mode, ch, sr, sr * ch * ss, ch * ss, bits)
+    body = b"WAVE" + fmt + struct.pack("<4sI", b"data", len(data)) + data
+    return b"RIFF" + struct.pack("<I", len(body)) + body

@@ -88,6 +88,15 @@ def main():
             if kept % 4 == 0:
                 break
     man["forged"] = forged
+    # WAV sample formats other than 16-bit (PCM::Get_PCM16 conversions): inputs are regenerated from synth.wav_typed,
+    # only digests are stored
+    typed = []
+    for kind in ("u8", "s24", "s32", "f32", "f64"):
+        for ch in (1, 2):
+            w = synth.wav_typed(7, 2600, ch, 44100, kind)
+            typed.append({"kind": kind, "args": [7, 2600, ch, 44100], "wav_sha": sha(w), "adx_sha": sha(R.adx_encode(w)),
+                          "hca_q1_sha": sha(R.hca_encode(w, 1))})
+    man["typed"] = typed
     # generator-independent known answers
     man["known"] = {"crc16_123456789": 0xFEE8,
                     "adx_coefs": {"500,48000": [7400, -3342], "500,44100": [7334, -3283], "500,22050": [6569, -2634], "0,48000": [8192, -4096]},

@@ -205,6 +205,33 @@ def test_hca_encode_special_signals(cc):
             assert diff(cc.HcaEncode(w, 0, q), O.hca_encode(w, q)) is None, q
 
 
+@pytest.mark.parametrize("t", MAN["typed"], ids=lambda t: "%s_%dch" % (t["kind"], t["args"][2]))
+def test_typed_wav_encode(cc, t):
+    """Non-16-bit WAV input: k_pcm_convert + both encoders against the reference's digests and the oracle."""
+    w = synth.wav_typed(*t["args"], t["kind"])
+    assert G.sha(w) == t["wav_sha"]
+    adx = cc.AdxEncode(w, 4, 18, 3, 500, 0, 4, False)
+    assert G.sha(adx) == t["adx_sha"]
+    hca = cc.HcaEncode(w, False, 1)
+    assert G.sha(hca) == t["hca_q1_sha"]
+    w2 = synth.wav_typed(21, 5000, t["args"][2], 48000, t["kind"])
+    for args in [(4, 18, 3, 500, 0, 4), (8, 34, 4, 500, 0, 5), (4, 18, 2, 500, 0, 3)]:
+        assert diff(cc.AdxEncode(w2, *args, False), O.adx_encode(w2, *args)) is None
+    assert diff(cc.HcaEncode(w2, False, 3), O.hca_encode(w2, quality=3)) is None
+
+
+def test_typed_wav_batch(cc):
+    """A batch mixing 16-bit and converted inputs (scratch regions for some items only)."""
+    from pycricodecs_amd import batch
+    ws = [synth.wav(1, 2000, 2, 44100), synth.wav_typed(2, 1500, 2, 44100, "f32"), synth.wav_typed(3, 900, 1, 22050, "u8"),
+          synth.wav(4, 100, 1, 48000), synth.wav_typed(5, 2500, 2, 48000, "s24")]
+    for mk, ora in ((lambda: batch.Job.adx_encode(ws), lambda w: O.adx_encode(w)), (lambda: batch.Job.hca_encode(ws, quality=2), lambda w: O.hca_encode(w, quality=2))):
+        outs, status = mk().run_host()
+        assert list(status) == [0] * len(ws)
+        for w, o in zip(ws, outs):
+            assert diff(bytes(o), ora(w)) is None
+
+
 def test_front_end_encode_roundtrip(cc):
     from pycricodecs_amd import HCA, CriHcaQuality
     w = synth.wav(11, 5000, 2, 48000)

@@ -128,3 +128,13 @@ def test_hca_random_frame_fuzz(q, ch, v3):
         assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
         assert O.hca_decode(f) == R.hca_decode(f)
     assert accepted > 0
+
+
+@pytest.mark.parametrize("kind", ["u8", "s24", "s32", "f32", "f64"])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_typed_wav_inputs(kind, ch):
+    """PCM::Get_PCM16 conversions (pcm.cpp:455-545) feed both encoders identically."""
+    w = synth.wav_typed(11, 3000, ch, 48000, kind)
+    assert O.adx_encode(w) == R.adx_encode(w)
+    assert O.hca_encode(w, quality=2) == R.hca_encode(w, 2)
+
