@@ -200,7 +200,6 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         uint32_t spc = (uint32_t)(total - h.delay - h.padding);
         uint32_t frames = spc == 0 ? 0 : (uint32_t)std::min<uint64_t>(h.frame_count, ((uint64_t)h.delay + spc + 1023) / 1024);
         if ((uint64_t)hs_arg + (uint64_t)frames * h.frame_size > len) { j->host_status[i] = CRI_ERR_HCA_DECODE; continue; }
-        if (h.min_res == 0) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // v3.0 noise fill: not on the device path yet
         // format
         std::vector<uint32_t> key = {h.channels, h.version, h.frame_size, h.min_res, h.max_res, h.total_bands, h.base_bands, h.stereo_bands,
                                      h.bands_per_hfr_group, h.hfr_group_count, h.track_count, h.channel_config};
@@ -266,6 +265,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames; a.runs = runs;
         a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
+        a.noise_fill = F.min_res == 0 ? 1 : 0;
         a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
         b = e;

@@ -470,7 +470,56 @@ __device__ __forceinline__ void imdct_dct4(float* x, float* y, uint32_t m, const
 
 struct TransformCtx {
     const Fmt* F; const uint8_t* ath; float* S; float* G; uint32_t C, lane;
+    // v3.0 noise fill (min_resolution == 0), hca.cpp:1602-1635
+    bool noise; uint8_t* vlist; uint8_t* nrank; uint32_t* ncnt;      // [C][128] valid bands ascending, [C][128] rank of a noise band (0xFF: none), [C][2] = {noise_count, valid_count}
 };
+
+// calculate_resolution for one band (hca.cpp:1450-1488)
+__device__ __forceinline__ uint32_t band_resolution(const Fmt& F, const uint8_t* ath, uint32_t packed, uint32_t i, uint32_t v) {
+    if (v == 0) return 0;
+    const int noise = (int)ath[i] + (int)((packed + i) >> 8);
+    const int cp = noise + 1 - (int)((5 * v) >> 1);
+    uint32_t res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)HCA_CURVE_TO_RES[cp] : 0u);
+    return res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+}
+
+// n steps of the decoder's generator r' = 0x343FD r + 0x269EC3 (hca.cpp:1616) in O(log n): affine maps composed by squaring
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t r, uint32_t n) {
+    uint32_t am = 0x343FDu, ac = 0x269EC3u, rm = 1, rc = 0;
+    while (n) {
+        if (n & 1) { rm *= am; rc = rc * am + ac; }
+        ac = (am + 1) * ac; am *= am; n >>= 1;
+    }
+    return rm * r + rc;
+}
+
+// noise / valid band lists of one frame and channel (the `noises` array of hca.cpp:1489-1497), two bands per lane.
+// Returns the draws one subframe of this channel consumes (noise_count, or 0 when reconstruct_noise returns early).
+__device__ __forceinline__ uint32_t noise_lists(const Fmt& F, const uint8_t* ath, const uint8_t* rec, uint32_t C, uint32_t c, uint32_t lane,
+                                               uint8_t* vlist, uint8_t* nrank, uint32_t* ncnt) {
+    const uint32_t packed = ((const uint32_t*)(rec + HCA_REC_TAIL(C)))[0];
+    const uint32_t sf2 = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
+    bool isn[2], isv[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t i = 2 * lane + h, v = (sf2 >> (8 * h)) & 0xFF;
+        const bool live = i < F.coded(c) && v > 0;
+        const uint32_t res = live ? band_resolution(F, ath, packed, i, v) : 0;
+        isn[h] = live && res < 1; isv[h] = live && res >= 1;
+    }
+    const uint64_t below = (1ull << lane) - 1;
+    const uint64_t bn0 = __ballot(isn[0]), bn1 = __ballot(isn[1]), bv0 = __ballot(isv[0]), bv1 = __ballot(isv[1]);
+    const uint32_t nc = __popcll(bn0) + __popcll(bn1), vc = __popcll(bv0) + __popcll(bv1);
+    if (vlist) {
+        const uint32_t rn = __popcll(bn0 & below) + __popcll(bn1 & below), rv = __popcll(bv0 & below) + __popcll(bv1 & below);
+        nrank[c * 128 + 2 * lane] = isn[0] ? (uint8_t)rn : (uint8_t)0xFF;
+        nrank[c * 128 + 2 * lane + 1] = isn[1] ? (uint8_t)(rn + (isn[0] ? 1 : 0)) : (uint8_t)0xFF;
+        if (isv[0]) vlist[c * 128 + rv] = (uint8_t)(2 * lane);
+        if (isv[1]) vlist[c * 128 + rv + (isv[0] ? 1 : 0)] = (uint8_t)(2 * lane + 1);
+        if (lane == 0) { ncnt[2 * c] = nc; ncnt[2 * c + 1] = vc; }
+    }
+    return (nc > 0 && vc > 0) ? nc : 0;
+}
 
 // gains of one frame: calculate_resolution + calculate_gain (hca.cpp:1444-1507), two bands per lane
 __device__ __forceinline__ void frame_gains(const TransformCtx& X, const uint8_t* rec) {
@@ -498,7 +547,8 @@ __device__ __forceinline__ void frame_gains(const TransformCtx& X, const uint8_t
 }
 
 // spectra of subframe sf of one frame into S: dequantise, HFR, intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
-__device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8_t* rec, uint32_t sf, const uint8_t* inten /* [C][8] resolved */) {
+// `rnd` is the generator state before this subframe's first draw; it is advanced past the subframe's draws.
+__device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8_t* rec, uint32_t sf, const uint8_t* inten /* [C][8] resolved */, uint32_t& rnd) {
     const Fmt& F = *X.F;
     const uint32_t C = X.C, lane = X.lane;
     for (uint32_t c = 0; c < C; c++) {
@@ -509,6 +559,28 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
         X.S[c * 128 + i0 + 1] = i0 + 1 < F.coded(c) ? X.G[c * 128 + i0 + 1] * q1 : 0.0f;
     }
     __syncthreads();
+    if (X.noise) {
+        // reconstruct_noise (hca.cpp:1602-1635): noise band number k of (sf, c) takes draw k+1 after `rnd`; its source is a
+        // valid band, which no noise band overwrites, so all noise bands of a channel are filled at once
+        for (uint32_t c = 0; c < C; c++) {
+            const uint32_t nc = X.ncnt[2 * c], vc = X.ncnt[2 * c + 1];
+            if (nc == 0 || vc == 0) continue;
+            const uint8_t* sfb = rec + HCA_REC_SF(C, c);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t b = 2 * lane + h, k = X.nrank[c * 128 + b];
+                if (k != 0xFF) {
+                    const uint32_t r = lcg_jump(rnd, k + 1);
+                    const uint32_t vi = X.vlist[c * 128 + vc - 1 - (((r & 0x7FFF) * vc) >> 15)];
+                    int sc = (int)sfb[b] - (int)sfb[vi] + 62;
+                    sc = sc & ~(sc >> 31);
+                    X.S[c * 128 + b] = HCA_SCALE_CONV[sc & 127] * X.S[c * 128 + vi];
+                }
+            }
+            rnd = lcg_jump(rnd, nc);
+        }
+        __syncthreads();
+    }
     if (F.bands_per_hfr_group > 0) {
         const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
         const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
@@ -589,6 +661,8 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     const uint32_t C = F.channels, lane = threadIdx.x, g = blockIdx.x;
     float* S = fsm; float* G = S + C * 128; float* P = G + C * 128; float* T = P + C * 128;
     uint8_t* inten = (uint8_t*)(T + 128);           // [C][8]
+    uint32_t* ncnt = (uint32_t*)(inten + ((C * 8 + 15) & ~15u));          // [C][2]
+    uint8_t* vlist = (uint8_t*)(ncnt + 2 * C); uint8_t* nrank = vlist + C * 128;
     const uint32_t si = find_stream(a.streams, a.stream_begin, a.stream_end, g);
     const HcaStream st = a.streams[si];
     const uint32_t f = g - st.first_frame;
@@ -603,14 +677,21 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     for (int i = 0; i < 7; i++) { tw_s[i] = HCA_IMDCT_SIN[i][lane]; tw_c[i] = HCA_IMDCT_COS[i][lane]; }
     const float w0 = HCA_WINDOW[lane], w1 = HCA_WINDOW[lane + 64], w2 = HCA_WINDOW[127 - lane], w3 = HCA_WINDOW[63 - lane];
     TransformCtx X; X.F = &F; X.ath = a.ath_tables + F.ath_index * 128; X.S = S; X.G = G; X.C = C; X.lane = lane;
+    X.noise = a.noise_fill != 0; X.vlist = vlist; X.nrank = nrank; X.ncnt = ncnt;
+    uint32_t rnd = 1;                                // hca.cpp:961 (random = 1 at decoder reset)
 
     // overlap tail from the previous frame's last subframe (hca.cpp:1990-1991); zeros at stream start (hca.cpp:962)
     if (f > 0) {
         const uint8_t* prec = rec - F.record_bytes;
         resolve_intensity(F, rec0, f - 1, C, lane, inten);
         frame_gains(X, prec);
+        if (X.noise) {                               // generator state before the previous frame's subframe 7
+            uint32_t per_sf = 0;
+            for (uint32_t c = 0; c < C; c++) per_sf += noise_lists(F, X.ath, prec, C, c, lane, vlist, nrank, ncnt);
+            rnd = lcg_jump(1, ((const uint32_t*)(prec + HCA_REC_TAIL(C)))[3] + 7 * per_sf);
+        }
         __syncthreads();
-        frame_spectra(X, prec, 7, inten);
+        frame_spectra(X, prec, 7, inten, rnd);
         for (uint32_t c = 0; c < C; c++) {
             imdct_dct4(S + c * 128, T, lane, tw_s, tw_c);
             const float* dct = S + c * 128;
@@ -623,10 +704,14 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     }
     resolve_intensity(F, rec0, f, C, lane, inten);
     frame_gains(X, rec);
+    if (X.noise) {
+        for (uint32_t c = 0; c < C; c++) noise_lists(F, X.ath, rec, C, c, lane, vlist, nrank, ncnt);
+        rnd = lcg_jump(1, ((const uint32_t*)(rec + HCA_REC_TAIL(C)))[3]);
+    }
     __syncthreads();
     int16_t* pcm = (int16_t*)(a.out + st.dst_offset);
     for (uint32_t sf = 0; sf < 8; sf++) {
-        frame_spectra(X, rec, sf, inten);
+        frame_spectra(X, rec, sf, inten, rnd);
         for (uint32_t c = 0; c < C; c++) {
             imdct_dct4(S + c * 128, T, lane, tw_s, tw_c);
             const float* dct = S + c * 128;
@@ -650,6 +735,25 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     }
 }
 
+// Streams with min_resolution == 0 (v3.0): the noise generator runs on across the frames of a stream (hca.cpp:1616, 1633),
+// so every frame needs the number of draws all earlier frames made.  One wave per stream walks its records and leaves
+// that count in tail[3]; the transform then jumps the generator there (lcg_jump).
+__global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
+    const Fmt F = load_fmt(a.formats + a.format);
+    const uint32_t C = F.channels, lane = threadIdx.x;
+    const HcaStream st = a.streams[a.stream_begin + blockIdx.x];
+    const uint8_t* ath = a.ath_tables + F.ath_index * 128;
+    uint32_t total = 0;
+    for (uint32_t f = 0; f < st.frames; f++) {
+        uint8_t* rec = a.scratch + st.scratch_offset + (uint64_t)f * F.record_bytes;
+        uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
+        if ((int32_t)tail[1] != 0) break;                  // nothing past a failed frame is decoded
+        if (lane == 0) tail[3] = total;
+        uint32_t per_sf = 0;
+        for (uint32_t c = 0; c < C; c++) per_sf += noise_lists(F, ath, rec, C, c, lane, nullptr, nullptr, nullptr);
+        total += 8 * per_sf;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // k_hca_transform: register-resident IMDCT, wavefront shuffles for the butterflies (1, 2 or 4 channels)
@@ -978,11 +1082,12 @@ size_t hca_transform_lds_bytes(uint32_t C) { return (size_t)C * 128 * 4 * 2 + 8 
 
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
-    if (a.channels == 1 || a.channels == 2 || a.channels == 4) {
+    if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
+    if (!a.noise_fill && (a.channels == 1 || a.channels == 2 || a.channels == 4)) {
         if (a.plain) hipLaunchKernelGGL(k_hca_transform<true>, dim3(a.runs), dim3(64), hca_transform_lds_bytes(a.channels), s, a);
         else hipLaunchKernelGGL(k_hca_transform<false>, dim3(a.runs), dim3(64), hca_transform_lds_bytes(a.channels), s, a);
     } else {
-        size_t lds = (size_t)(3 * a.channels + 1) * 128 * 4 + a.channels * 8 + 16;
+        size_t lds = (size_t)(3 * a.channels + 1) * 128 * 4 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);
     }
 }

@@ -149,7 +149,7 @@ def test_hca_decode_errors(cc):
         cc.AdxEncode(synth.wav(0, 320, 2), 1, 18, 3, 500, 0, 4, False)
 
 
-@pytest.mark.parametrize("f", [x for x in MAN["forged"] if "v3min0" not in x["file"] and "fuzz_v3" not in x["file"]], ids=lambda f: f["file"])
+@pytest.mark.parametrize("f", MAN["forged"], ids=lambda f: f["file"])
 def test_forged_golden(cc, f):
     data = G.load(f["file"])
     assert G.sha(cc.HcaDecode(data, int.from_bytes(data[6:8], "big"), 0, 0)) == f["decoded_sha"]
@@ -170,6 +170,47 @@ def test_hca_v2_random_frame_fuzz(cc):
                     cc.HcaDecode(f, hs, 0, 0)
                 continue
             assert diff(cc.HcaDecode(f, hs, 0, 0), ref) is None, (q, ch, seed)
+
+
+@pytest.mark.parametrize("q,ch,n", [(1, 2, 9000), (2, 2, 30000), (3, 2, 5000), (1, 1, 12000), (2, 4, 6000), (1, 6, 4000), (1, 4, 6000),
+                                    (3, 1, 3000), (4, 1, 3000), (4, 2, 1100), (3, 2, 2100), (0, 4, 5000)])
+def test_hca_v3_noise_fill(cc, q, ch, n):
+    """v3.0 / min_resolution 0: noise reconstruction (hca.cpp:1602-1635); the generator state runs across frames, so
+    multi-frame streams check k_hca_noise_scan + the jump-ahead.  Also random frames under the v3.0 rules."""
+    base = hca_forge.forge_v3(O.hca_encode(synth.wav(30 + q, n, ch, 48000), q), 0)
+    hs = int.from_bytes(base[6:8], "big")
+    # (with HFR groups the v2.0 frames are not valid v3.0 frames: then both sides must reject, and only random frames decode)
+    accepted = 0
+    for seed in range(-1, 30):
+        f = base if seed < 0 else hca_forge.random_frames(base, seed, density=1.0 if seed % 2 else 0.35)
+        try:
+            ref = O.hca_decode(f)
+        except O.OracleError:
+            with pytest.raises(ValueError):
+                cc.HcaDecode(f, hs, 0, 0)
+            continue
+        accepted += 1
+        assert diff(cc.HcaDecode(f, hs, 0, 0), ref) is None, seed
+    assert accepted > 0
+
+
+def test_hca_v3_noise_batch(cc):
+    from pycricodecs_amd.batch import Job
+    items = []
+    for i in range(7):
+        h = O.hca_encode(synth.wav(50 + i, 3000 + 2100 * i, 1 + i % 2, 44100), 1 + i % 3)
+        items.append(hca_forge.forge_v3(h, 0) if i % 3 != 2 else h)
+    outs, st = Job.hca_decode(items).run_host()
+    good = 0
+    for o, h, code in zip(outs, items, st):
+        try:
+            ref = O.hca_decode(h)
+        except O.OracleError:
+            assert code != 0
+            continue
+        good += 1
+        assert code == 0 and diff(bytes(o), ref) is None
+    assert good >= 5
 
 
 # ------------------------------------------------------------------------------------------------ HCA encode
