@@ -999,6 +999,8 @@ typedef struct {
     uint32_t channels, rate, frame_size, frame_count, delay, padding, channel_config;
     uint32_t total_bands, base_bands, stereo_bands, hfr_group_count, bands_per_hfr_group, hfr_band_count;
     uint32_t header_size, spc;
+    uint32_t loop_flag, loop_start_frame, loop_end_frame, loop_start_delay, loop_end_padding;
+    uint32_t pre_samples, post_samples;                      /* BufferPreSamples, PostSamples */
     int noise_level, eval_boundary;
     enc_chan ch[16];
 } hca_enc;
@@ -1049,6 +1051,30 @@ static int enc_setup(hca_enc* E, uint32_t channels, uint32_t rate, uint32_t spc,
         E->ch[i].coded = types[i] == CH_SECONDARY ? E->base_bands : E->base_bands + E->stereo_bands;
     }
     return 0;
+}
+
+/* Loop branch of initHCAEncode (hca.cpp:2439-2462) with CalculateLoopInfo (2292-2306) and CalculateHeaderSize (2308-2321).
+ * Runs after enc_setup; `column_size` is the WAV's total interleaved sample count (the reference clamps with it as is). */
+static void enc_setup_loop(hca_enc* E, uint32_t loop_start, uint32_t loop_end, uint32_t column_size) {
+    uint32_t input, ls, le, off, pad_bytes, pad_frames;
+    E->loop_flag = 1;
+    E->spc = umin(loop_end, column_size);
+    E->delay += (uint32_t)next_multiple((int)loop_start, 1024) - loop_start;
+    ls = loop_start + E->delay; le = loop_end + E->delay;
+    E->loop_start_frame = ls / 1024; E->loop_start_delay = ls % 1024;
+    E->loop_end_frame = le / 1024; E->loop_end_padding = 1024 - le % 1024;
+    if (E->loop_end_padding == 1024) { E->loop_end_frame--; E->loop_end_padding = 0; }
+    input = umin((uint32_t)next_multiple((int)E->spc, 128), column_size) + 256;
+    E->post_samples = input - E->spc;
+    off = E->header_size + E->frame_size * E->loop_start_frame;
+    pad_bytes = (uint32_t)next_multiple((int)off, 2048) - off;
+    pad_frames = pad_bytes / E->frame_size;
+    E->delay += pad_frames * 1024;
+    E->loop_start_frame += pad_frames; E->loop_end_frame += pad_frames;
+    E->header_size += pad_bytes % E->frame_size;
+    E->frame_count = (uint32_t)div_round_up((int)(input + E->delay), 1024);
+    E->padding = E->frame_count * 1024 - E->delay - input;
+    E->pre_samples = E->delay - 128;
 }
 
 static void enc_dct4(enc_chan* ch, const float* in, uint32_t sf) {          /* hca.cpp:2481-2527 */
@@ -1329,28 +1355,47 @@ static int enc_frame(hca_enc* E, const int16_t* pcm /* 1024*channels interleaved
 }
 
 int ora_hca_encode(const uint8_t* wav, size_t len, uint32_t force_no_loop, uint32_t quality, uint8_t** out, size_t* out_len) {
-    wavin w; hca_enc* E; int rc; uint8_t* o; int16_t* fr; uint32_t f; size_t total;
+    wavin w; hca_enc* E; int rc, looping; uint8_t* o; int16_t* seq; uint32_t f, loop_start = 0, have_spc, pos; size_t total;
     if (!wav || !out || !out_len) return E_ARG;
     rc = wav_parse(wav, len, &w);
     if (rc) return rc;
-    if (w.looping && !force_no_loop) return E_UNSUPPORTED;   /* loop feeding path (hca.cpp:2440-2449, 3015-3023) not restated yet */
+    looping = w.looping && !force_no_loop;
+    if (looping && w.num_loops == 0) return E_UNSUPPORTED;   /* reference reads an empty loop array here */
     rc = wav_pcm16(&w);
     if (rc) { wav_release(&w); return rc; }
     E = (hca_enc*)calloc(1, sizeof *E);
     if (!E) { wav_release(&w); return E_NOMEM; }
     rc = enc_setup(E, w.channels, w.rate, w.column_size / w.channels, quality);
     if (rc) { free(E); wav_release(&w); return rc; }
+    have_spc = w.column_size / w.channels;
+    if (looping) { loop_start = le32(w.loops + 8); enc_setup_loop(E, loop_start, le32(w.loops + 12), w.column_size); }
+    else E->post_samples = 128;
     total = (size_t)E->header_size + (size_t)E->frame_count * E->frame_size;
     o = (uint8_t*)calloc(1, total);
-    fr = (int16_t*)calloc((size_t)1024 * E->channels, 2);
-    for (f = 0; f < E->frame_count && !rc; f++) {            /* feeding, non-loop: hca.cpp:3025-3070 */
-        uint32_t have = 0, first = f * 1024;
-        if (first < E->spc) have = umin(1024, E->spc - first);
-        memset(fr, 0, (size_t)2048 * E->channels);
-        if (have) memcpy(fr, w.pcm + (size_t)first * E->channels, (size_t)have * E->channels * 2);
-        rc = enc_frame(E, fr, o + E->header_size + (size_t)f * E->frame_size);
+    /* The feeding state machine (Encode / HcaEncode / PreEncode / SaveLoopAudio / EncodeMainAudio / EncodePostAudio,
+     * hca.cpp:2990-3107) amounts to encoding this sample sequence frame by frame: whole zero frames while more than 1024
+     * pre-samples remain, the remaining pre-samples as copies of the first sample, the main audio [0, spc), PostSamples
+     * of audio from the loop start (only what SaveLoopAudio saw: chunks of 1024 up to the one where the main audio ends),
+     * zeros to the end.  Samples past the end of the WAV data read as zero (the reference reads out of bounds there). */
+    seq = (int16_t*)calloc((size_t)E->frame_count * 1024 * E->channels + 1, 2);
+    if (!o || !seq) { free(o); free(seq); free(E); wav_release(&w); return E_NOMEM; }
+    {
+        uint32_t pre = E->pre_samples, pos = 0, k, c, seen_end, cap = E->frame_count * 1024;
+        while (pre > 1024) { pos += 1024; pre -= 1024; }
+        for (k = 0; k < pre && pos + k < cap; k++) for (c = 0; c < E->channels; c++) seq[(size_t)(pos + k) * E->channels + c] = have_spc ? w.pcm[c] : 0;
+        pos += pre;
+        for (k = 0; k < E->spc && pos + k < cap; k++) if (k < have_spc)
+            memcpy(seq + (size_t)(pos + k) * E->channels, w.pcm + (size_t)k * E->channels, (size_t)E->channels * 2);
+        pos += E->spc;
+        seen_end = E->spc == 0 ? 1024 : ((E->spc - 1) / 1024 + 1) * 1024;
+        if (looping) for (k = 0; k < E->post_samples && pos + k < cap; k++) {
+            uint64_t src = (uint64_t)loop_start + k;
+            if (src < seen_end && src < have_spc) memcpy(seq + (size_t)(pos + k) * E->channels, w.pcm + (size_t)src * E->channels, (size_t)E->channels * 2);
+        }
     }
-    free(fr);
+    for (f = 0; f < E->frame_count && !rc; f++)
+        rc = enc_frame(E, seq + (size_t)f * 1024 * E->channels, o + E->header_size + (size_t)f * E->frame_size);
+    free(seq);
     if (rc) { free(o); free(E); wav_release(&w); return rc; }
     /* hca.cpp:3109-3164 */
     put_be32(o, 0x48434100u); put_be16(o + 4, 0x0200); put_be16(o + 6, E->header_size);
@@ -1359,8 +1404,14 @@ int ora_hca_encode(const uint8_t* wav, size_t len, uint32_t force_no_loop, uint3
     put_be32(o + 24, 0x636F6D70u); put_be16(o + 28, E->frame_size); o[30] = 1; o[31] = 15; o[32] = 1;
     o[33] = (uint8_t)E->channel_config; o[34] = (uint8_t)E->total_bands; o[35] = (uint8_t)E->base_bands;
     o[36] = (uint8_t)E->stereo_bands; o[37] = (uint8_t)E->bands_per_hfr_group;
-    put_be32(o + 40, 0x63697068u); put_be16(o + 44, 0);
-    put_be32(o + 46, 0x70616400u);
+    pos = 40;
+    if (E->loop_flag) {
+        put_be32(o + 40, 0x6C6F6F70u); put_be32(o + 44, E->loop_start_frame); put_be32(o + 48, E->loop_end_frame);
+        put_be16(o + 52, E->loop_start_delay); put_be16(o + 54, E->loop_end_padding);
+        pos = 56;
+    }
+    put_be32(o + pos, 0x63697068u); put_be16(o + pos + 4, 0);
+    put_be32(o + pos + 6, 0x70616400u);
     put_be16(o + E->header_size - 2, ora_crc16(o, E->header_size - 2));
     free(E); wav_release(&w);
     *out = o; *out_len = total;

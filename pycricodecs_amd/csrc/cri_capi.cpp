@@ -521,11 +521,13 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
         WavInfo w;
         int rc = wav_parse(d, len, w);
         if (rc) { j->host_status[i] = rc; continue; }
-        if (w.looping && !force_no_looping) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // loop feeding path: next
+        const bool looping = w.looping && !force_no_looping;
+        if (looping && w.num_loops == 0) { j->host_status[i] = CRI_ERR_UNSUPPORTED; continue; }   // the reference reads an empty loop array here
         if ((rc = wav_convertible(w))) { j->host_status[i] = rc; continue; }
         HcaEncSetup e;
         rc = hca_enc_setup(w.channels, w.rate, w.column_size / w.channels, quality, e);
         if (rc) { j->host_status[i] = rc; continue; }
+        if (looping) hca_enc_setup_loop(e, w.loop_start[0], w.loop_end[0], w.column_size);
         std::vector<uint32_t> key = {e.channels, e.frame_size, e.total_bands, e.base_bands, e.stereo_bands, e.hfr_group_count,
                                      e.bands_per_hfr_group, e.hfr_band_count, e.channel_config};
         auto fi = fmt_index.find(key);
@@ -544,6 +546,12 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
         HcaStream S; memset(&S, 0, sizeof S);
         S.src_offset = offsets[i] + w.data_offset; S.dst_offset = out_pos + e.header_size; S.format = fidx; S.frames = e.frame_count;
         S.samples = e.samples_per_channel; S.item = i;
+        if (looping) {
+            const uint32_t have = w.column_size / w.channels;
+            const uint32_t seen_end = e.samples_per_channel == 0 ? 1024 : ((e.samples_per_channel - 1) / 1024 + 1) * 1024;   // chunks SaveLoopAudio saw
+            S.enc_loop = 1; S.enc_pre = e.pre_samples; S.enc_pre_zero = e.pre_samples > 1024 ? ((e.pre_samples - 1) / 1024) * 1024 : 0;
+            S.enc_post = e.post_samples; S.enc_loop_src = e.loop_start; S.enc_loop_src_end = std::min(seen_end, have); S.enc_have = have;
+        }
         if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(offsets[i] + w.data_offset, w); S.src_in_scratch = 1; }
         streams.push_back(S);
         out_pos = align_up(out_pos + e.header_size + (uint64_t)e.frame_count * e.frame_size, 64);

@@ -158,7 +158,16 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
     const uint8_t* pcm = (st.src_in_scratch ? a.scratch : a.in) + st.src_offset;
     const int64_t nsamp = (int64_t)st.samples;
     auto sample = [&](int64_t n, uint32_t c) -> float {      // PcmToFloat, hca.cpp:2470-2479 (+ zero history / zero tail)
-        if (n < 0 || n >= nsamp) return 0.0f;
+        if (n < 0) return 0.0f;
+        if (st.enc_loop) {                                   // the feeding sequence of hca.cpp:2990-3107 (see cri_types.h)
+            const int64_t m = n - (int64_t)st.enc_pre;
+            if (n < (int64_t)st.enc_pre_zero) return 0.0f;
+            if (m < 0) n = 0;
+            else if (m < nsamp) n = m;
+            else if (m - nsamp < (int64_t)st.enc_post) { n = (int64_t)st.enc_loop_src + (m - nsamp); if (n >= (int64_t)st.enc_loop_src_end) return 0.0f; }
+            else return 0.0f;
+            if (n >= (int64_t)st.enc_have) return 0.0f;
+        } else if (n >= nsamp) return 0.0f;
         const uint8_t* p = pcm + ((uint64_t)n * C + c) * 2;
         const int v = (int)(int16_t)(p[0] | (p[1] << 8));
         return (float)v * (float)(1.0f / 32768.0f);

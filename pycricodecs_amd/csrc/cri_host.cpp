@@ -479,7 +479,31 @@ int hca_enc_setup(uint32_t channels, uint32_t rate, uint32_t spc, uint32_t quali
     return 0;
 }
 
-void hca_pack_header(const HcaEncSetup& e, uint8_t* o) {      // hca.cpp:3109-3164 (no loop chunk)
+// Loop branch of initHCAEncode (hca.cpp:2439-2462) + CalculateLoopInfo (2292-2306) + CalculateHeaderSize (2308-2321);
+// runs after hca_enc_setup.  column_size is the WAV's total interleaved sample count (the reference clamps with it as is).
+void hca_enc_setup_loop(HcaEncSetup& e, uint32_t loop_start, uint32_t loop_end, uint32_t column_size) {
+    e.loop_flag = 1;
+    e.samples_per_channel = loop_end < column_size ? loop_end : column_size;
+    e.delay += (uint32_t)next_multiple((int)loop_start, 1024) - loop_start;
+    const uint32_t ls = loop_start + e.delay, le = loop_end + e.delay;
+    e.loop_start_frame = ls / 1024; e.loop_start_delay = ls % 1024;
+    e.loop_end_frame = le / 1024; e.loop_end_padding = 1024 - le % 1024;
+    if (e.loop_end_padding == 1024) { e.loop_end_frame--; e.loop_end_padding = 0; }
+    uint32_t input = (uint32_t)next_multiple((int)e.samples_per_channel, 128);
+    input = (input < column_size ? input : column_size) + 256;
+    e.post_samples = input - e.samples_per_channel;
+    const uint32_t off = e.header_size + e.frame_size * e.loop_start_frame;
+    const uint32_t pad_bytes = (uint32_t)next_multiple((int)off, 2048) - off, pad_frames = pad_bytes / e.frame_size;
+    e.delay += pad_frames * 1024;
+    e.loop_start_frame += pad_frames; e.loop_end_frame += pad_frames;
+    e.header_size += pad_bytes % e.frame_size;
+    e.frame_count = (uint32_t)div_round_up((int)(input + e.delay), 1024);
+    e.padding = e.frame_count * 1024 - e.delay - input;
+    e.pre_samples = e.delay - 128;
+    e.loop_start = loop_start;
+}
+
+void hca_pack_header(const HcaEncSetup& e, uint8_t* o) {      // hca.cpp:3109-3164
     memset(o, 0, e.header_size);
     put_be32(o, 0x48434100u); put_be16(o + 4, 0x0200); put_be16(o + 6, e.header_size);
     put_be32(o + 8, 0x666D7400u); put_be32(o + 12, e.rate); o[12] = (uint8_t)e.channels;
@@ -487,8 +511,14 @@ void hca_pack_header(const HcaEncSetup& e, uint8_t* o) {      // hca.cpp:3109-31
     put_be32(o + 24, 0x636F6D70u); put_be16(o + 28, e.frame_size); o[30] = 1; o[31] = 15; o[32] = 1;
     o[33] = (uint8_t)e.channel_config; o[34] = (uint8_t)e.total_bands; o[35] = (uint8_t)e.base_bands;
     o[36] = (uint8_t)e.stereo_bands; o[37] = (uint8_t)e.bands_per_hfr_group;
-    put_be32(o + 40, 0x63697068u); put_be16(o + 44, 0);
-    put_be32(o + 46, 0x70616400u);
+    uint32_t pos = 40;
+    if (e.loop_flag) {
+        put_be32(o + 40, 0x6C6F6F70u); put_be32(o + 44, e.loop_start_frame); put_be32(o + 48, e.loop_end_frame);
+        put_be16(o + 52, e.loop_start_delay); put_be16(o + 54, e.loop_end_padding);
+        pos = 56;
+    }
+    put_be32(o + pos, 0x63697068u); put_be16(o + pos + 4, 0);
+    put_be32(o + pos + 6, 0x70616400u);
     put_be16(o + e.header_size - 2, crc16(o, e.header_size - 2));
 }
 

@@ -79,9 +79,12 @@ void hca_crypt_header(uint8_t* d, uint32_t header_size, uint32_t encrypt, uint32
 struct HcaEncSetup {
     uint32_t channels, rate, frame_size, frame_count, delay, padding, channel_config;
     uint32_t total_bands, base_bands, stereo_bands, hfr_group_count, bands_per_hfr_group, hfr_band_count;
-    uint32_t header_size, samples_per_channel;
+    uint32_t header_size, samples_per_channel;     // samples_per_channel: main audio fed to the encoder (clamped to the loop end)
+    uint32_t loop_flag, loop_start_frame, loop_end_frame, loop_start_delay, loop_end_padding;
+    uint32_t pre_samples, post_samples, loop_start; // BufferPreSamples, PostSamples, first sample of the post audio
     uint8_t type[16]; uint32_t coded[16];
 };
+void hca_enc_setup_loop(HcaEncSetup& e, uint32_t loop_start, uint32_t loop_end, uint32_t column_size);
 int hca_enc_setup(uint32_t channels, uint32_t rate, uint32_t samples_per_channel, uint32_t quality, HcaEncSetup& e);
 void hca_pack_header(const HcaEncSetup& e, uint8_t* out);
 

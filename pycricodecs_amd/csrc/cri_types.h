@@ -32,7 +32,14 @@ struct HcaStream {
     uint32_t src_in_scratch;       // encode: src_offset is relative to the job scratch (converted PCM16)
     uint32_t first_frame;          // global frame number of this stream's frame 0 within its format group
     uint32_t first_run;            // global number of this stream's first run of HCA_RUN (8) frames within its format group
-    uint32_t pad1;
+    // encode, looping input (hca.cpp:2990-3107): the encoder's input is the sequence
+    //   enc_pre_zero zeros | first sample up to enc_pre | `samples` of main audio | enc_post samples from enc_loop_src | zeros
+    uint32_t enc_loop;             // 1: use the sequence above (0: main audio then zeros)
+    uint32_t enc_pre_zero, enc_pre, enc_post;
+    uint32_t enc_loop_src;         // first source sample of the post audio (the loop start)
+    uint32_t enc_loop_src_end;     // source samples at or past this index read as zero in the post audio
+    uint32_t enc_have;             // samples per channel actually present in the WAV data
+    uint32_t pad1, pad2, pad3;
 };
 
 // Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):

@@ -97,6 +97,23 @@ def main():
             typed.append({"kind": kind, "args": [7, 2600, ch, 44100], "wav_sha": sha(w), "adx_sha": sha(R.adx_encode(w)),
                           "hca_q1_sha": sha(R.hca_encode(w, 1))})
     man["typed"] = typed
+    # (sample counts are multiples of 32: the reference's ADX decoder writes whole blocks past its buffer otherwise)
+    # looping WAV input ('smpl' chunk): ADX loop header, HCA loop feeding path + 'loop' chunk, and the decoders' smpl output
+    loops = []
+    for (seed, n, ch, sr, ls, le) in [(0, 8992, 2, 48000, 1000, 8000), (1, 4992, 1, 44100, 0, 4992), (2, 7040, 2, 22050, 2047, 2049),
+                                      (3, 12000, 2, 48000, 5000, 11000), (4, 4000, 1, 48000, 3700, 4000), (5, 6016, 2, 32000, 1, 2)]:
+        w = synth.wav_bytes(synth.pcm16(seed, n, ch, sr), sr, loop=(ls, le))
+        ent = {"args": [seed, n, ch, sr], "loop": [ls, le], "wav_sha": sha(w), "adx": {}, "hca": {}}
+        for ver in (3, 4, 5):
+            a = R.adx_encode(w, 4, 18, 3, 500, 0, ver, 0)
+            ent["adx"][str(ver)] = {"sha": sha(a), "decoded_sha": sha(R.adx_decode(a))}
+        ent["adx_v5_noloop_sha"] = sha(R.adx_encode(w, 4, 18, 3, 500, 0, 5, 1))
+        for q in (1, 3):
+            h = R.hca_encode(w, q)
+            ent["hca"][str(q)] = {"sha": sha(h), "decoded_sha": sha(R.hca_decode(h))}
+        ent["hca_q1_noloop_sha"] = sha(R.hca_encode(w, 1, 1))
+        loops.append(ent)
+    man["loops"] = loops
     # generator-independent known answers
     man["known"] = {"crc16_123456789": 0xFEE8,
                     "adx_coefs": {"500,48000": [7400, -3342], "500,44100": [7334, -3283], "500,22050": [6569, -2634], "0,48000": [8192, -4096]},

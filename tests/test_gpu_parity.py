@@ -273,6 +273,33 @@ def test_typed_wav_batch(cc):
             assert diff(bytes(o), ora(w)) is None
 
 
+@pytest.mark.parametrize("t", MAN["loops"], ids=lambda t: "s%d_%d_%d" % (t["args"][0], t["loop"][0], t["loop"][1]))
+def test_loop_golden(cc, t):
+    """Looping WAV input: ADX loop header, the HCA encoder's loop feeding sequence + loop chunk, smpl chunk out of both decoders."""
+    seed, n, ch, sr = t["args"]
+    w = synth.wav_bytes(synth.pcm16(seed, n, ch, sr), sr, loop=tuple(t["loop"]))
+    assert G.sha(w) == t["wav_sha"]
+    for ver, e in t["adx"].items():
+        a = cc.AdxEncode(w, 4, 18, 3, 500, 0, int(ver), False)
+        assert G.sha(a) == e["sha"] and G.sha(cc.AdxDecode(a)) == e["decoded_sha"]
+    assert G.sha(cc.AdxEncode(w, 4, 18, 3, 500, 0, 5, True)) == t["adx_v5_noloop_sha"]
+    for q, e in t["hca"].items():
+        h = cc.HcaEncode(w, False, int(q))
+        assert G.sha(h) == e["sha"]
+        assert G.sha(cc.HcaDecode(h, int.from_bytes(h[6:8], "big"), 0, 0)) == e["decoded_sha"]
+    assert G.sha(cc.HcaEncode(w, True, 1)) == t["hca_q1_noloop_sha"]
+
+
+@pytest.mark.parametrize("seed,n,ch,sr", [(0, 9000, 2, 48000), (1, 5000, 1, 44100), (2, 20000, 2, 22050), (3, 3000, 4, 48000), (4, 40000, 2, 48000)])
+def test_hca_loop_encode_vs_oracle(cc, seed, n, ch, sr):
+    pcm = synth.pcm16(seed, n, ch, sr)
+    for loop in [(0, n), (100, n - 1), (1024, 2048), (1000, 2000), (2047, 2049), (n - 300, n), (n // 2, n // 2 + 1), (1, 2), (0, 1024), (3000, 2900),
+                 (n - 1, n), (0, 0), (5, n + 700)]:
+        w = synth.wav_bytes(pcm, sr, loop=loop)
+        for q in (0, 3):
+            assert diff(cc.HcaEncode(w, False, q), O.hca_encode(w, quality=q)) is None, (loop, q)
+
+
 def test_front_end_encode_roundtrip(cc):
     from pycricodecs_amd import HCA, CriHcaQuality
     w = synth.wav(11, 5000, 2, 48000)

@@ -138,3 +138,21 @@ def test_typed_wav_inputs(kind, ch):
     assert O.adx_encode(w) == R.adx_encode(w)
     assert O.hca_encode(w, quality=2) == R.hca_encode(w, 2)
 
+
+@pytest.mark.parametrize("seed,n,ch,sr", [(0, 8992, 2, 48000), (1, 4992, 1, 44100), (2, 20000, 2, 22050)])
+@pytest.mark.parametrize("loop", [(0, 3000), (100, 2999), (1024, 4096), (1000, 2000), (2047, 2049), (1, 2), (0, 1024), (3000, 2900)])
+def test_loops(seed, n, ch, sr, loop):
+    """Looping WAV input through both encoders and decoders (sample positions inside the WAV data; the reference reads
+    out of bounds when the post-loop audio runs past it)."""
+    w = synth.wav_bytes(synth.pcm16(seed, n, ch, sr), sr, loop=loop)
+    for ver in (3, 4, 5):
+        for force in (0, 1):
+            a = O.adx_encode(w, version=ver, force_no_loop=bool(force))
+            assert a == R.adx_encode(w, 4, 18, 3, 500, 0, ver, force)
+            assert O.adx_decode(a) == R.adx_decode(a)
+    for q in (0, 2, 4):
+        h = O.hca_encode(w, quality=q)
+        assert h == R.hca_encode(w, q)
+        assert O.hca_decode(h) == R.hca_decode(h)
+    assert O.hca_encode(w, quality=1, force_no_loop=True) == R.hca_encode(w, 1, 1)
+
