@@ -772,65 +772,7 @@ __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
 #include "cri_imdct_tables.h"
 #define HCA_RUN 8
 
-template <int CTRL, int BANK> __device__ __forceinline__ float dpp_f(float old, float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK, false));
-}
-template <int X> __device__ __forceinline__ float lane16_xor(float v) {
-    if (X == 1) return dpp_f<0xB1, 0xF>(v, v);            // quad_perm [1,0,3,2]
-    if (X == 2) return dpp_f<0x4E, 0xF>(v, v);            // quad_perm [2,3,0,1]
-    if (X == 8) return dpp_f<0x128, 0xF>(v, v);           // row_ror:8
-    float t = dpp_f<0x104, 0x5>(v, v);                    // row_shl:4 into banks 0,2
-    return dpp_f<0x114, 0xA>(t, v);                       // row_shr:4 into banks 1,3
-}
-__device__ __forceinline__ float fneg_if(float v, bool n) { return n ? -v : v; }
-
-struct DctLane {
-    float s[11], c[11];        // per-lane twiddles (stages 0-4: one each, stage 5: two, stage 6: four); c of stages 0-3 is role-folded
-    uint32_t l16;              // lane16: bit k set -> this lane is `b` of the cross-lane sum/difference stage k
-};
-
-template <int X, int K> __device__ __forceinline__ void sumdiff_cross(float x[8], const DctLane& L) {
-    const uint32_t m = (L.l16 << (31 - K)) & 0x80000000u;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const float partner = lane16_xor<X>(x[r]);
-        x[r] = partner + __uint_as_float(__float_as_uint(x[r]) ^ m);            // a+b in the `a` lane, a-b in the `b` lane
-    }
-}
-template <int X, int ST> __device__ __forceinline__ void rotate_cross(float x[8], const DctLane& L) {
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const float p1 = x[r] * L.s[ST];
-        const float partner = lane16_xor<X>(x[r]);
-        const float p2 = partner * fneg_if(L.c[ST], HCA_DCT_REGSIGN(ST, r));     // -b*cos in the `a` lane, +a*cos in the `b` lane
-        x[r] = p1 + p2;
-    }
-}
-template <int BIT, int ST> __device__ __forceinline__ void rotate_regs(float x[8], const DctLane& L) {
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        if (r & BIT) continue;
-        const int ti = ST == 4 ? 4 : (ST == 5 ? 5 + (r >> 2) : 7 + (r >> 1));
-        const float sn = L.s[ti], cs = fneg_if(L.c[ti], HCA_DCT_REGSIGN(ST, r));
-        const float a = x[r], b = x[r | BIT];
-        const float as = a * sn, bc = b * cs, ac = a * cs, bs = b * sn;
-        x[r] = as - bc;
-        x[r | BIT] = ac + bs;
-    }
-}
-__device__ __forceinline__ void dct4_inplace(float x[8], const DctLane& L) {
-#pragma unroll
-    for (int bit = 1; bit <= 4; bit <<= 1)                 // sum/difference stages 0..2: register pairs
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (r & bit) continue;
-            const float a = x[r], b = x[r | bit];
-            x[r] = a + b; x[r | bit] = a - b;
-        }
-    sumdiff_cross<1, 0>(x, L); sumdiff_cross<2, 1>(x, L); sumdiff_cross<4, 2>(x, L); sumdiff_cross<8, 3>(x, L);   // stages 3..6
-    rotate_cross<8, 0>(x, L); rotate_cross<4, 1>(x, L); rotate_cross<2, 2>(x, L); rotate_cross<1, 3>(x, L);       // rotation stages 0..3
-    rotate_regs<4, 4>(x, L); rotate_regs<2, 5>(x, L); rotate_regs<1, 6>(x, L);                                    // rotation stages 4..6
-}
+#include "cri_dct_lane.h"
 
 struct TrLds {
     float* G;          // [C][128] gains of the current frame
@@ -840,33 +782,54 @@ struct TrLds {
     float* D;          // [8][128] ring of DCT outputs in logical order
     uint16_t* pcm;     // [512] int16 staging of one pass
     float* win;        // [128] synthesis window
+    float* scale;      // [64] HCA_DEQ_SCALE
+    float* range;      // [16] HCA_DEQ_RANGE
+    uint8_t* curve;    // [66] HCA_CURVE_TO_RES
 };
 
-// per-frame setup: gains (hca.cpp:1444-1507), HFR source/scale per band (1638-1683), intensity indexes (1361-1441 + stale rule)
-__device__ __forceinline__ void tr_setup_frame(const HcaDecArgs& a, const Fmt& F, const TrLds& T, const uint8_t* rec0, uint32_t f, uint32_t lane, int nproc) {
-    const uint32_t C = F.channels;
-    const uint8_t* rec = rec0 + (uint64_t)f * F.record_bytes;
-    const uint8_t* ath = a.ath_tables + F.ath_index * 128;
-    const uint32_t packed = ((const uint32_t*)(rec + HCA_REC_TAIL(C)))[0];
-    for (uint32_t c = 0; c < C; c++) {
-        const uint32_t sf2 = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
+// what the per-frame setup needs from the frame record, fetched one frame ahead so its latency hides behind the
+// previous frame's transforms
+template <int C> struct FramePre { uint32_t packed; int32_t status; uint32_t sf2[C]; };
+template <int C>
+__device__ __forceinline__ FramePre<C> tr_prefetch_frame(const uint8_t* rec, uint32_t lane) {
+    FramePre<C> p;
+    const uint32_t* tail = (const uint32_t*)(rec + HCA_REC_TAIL(C));
+    p.packed = tail[0]; p.status = (int32_t)tail[1];
+#pragma unroll
+    for (int c = 0; c < C; c++) p.sf2[c] = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
+    return p;
+}
+
+// per-frame setup: gains (hca.cpp:1444-1507), HFR source/scale per band (1638-1683), intensity indexes (1361-1441 + stale rule).
+// Table lookups go to LDS copies and are unconditional (selects instead of branches around loads).
+template <bool PLAIN, int C>
+__device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, const uint8_t* rec0, uint32_t f, uint32_t lane, int nproc,
+                                               const FramePre<C>& pre, uint32_t ath2) {
+    const uint32_t packed = __builtin_amdgcn_readfirstlane(pre.packed);
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint32_t sf2 = pre.sf2[c], coded = F.coded(c);
+        float g[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t i = 2 * lane + h, v = (sf2 >> (8 * h)) & 0xFF;
-            float gain = 0.0f;
-            if (i < F.coded(c)) {
-                uint32_t res = 0;
-                if (v > 0) {
-                    const int noise = (int)ath[i] + (int)((packed + i) >> 8);
-                    const int cp = noise + 1 - (int)((5 * v) >> 1);
-                    res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)HCA_CURVE_TO_RES[cp] : 0u);
-                    res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
-                }
-                gain = HCA_DEQ_SCALE[v & 63] * HCA_DEQ_RANGE[res];
-            }
-            T.G[c * 128 + i] = gain;
+            const int noise = (int)((ath2 >> (8 * h)) & 0xFF) + (int)((packed + i) >> 8);
+            const int cp = noise + 1 - (int)((5 * v) >> 1);
+            const int cpc = cp < 0 ? 0 : (cp > 65 ? 65 : cp);
+            uint32_t res = T.curve[cpc];
+            res = cp < 0 ? 15u : (cp > 65 ? 0u : res);
+            res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+            res = v > 0 ? res : 0u;
+            const float gain = T.scale[v & 63] * T.range[res & 15];
+            g[h] = i < coded ? gain : 0.0f;
         }
-        if (F.bands_per_hfr_group > 0 && F.type(c) != CRI_CH_SECONDARY) {
+        *(float2*)(T.G + c * 128 + 2 * lane) = make_float2(g[0], g[1]);
+    }
+    if (!PLAIN) {
+        const uint8_t* rec = rec0 + (uint64_t)f * F.record_bytes;
+#pragma unroll 1
+        for (uint32_t c = 0; c < (uint32_t)C; c++) {
+            if (!(F.bands_per_hfr_group > 0 && F.type(c) != CRI_CH_SECONDARY)) continue;
             const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
             const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
             const uint8_t* sfb = rec + HCA_REC_SF(C, c);
@@ -884,39 +847,34 @@ __device__ __forceinline__ void tr_setup_frame(const HcaDecArgs& a, const Fmt& F
                 }
             }
         }
+        resolve_intensity(F, rec0, f, C, lane, T.inten);
     }
-    resolve_intensity(F, rec0, f, C, lane, T.inten);
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // the 8 spectral lines b = lane16*8 + r of (frame record, subframe, channel) after dequantisation, high-frequency
 // reconstruction and intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
 struct TrFetch { uint4 q, p; };      // quantised lines of (sf, c) for this lane's 8 bands, and of channel c-1 when c is a stereo secondary
-template <bool PLAIN>
+template <bool PLAIN, int C>
 __device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* rec, uint32_t sf, uint32_t c, uint32_t l16) {
     TrFetch t;
-    const uint32_t C = F.channels;
-    t.q = *(const uint4*)(rec + HCA_REC_QC(C, sf, c) + l16 * 16);
+    t.q = *(const uint4*)(rec + (HCA_REC_QC(C, sf, c) + l16 * 16));
     t.p = make_uint4(0, 0, 0, 0);
-    if (!PLAIN && F.type(c) == CRI_CH_SECONDARY && F.stereo_bands > 0) t.p = *(const uint4*)(rec + HCA_REC_QC(C, sf, c - 1) + l16 * 16);
+    if (!PLAIN && F.type(c) == CRI_CH_SECONDARY && F.stereo_bands > 0) t.p = *(const uint4*)(rec + (HCA_REC_QC(C, sf, c - 1) + l16 * 16));
     return t;
 }
-template <bool PLAIN>
-__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const uint8_t* rec, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t l16, int nproc, float x[8]) {
-    const uint32_t C = F.channels;
+template <bool PLAIN, int C>
+__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const uint8_t* rec, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t l16, int nproc, f2 x[4]) {
     const bool secondary = F.type(c) == CRI_CH_SECONDARY;
     const uint32_t qw[4] = {ft.q.x, ft.q.y, ft.q.z, ft.q.w};
     if (PLAIN) {
-        const uint32_t ncoded = F.coded(c);
-        const bool full = ncoded == 128;                  // wave-uniform: no masking needed (the usual "High" layout)
+        // gains are 0 past the coded bands, so no masking is needed
         const float4 g0 = *(const float4*)(T.G + c * 128 + l16 * 8), g1 = *(const float4*)(T.G + c * 128 + l16 * 8 + 4);
-        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const f2 g[4] = {f2{g0.x, g0.y}, f2{g0.z, g0.w}, f2{g1.x, g1.y}, f2{g1.z, g1.w}};
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t b = l16 * 8 + r;
-            const float q = (float)(int)(int16_t)(qw[r >> 1] >> (16 * (r & 1)));
-            const float v = g[r] * q;
-            x[r] = (full || b < ncoded) ? v : 0.0f;
+        for (int k = 0; k < 4; k++) {
+            const f2 q = {(float)(int)(int16_t)(qw[k] & 0xFFFF), (float)((int)qw[k] >> 16)};
+            x[k] = g[k] * q;
         }
         return;
     }
@@ -943,18 +901,21 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
             if (from_prev) v = v * rr;
             else if (F.type(c) == CRI_CH_PRIMARY) v = v * rl;
         }
-        x[r] = v;
+        x[r >> 1][r & 1] = v;
     }
 }
 
-template <bool PLAIN>
+// One loop over "steps": step -1 (only when the run does not start the stream) is the halo -- the DCT of the previous
+// frame's last subframe, which only feeds the overlap ring -- and steps 0 .. nf*2C-1 are the passes of the run's frames.
+template <bool PLAIN, int C>
 __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
-    const uint32_t C = F.channels, lane = threadIdx.x, slot = lane >> 4, l16 = lane & 15;
+    const uint32_t lane = threadIdx.x, slot = lane >> 4, l16 = lane & 15;
     TrLds T;
     T.G = (float*)smem; T.hconv = T.G + C * 128; T.D = T.hconv + C * 128; T.pcm = (uint16_t*)(T.D + 8 * 128);
-    T.win = (float*)(T.pcm + 512); T.hlow = (uint8_t*)(T.win + 128); T.inten = T.hlow + C * 128;
+    T.win = (float*)(T.pcm + 512); T.scale = T.win + 128; T.range = T.scale + 64; T.curve = (uint8_t*)(T.range + 16);
+    T.hlow = T.curve + 80; T.inten = T.hlow + C * 128;
 
     // run -> stream, first frame
     uint32_t lo = a.stream_begin, hi = a.stream_end;
@@ -964,17 +925,19 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
     const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
     const uint8_t* rec0 = a.scratch + st.scratch_offset;
 
-    // per-lane constants
+    // per-lane constants; small tables the setup indexes go to LDS
     DctLane L;
-#pragma unroll
-    for (int i = 0; i < 11; i++) { L.s[i] = HCA_DCT_LANE_SIN[l16][i]; L.c[i] = HCA_DCT_LANE_COS[l16][i]; }
-    L.c[0] = fneg_if(L.c[0], !(l16 & 8)); L.c[1] = fneg_if(L.c[1], !(l16 & 4)); L.c[2] = fneg_if(L.c[2], !(l16 & 2)); L.c[3] = fneg_if(L.c[3], !(l16 & 1));
-    L.l16 = l16;
+    dct_lane_init(L, l16, HCA_DCT_LANE_SIN, HCA_DCT_LANE_COS);
     const uint2 dlogp = *(const uint2*)(HCA_DCT_LOGICAL + l16 * 8);          // 8 logical indexes, one byte each
     T.win[lane] = HCA_WINDOW[lane]; T.win[lane + 64] = HCA_WINDOW[lane + 64];
+    T.scale[lane] = HCA_DEQ_SCALE[lane];
+    if (lane < 16) T.range[lane] = HCA_DEQ_RANGE[lane];
+    T.curve[lane] = HCA_CURVE_TO_RES[lane]; if (lane < 2) T.curve[64 + lane] = HCA_CURVE_TO_RES[64 + lane];
+    const uint32_t ath2 = ((const uint16_t*)(a.ath_tables + F.ath_index * 128))[lane];
+    wave_lds_sync();
     // bands reconstructed by HFR (format constant): stops when the high band leaves the spectrum or the low band index hits 0
     int nproc = 0;
-    if (F.bands_per_hfr_group > 0) {
+    if (!PLAIN && F.bands_per_hfr_group > 0) {
         const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
         const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
         nproc = groups * bpg;
@@ -982,110 +945,116 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
         if (nproc < 0) nproc = 0;
         if (limit * bpg > start - 1 && nproc > start) nproc = start;
     }
-    const uint32_t per_pass_sf = 4 / C;                    // subframes completed by one pass (C = 1, 2, 4)
+    constexpr uint32_t PASSES = 2 * C;                     // passes per frame
+    constexpr uint32_t SPAN = (4 / C) * 128;               // samples per channel completed by one pass
     const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
-    uint32_t sglob = 8;                                    // ring position of the next pass's slot 0
+    uint8_t* dst = a.out + st.dst_offset;
 
-    // ---- halo: DCT of the previous frame's last subframe gives the overlap tail of this run's first subframe
-    if (f0 > 0) {
-        const uint8_t* prec = rec0 + (uint64_t)(f0 - 1) * F.record_bytes;
-        if ((int32_t)((const uint32_t*)(prec + HCA_REC_TAIL(C)))[1] != 0) return;        // the stream failed at an earlier frame
-        tr_setup_frame(a, F, T, rec0, f0 - 1, lane, nproc);
-        float x[8];
-        if (slot < C) { const TrFetch hf = tr_fetch<PLAIN>(F, prec, 7, slot, l16); tr_load_spectra<PLAIN>(F, T, prec, hf, 7, slot, l16, nproc, x); }
-        else { for (int r = 0; r < 8; r++) x[r] = 0.0f; }
-        dct4_inplace(x, L);
-        if (slot < C) {
-            float* d = T.D + ((sglob - C + slot) & 7) * 128;
-#pragma unroll
-            for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r];
+    // records are fetched ahead of use: the setup inputs one frame ahead, the quantised lines one step ahead
+    const bool has_halo = f0 > 0;
+    const uint32_t f_first = has_halo ? f0 - 1 : f0;
+    const uint8_t* rec = rec0 + (uint64_t)f_first * F.record_bytes;         // record of the step's frame
+    FramePre<C> pre = tr_prefetch_frame<C>(rec, lane);
+    TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, rec, 7, slot < (uint32_t)C ? slot : 0, l16) : tr_fetch<PLAIN, C>(F, rec, slot / C, slot % C, l16);
+    uint32_t f = f_first, pass = has_halo ? PASSES : 0;    // pass == PASSES marks the halo step
+    uint32_t ring = 8;                                     // ring position of a normal step's slot 0
+    const uint32_t f_end = f0 + nf;
+
+#pragma unroll 1
+    while (f < f_end) {
+        const bool halo = pass == PASSES;
+        if (halo || pass == 0) {                           // entering a frame
+            const FramePre<C> cur_pre = pre;
+            const int32_t status = __builtin_amdgcn_readfirstlane(cur_pre.status);
+            if (status != 0) { if (!halo && lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
+            if (f + 1 < f_end) pre = tr_prefetch_frame<C>(rec + F.record_bytes, lane);
+            tr_setup_frame<PLAIN, C>(F, T, rec0, f, lane, nproc, cur_pre, ath2);
         }
-        __syncthreads();
-    }
-#pragma unroll 1
-    for (uint32_t fi = 0; fi < nf; fi++) {
-        const uint32_t f = f0 + fi;
-        const uint8_t* rec = rec0 + (uint64_t)f * F.record_bytes;
-        const int32_t status = (int32_t)((const uint32_t*)(rec + HCA_REC_TAIL(C)))[1];
-        if (status != 0) { if (lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
-        tr_setup_frame(a, F, T, rec0, f, lane, nproc);
-        TrFetch ft = tr_fetch<PLAIN>(F, rec, slot / C, slot % C, l16);
-#pragma unroll 1
-        for (uint32_t pass = 0; pass < 2 * C; pass++, sglob += 4) {
-            const uint32_t t = pass * 4 + slot, sf = t / C, c = t % C;
-            const TrFetch cur = ft;
-            if (pass + 1 < 2 * C) ft = tr_fetch<PLAIN>(F, rec, (t + 4) / C, (t + 4) % C, l16);      // next pass's lines are in flight during this pass
-            float x[8];
-            tr_load_spectra<PLAIN>(F, T, rec, cur, sf, c, l16, nproc, x);
-            dct4_inplace(x, L);
-            float* d = T.D + ((sglob + slot) & 7) * 128;
+        const uint32_t t = halo ? 7 * C + slot : pass * 4 + slot, sf = t / C, c = t % C;
+        const TrFetch cur = ft;
+        {   // next step's lines: same frame's next pass, or the next frame's first pass
+            const bool last = halo || pass + 1 == PASSES;
+            if (!last) ft = tr_fetch<PLAIN, C>(F, rec, (t + 4) / C, (t + 4) % C, l16);
+            else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, rec + F.record_bytes, slot / C, slot % C, l16);
+        }
+        f2 x[4];
+        tr_load_spectra<PLAIN, C>(F, T, rec, cur, sf, halo && slot >= (uint32_t)C ? 0 : c, l16, nproc, x);
+        dct4_inplace(x, L);
+        const uint32_t dslot = halo ? ring - C + slot : ring + slot;
+        float* d = T.D + (dslot & 7) * 128;
+        if (!halo || slot < (uint32_t)C) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r];
-            __syncthreads();
-            // window + overlap-add (hca.cpp:1987-1992) against the predecessor (same channel, previous subframe)
-            const float* dp = T.D + ((sglob + slot - C) & 7) * 128;
-            const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
-            const uint32_t sfl = slot / C;                                             // subframe within this pass
-            float o0[4], o1[4];
-            bool odd = false;                              // any product outside int32 range or NaN: x86 cvttss2si semantics needed
+            for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r >> 1][r & 1];
+        }
+        wave_lds_sync();
+        if (halo) { pass = 0; f++; rec += F.record_bytes; continue; }
+
+        // window + overlap-add (hca.cpp:1987-1992) against the predecessor (same channel, previous subframe)
+        const float* dp = T.D + ((dslot - C) & 7) * 128;
+        const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
+        const uint32_t sfl = slot / C;                                             // subframe within this pass
+        float o0[4], o1[4];
+        bool odd = false;                                  // any product outside int32 range or NaN: x86 cvttss2si semantics needed
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int i = (int)l16 + 16 * m;
-                const float p0 = have_prev ? T.win[127 - i] * dp[63 - i] : 0.0f;
-                const float p1 = have_prev ? T.win[63 - i] * dp[i] : 0.0f;
-                o0[m] = (T.win[i] * d[i + 64] + p0) * 32768.0f;
-                o1[m] = (T.win[i + 64] * d[127 - i] - p1) * 32768.0f;
-                odd = odd || !(fabsf(o0[m]) < 2147483648.0f) || !(fabsf(o1[m]) < 2147483648.0f);
-            }
-            const bool slow_cvt = __any(odd);
+        for (int m = 0; m < 4; m++) {
+            const int i = (int)l16 + 16 * m;
+            const float t0 = T.win[127 - i] * dp[63 - i], t1 = T.win[63 - i] * dp[i];
+            const float p0 = have_prev ? t0 : 0.0f, p1 = have_prev ? t1 : 0.0f;
+            o0[m] = (T.win[i] * d[i + 64] + p0) * 32768.0f;
+            o1[m] = (T.win[i + 64] * d[127 - i] - p1) * 32768.0f;
+            odd = odd || !(fabsf(o0[m]) < 2147483648.0f) || !(fabsf(o1[m]) < 2147483648.0f);
+        }
+        const bool slow_cvt = __any(odd);
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int i = (int)l16 + 16 * m;
-                int32_t q0, q1;                                                                  // hca.cpp:339-360
-                if (slow_cvt) { q0 = cvt_trunc_x86(o0[m]); q1 = cvt_trunc_x86(o1[m]); }
-                else { q0 = (int32_t)o0[m]; q1 = (int32_t)o1[m]; }
-                q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
-                q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
-                T.pcm[((sfl * 128 + i) * C) + c] = (uint16_t)(int16_t)q0;
-                T.pcm[((sfl * 128 + i + 64) * C) + c] = (uint16_t)(int16_t)q1;
-            }
-            __syncthreads();
-            // 1 KB of interleaved PCM16 per pass; delay / length trim of hca.cpp:3392-3425
-            const uint32_t n0 = f * 1024 + (pass * per_pass_sf) * 128;
-            uint8_t* dst = a.out + st.dst_offset;
-            const uint32_t span = per_pass_sf * 128;
-            if (dword_ok && n0 >= st.delay && n0 + span - st.delay <= st.samples) {            // whole pass inside the output
-                uint32_t* q = (uint32_t*)(dst + (uint64_t)(n0 - st.delay) * C * 2);
+        for (int m = 0; m < 4; m++) {
+            const int i = (int)l16 + 16 * m;
+            int32_t q0, q1;                                                                  // hca.cpp:339-360
+            if (slow_cvt) { q0 = cvt_trunc_x86(o0[m]); q1 = cvt_trunc_x86(o1[m]); }
+            else { q0 = (int32_t)o0[m]; q1 = (int32_t)o1[m]; }
+            q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
+            q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
+            T.pcm[((sfl * 128 + i) * C) + c] = (uint16_t)(int16_t)q0;
+            T.pcm[((sfl * 128 + i + 64) * C) + c] = (uint16_t)(int16_t)q1;
+        }
+        wave_lds_sync();
+        // 1 KB of interleaved PCM16 per pass; delay / length trim of hca.cpp:3392-3425
+        const uint32_t n0 = f * 1024 + pass * SPAN;
+        if (dword_ok && n0 >= st.delay && n0 + SPAN - st.delay <= st.samples) {              // whole pass inside the output
+            uint32_t* q = (uint32_t*)(dst + (uint64_t)(n0 - st.delay) * C * 2);
 #pragma unroll
-                for (int k = 0; k < 4; k++) q[k * 64 + lane] = ((const uint32_t*)T.pcm)[k * 64 + lane];
-            } else {
+            for (int k = 0; k < 4; k++) q[k * 64 + lane] = ((const uint32_t*)T.pcm)[k * 64 + lane];
+        } else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
-                    const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
-                    const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
-                    const uint32_t word = ((const uint32_t*)T.pcm)[dw];
-                    const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
-                    if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
-                    else {
-                        if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
-                        if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
-                    }
+            for (int q = 0; q < 4; q++) {
+                const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
+                const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
+                const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
+                const uint32_t word = ((const uint32_t*)T.pcm)[dw];
+                const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
+                if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
+                else {
+                    if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
+                    if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
                 }
             }
-            __syncthreads();
         }
+        wave_lds_sync();
+        ring += 4;
+        if (++pass == PASSES) { pass = 0; f++; rec += F.record_bytes; }
     }
 }
 
-size_t hca_transform_lds_bytes(uint32_t C) { return (size_t)C * 128 * 4 * 2 + 8 * 128 * 4 + 1024 + 512 + C * 128 + 64; }
+size_t hca_transform_lds_bytes(uint32_t C) { return (size_t)C * 128 * 4 * 2 + 8 * 128 * 4 + 1024 + 512 + 256 + 64 + 80 + C * 128 + 64; }
 
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
     if (!a.noise_fill && (a.channels == 1 || a.channels == 2 || a.channels == 4)) {
-        if (a.plain) hipLaunchKernelGGL(k_hca_transform<true>, dim3(a.runs), dim3(64), hca_transform_lds_bytes(a.channels), s, a);
-        else hipLaunchKernelGGL(k_hca_transform<false>, dim3(a.runs), dim3(64), hca_transform_lds_bytes(a.channels), s, a);
+        const size_t lds = hca_transform_lds_bytes(a.channels);
+#define CRI_LAUNCH_TR(P, CH) hipLaunchKernelGGL((k_hca_transform<P, CH>), dim3(a.runs), dim3(64), lds, s, a)
+        if (a.plain) { if (a.channels == 1) CRI_LAUNCH_TR(true, 1); else if (a.channels == 2) CRI_LAUNCH_TR(true, 2); else CRI_LAUNCH_TR(true, 4); }
+        else { if (a.channels == 1) CRI_LAUNCH_TR(false, 1); else if (a.channels == 2) CRI_LAUNCH_TR(false, 2); else CRI_LAUNCH_TR(false, 4); }
+#undef CRI_LAUNCH_TR
     } else {
         size_t lds = (size_t)(3 * a.channels + 1) * 128 * 4 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);
