@@ -994,7 +994,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
         const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
         const uint32_t sfl = slot / C;                                             // subframe within this pass
         float o0[4], o1[4];
-        bool odd = false;                                  // any product outside int32 range or NaN: x86 cvttss2si semantics needed
+        uint32_t big = 0;                                  // largest |value| bit pattern: >= 2^31 or NaN needs x86 cvttss2si semantics
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int i = (int)l16 + 16 * m;
@@ -1002,9 +1002,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
             const float p0 = have_prev ? t0 : 0.0f, p1 = have_prev ? t1 : 0.0f;
             o0[m] = (T.win[i] * d[i + 64] + p0) * 32768.0f;
             o1[m] = (T.win[i + 64] * d[127 - i] - p1) * 32768.0f;
-            odd = odd || !(fabsf(o0[m]) < 2147483648.0f) || !(fabsf(o1[m]) < 2147483648.0f);
+            const uint32_t u0 = __float_as_uint(o0[m]) & 0x7FFFFFFFu, u1 = __float_as_uint(o1[m]) & 0x7FFFFFFFu;
+            big = max(big, max(u0, u1));
         }
-        const bool slow_cvt = __any(odd);
+        const bool slow_cvt = __any(big >= 0x4F000000u);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int i = (int)l16 + 16 * m;
