@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_adx_decode(AdxArgs a) {
             const uint32_t nrows = act ? (S.frames - f0 < T ? S.frames - f0 : T) : 0;
             stage_in<16, 2>(lin, __ballot(act), lane, (uint64_t)(src + (uint64_t)f0 * C * bs), (uint64_t)end, X.in_off, nrows * C * bs);
         }
-        __syncthreads();
+        wave_lds_sync();
         // 2. every lane decodes its chain's T blocks out of LDS
         if (X.valid) {
             const uint8_t* fin = lin + X.in_off;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void k_adx_decode(AdxArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         // 3. copy the decoded rows out, clipped to the stream's sample count
         for (uint32_t l = 0; l < 64; l++) {
             if (!__builtin_amdgcn_readlane((int)X.leader, l)) continue;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_adx_decode(AdxArgs a) {
             uint8_t* q = (uint8_t*)readlane64((uint64_t)dst, l) + s0 * C_l * 2;
             copy_out(q, lout + __builtin_amdgcn_readlane(X.out_off, l), (uint32_t)((s1 - s0) * C_l * 2), lane);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
             const uint32_t nrows = act ? (S.frames - f0 < T ? S.frames - f0 : T) : 0;
             stage_in<4, 6>(lin, __ballot(act), lane, (uint64_t)(pcm + (uint64_t)f0 * spb * C * 2), (uint64_t)pcm_end, X.in_off, nrows * spb * C * 2);
         }
-        __syncthreads();
+        wave_lds_sync();
         if (X.valid) {
             const int16_t* fin = (const int16_t*)(lin + X.in_off);
             uint8_t* fo = lout + X.out_off;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t l = 0; l < 64; l++) {
             if (!__builtin_amdgcn_readlane((int)X.leader, l)) continue;
             const uint32_t frames_l = __builtin_amdgcn_readlane(S.frames, l);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
             uint8_t* q = (uint8_t*)readlane64((uint64_t)dst, l) + (uint64_t)f0 * rowb;
             copy_out(q, lout + __builtin_amdgcn_readlane(X.out_off, l), nrows * rowb, lane);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -490,12 +490,12 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
             // two 4-bit codes per byte, first sample in the high nibble; even lanes hold the byte
             const uint32_t nib = silent ? 0u : ((uint32_t)mine & 15);
             const uint32_t nxt = (uint32_t)__shfl_xor((int)nib, 1);
-            __syncthreads();
+            wave_lds_sync();
             if (act) {
                 if (!(s & 1)) blk_img[half * 18 + 2 + (s >> 1)] = (uint8_t)((nib << 4) | nxt);
                 if (s == 0) { blk_img[half * 18] = silent ? 0 : (uint8_t)(word >> 8); blk_img[half * 18 + 1] = silent ? 0 : (uint8_t)word; }
             }
-            __syncthreads();
+            wave_lds_sync();
             uint8_t* row = dst + (uint64_t)fr * 18 * C;
             if (lane < 18 * C) row[lane] = blk_img[lane];
         }

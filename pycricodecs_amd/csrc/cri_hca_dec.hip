@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
     uint32_t* tb = (uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64;
     uint32_t crc = 0;
     int status = 0;
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t r0 = 0; r0 < R; r0 += RC) {
         const uint32_t nr = R - r0 < RC ? R - r0 : RC;
         // coalesced staging: 256 contiguous bytes of one frame per wave load
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
                 rows[r * 64 + fr] = v;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         if (valid) {
             for (uint32_t r = 0; r < nr; r++) {
                 const uint32_t raw = rows[r * 64 + lane];
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
                 rows[r * 64 + lane] = be;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t r = 0; r < nr; r++) tb[(uint64_t)(r0 + r) * 64 + lane] = rows[r * 64 + lane];
-        __syncthreads();
+        wave_lds_sync();
     }
     tb[(uint64_t)R * 64 + lane] = 0;
     if (valid) {
@@ -239,7 +239,7 @@ __device__ __forceinline__ uint32_t band_meta(uint32_t res) {
 
 // transposed flush of the 16 staged words of every lane: frame fr's words go to its record + byte_off, 64 B per frame
 __device__ __forceinline__ void flush16(const uint32_t* ostage, const uint64_t* recoff, uint8_t* scratch, uint32_t lane, uint32_t byte_off, uint32_t nwords) {
-    __syncthreads();
+    wave_lds_sync();
     const uint32_t w = lane & 15;
 #pragma unroll 4
     for (uint32_t it = 0; it < 16; it++) {
@@ -247,7 +247,7 @@ __device__ __forceinline__ void flush16(const uint32_t* ostage, const uint64_t* 
         const uint64_t ro = recoff[fr];
         if (ro != ~0ull && w < nwords) ((uint32_t*)(scratch + ro + byte_off))[w] = ostage[w * 65 + fr];
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     }
     const uint8_t* ath = a.ath_tables + F.ath_index * 128;
     uint8_t* sfst = (uint8_t*)ostage;
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t c = 0; c < C; c++) {
         const uint32_t coded = F.coded(c), type = F.type(c), groups = F.hfr_group_count;
         uint32_t cs = coded, extra = 0;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             }
         }
         if (extra) {                                              // v3.0: scalefactors[127 - i] = scalefactors[cs - i]
-            __syncthreads();
+            __syncthreads();                                      // (global data written by other lanes: drain the stores)
             if (valid) for (uint32_t i = 0; i < extra; i++) {
                 const uint32_t srci = cs - i;
                 rec[HCA_REC_SF(C, c) + 127 - i] = srci < cs ? rec[HCA_REC_SF(C, c) + srci] : 0;
@@ -452,7 +452,7 @@ __device__ __forceinline__ void imdct_dct4(float* x, float* y, uint32_t m, const
         float p = x[2 * m], q = x[2 * m + 1];
         y[2 * c * j + k] = p + q;
         y[2 * c * j + c + k] = p - q;
-        __syncthreads();
+        wave_lds_sync();
         float* t = x; x = y; y = t;
     }
 #pragma unroll
@@ -463,7 +463,7 @@ __device__ __forceinline__ void imdct_dct4(float* x, float* y, uint32_t m, const
         float ps = p * tw_s[i], qc = q * tw_c[i], pc = p * tw_c[i], qs = q * tw_s[i];
         y[2 * c * j + k] = ps - qc;
         y[2 * c * j + 2 * c - 1 - k] = pc + qs;
-        __syncthreads();
+        wave_lds_sync();
         float* t = x; x = y; y = t;
     }
 }
@@ -558,7 +558,7 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
         X.S[c * 128 + i0] = i0 < F.coded(c) ? X.G[c * 128 + i0] * q0 : 0.0f;
         X.S[c * 128 + i0 + 1] = i0 + 1 < F.coded(c) ? X.G[c * 128 + i0 + 1] * q1 : 0.0f;
     }
-    __syncthreads();
+    wave_lds_sync();
     if (X.noise) {
         // reconstruct_noise (hca.cpp:1602-1635): noise band number k of (sf, c) takes draw k+1 after `rnd`; its source is a
         // valid band, which no noise band overwrites, so all noise bands of a channel are filled at once
@@ -579,7 +579,7 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
             }
             rnd = lcg_jump(rnd, nc);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     if (F.bands_per_hfr_group > 0) {
         const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
@@ -609,12 +609,12 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
                     idx[h] = start + k;
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
 #pragma unroll
             for (int h = 0; h < 2; h++) if (idx[h] >= 0) X.S[c * 128 + idx[h]] = vals[h];
-            __syncthreads();
+            wave_lds_sync();
             if (lane == 0 && start + nproc - 1 >= 0) X.S[c * 128 + start + nproc - 1] = 0.0f;
-            __syncthreads();
+            wave_lds_sync();
         }
     }
     if (F.stereo_bands > 0) {
@@ -632,7 +632,7 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
             for (uint32_t c = 0; c < C; c++) per_sf += noise_lists(F, X.ath, prec, C, c, lane, vlist, nrank, ncnt);
             rnd = lcg_jump(1, ((const uint32_t*)(prec + HCA_REC_TAIL(C)))[3] + 7 * per_sf);
         }
-        __syncthreads();
+        wave_lds_sync();
         frame_spectra(X, prec, 7, inten, rnd);
         for (uint32_t c = 0; c < C; c++) {
             imdct_dct4(S + c * 128, T, lane, tw_s, tw_c);
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
             float p0 = w2 * dct[63 - lane], p1 = w3 * dct[lane];
             P[c * 128 + lane] = p0; P[c * 128 + 64 + lane] = p1;
         }
-        __syncthreads();
+        wave_lds_sync();
     } else {
         for (uint32_t c = 0; c < C; c++) { P[c * 128 + lane] = 0.0f; P[c * 128 + 64 + lane] = 0.0f; }
     }
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
         for (uint32_t c = 0; c < C; c++) noise_lists(F, X.ath, rec, C, c, lane, vlist, nrank, ncnt);
         rnd = lcg_jump(1, ((const uint32_t*)(rec + HCA_REC_TAIL(C)))[3]);
     }
-    __syncthreads();
+    wave_lds_sync();
     int16_t* pcm = (int16_t*)(a.out + st.dst_offset);
     for (uint32_t sf = 0; sf < 8; sf++) {
         frame_spectra(X, rec, sf, inten, rnd);
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 

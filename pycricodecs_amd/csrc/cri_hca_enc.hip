@@ -97,7 +97,7 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const EncLds&
         else if (F.groups > 0) min_len += 6 * (int)F.groups;
         if (lane == 0) { L.hbits[c] = min_len; L.dbits[c] = min_db; }
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // CalculateUsedBits, hca.cpp:2763-2790 (integer; reduced across the wave)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 L.tin[i] = ta - tb;
                 L.tin[64 + i] = tc - td;
             }
-            __syncthreads();
+            wave_lds_sync();
             {
                 const int i = (int)lane;
                 const float x = L.tin[2 * i], y = L.tin[127 - 2 * i], s = HCA_ENC_SIN[7][i], co = HCA_ENC_COS[7][i];
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 L.tt[2 * i] = xc + ys;
                 L.tt[2 * i + 1] = xs - yc;
             }
-            __syncthreads();
+            wave_lds_sync();
 #pragma unroll
             for (int stage = 0; stage < 6; stage++) {
                 const int half_bits = 5 - stage, bsz = 1 << (6 - stage), bh = 1 << half_bits;
@@ -209,14 +209,14 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 float vf, vb;
                 if (comp == 0) { vf = A0 + B0; const float m1 = da * co, m2 = db * s; vb = m1 + m2; }
                 else { vf = A1 + B1; const float m1 = da * s, m2 = db * co; vb = m1 - m2; }
-                __syncthreads();
+                wave_lds_sync();
                 L.tt[fp + comp] = vf;
                 L.tt[bp + comp] = vb;
-                __syncthreads();
+                wave_lds_sync();
             }
             L.sp[(c * 8 + sf) * 128 + lane] = L.tt[HCA_ENC_SHUFFLE[lane]] * 0.125f;
             L.sp[(c * 8 + sf) * 128 + 64 + lane] = L.tt[HCA_ENC_SHUFFLE[64 + lane]] * 0.125f;
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 L.inten[(c + 1) * 8 + lane] = (uint8_t)q;
                 L.ratio[lane] = ratio;
             }
-            __syncthreads();
+            wave_lds_sync();
             for (uint32_t sf = 0; sf < 8; sf++) {
                 const float ratio = L.ratio[sf];
                 for (uint32_t b = F.base + lane; b < F.total; b += 64) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                     rsp[sf * 128 + b] = 0;
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     // ---- CalculateHfrGroupAverages + CalculateHfrScale, hca.cpp:2656-2706 (sequential sums: one lane per group)
     if (F.groups > 0) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 
     // ---- rate loop: CalculateNoiseLevel, CalculateEvaluationBoundary (hca.cpp:2792-2866)
@@ -335,9 +335,9 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
             if (noise_level >= 0) break;
             highest -= 2;
             if (highest < 0) { status = CRI_ERR_HCA_ENCODE; break; }
-            __syncthreads();
+            wave_lds_sync();
             if (lane < C) { L.sfac[lane * 128 + highest + 1] = 0; L.sfac[lane * 128 + highest + 2] = 0; }
-            __syncthreads();
+            wave_lds_sync();
             enc_header_length(F, L, lane);
         }
     }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
             L.res[c * 128 + i] = (uint8_t)r;
         }
     for (uint32_t i = lane; i < nwords; i += 64) L.words[i] = 0;
-    __syncthreads();
+    wave_lds_sync();
 
     // ---- PackFrame (hca.cpp:2938-2963): sync word, 9+7 bit header, per channel scalefactors + intensity / HFR scales
     uint32_t pos = 16;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
             pos += (uint32_t)wave_sum((int)(len[0] + len[1]));
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     // ---- CRC16 over frame_size-2 bytes (hca.cpp:2961-2962), chunk per lane + log-step combine.
     // The message is front-padded with zero bytes to 64*m bytes (leading zeros do not change a zero-init CRC).
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
         crc = (uint32_t)__shfl((int)crc, 0);
         if (lane == 0) put_bits(L.words, (F.frame_size - 2) * 8, crc & 0xFFFF, 16);
     }
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t i = lane; i < F.frame_size; i += 64) dst[i] = (uint8_t)(L.words[i >> 2] >> (24 - 8 * (i & 3)));
 }
 
