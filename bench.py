@@ -227,6 +227,17 @@ def main():
     dom = max(kernel_ms, key=kernel_ms.get)
     dom_ms = kernel_ms[dom] / args.steps
     achieved = job.algorithmic_bytes / (dom_ms * 1e-3) / 1e9
+    # HBM bytes of the dominant kernel per launch: PMC counters cannot be collected from inside this process, so the
+    # per-frame figure comes from the committed rocprofv3 counter passes of this same command (profiles/, tools/prof_traffic.sh)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_traffic.json")
+    if args.workload == "hca_decode" and os.path.exists(tpath):
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        if dom in tj.get("kernels", {}):
+            traffic = int(round(tj["kernels"][dom]["hbm_bytes_per_frame"] * units))
+            traffic_src = "profiles/r01_e_traffic.json: %.0f B/frame (FETCH_SIZE x%.0f + WRITE_SIZE, separate --pmc passes) x %d frames" % (
+                tj["kernels"][dom]["hbm_bytes_per_frame"], tj["kernels"][dom]["fetch_correction"], units)
     out = {
         "metric": "audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline",
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,7 +245,7 @@ def main():
         "dtype": "f32" if args.workload == "hca_decode" else "int32", "data": "synthetic (seeded sines+noise; %d unique streams tiled to %d, each copy in its own HBM)" % (args.unique, args.streams),
         "config": metric_cfg,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": job.algorithmic_bytes, "bytes_per_unit": unit_bytes,
                      "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kernel_ms.items()}},
     }
