@@ -38,22 +38,42 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
     uint32_t tt = (t << 1) ^ (t << 2) ^ ((__builtin_popcount(t) & 1) ? 0x8003u : 0u);
     return ((crc << 8) & 0xFFFF) ^ tt;
 }
-__device__ __forceinline__ int enc_find_scalefactor(float v) {               // hca.cpp:2611-2623
+// Workgroup-shared LDS copies of every table the per-frame code indexes with data (global-memory lookups were the
+// encoder's bottleneck: ~940 dependent loads per frame)
+struct EncTab {
+    const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64] [8][64] [64] [64] [16] [16] [16]
+    const uint8_t *curve, *clen, *code, *shuf;                              // [64] [8][16] [8][16] [128]
+};
+#define ENC_TAB_BYTES (512 + 2048 + 2048 + 256 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128)
+__device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads) {
+    float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 64;
+    float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
+    uint8_t* curve = (uint8_t*)(ib + 16); uint8_t* clen = curve + 64; uint8_t* code = clen + 128; uint8_t* shuf = code + 128;
+    for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[i] = HCA_ENC_SHUFFLE[i]; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
+    for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
+    for (uint32_t i = tid; i < 64; i += nthreads) { deq[i] = HCA_DEQ_SCALE[i]; escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
+    for (uint32_t i = tid; i < 16; i += nthreads) { dead[i] = HCA_ENC_DEAD_ZONE[i]; inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f; }
+    EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
+    T.curve = curve; T.clen = clen; T.code = code; T.shuf = shuf;
+    return T;
+}
+
+__device__ __forceinline__ int enc_find_scalefactor(const EncTab& T, float v) {   // hca.cpp:2611-2623
     uint32_t low = 0, high = 63;
-    while (low < high) { uint32_t mid = (low + high) / 2; if (HCA_DEQ_SCALE[mid] <= v) low = mid + 1; else high = mid; }
+    while (low < high) { uint32_t mid = (low + high) / 2; if (T.deq[mid] <= v) low = mid + 1; else high = mid; }
     return (int)low;
 }
-__device__ __forceinline__ int enc_resolution(int sf, int noise) {           // hca.cpp:2752-2761
-    if (sf == 0) return 0;
+__device__ __forceinline__ int enc_resolution(const EncTab& T, int sf, int noise) {   // hca.cpp:2752-2761
     int cp = noise - 5 * sf / 2 + 2;
     cp = cp < 0 ? 0 : (cp > 58 ? 58 : cp);
-    return HCA_ENC_CURVE_TO_RES[cp];
+    const int r = T.curve[cp];
+    return sf == 0 ? 0 : r;
 }
 __device__ __forceinline__ int enc_maxbits(int res) { return res > 7 ? res - 3 : (int)((0x44443320u >> (res * 4)) & 15); }
 
 struct EncLds {
     float* sp;        // [C][8][128] spectra
-    float* sc;        // [C][8][128] scaled spectra
+    float* sc;        // scaled spectra: the same buffer, scaled in place once the unscaled values are no longer needed
     float* tin;       // [128] windowed MDCT input
     float* tt;        // [128] DCT work buffer
     uint32_t* words;  // frame as big-endian 32-bit words
@@ -101,22 +121,22 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const EncLds&
 }
 
 // CalculateUsedBits, hca.cpp:2763-2790 (integer; reduced across the wave)
-__device__ __forceinline__ int enc_used_bits(const EncFmt& F, const EncLds& L, uint32_t lane, int noise_level, int eval_boundary) {
+__device__ __forceinline__ int enc_used_bits(const EncFmt& F, const EncLds& L, const EncTab& T, uint32_t lane, int noise_level, int eval_boundary) {
     int part = 0;
     for (uint32_t c = 0; c < F.C; c++) {
         const int coded = (int)F.coded(c);
         for (int i = (int)lane; i < coded; i += 64) {
             const int noise = i < eval_boundary ? noise_level - 1 : noise_level;
-            const int res = enc_resolution(L.sfac[c * 128 + i], noise);
+            const int res = enc_resolution(T, L.sfac[c * 128 + i], noise);
             const float* x = L.sc + (c * 8) * 128 + i;
             if (res >= 8) {
                 const int bits = enc_maxbits(res) - 1;
-                const float dz = HCA_ENC_DEAD_ZONE[res];
+                const float dz = T.dead[res];
                 for (int j = 0; j < 8; j++) { part += bits; if (fabsf(x[j * 128]) >= dz) part++; }
             } else {
-                const float inv = HCA_ENC_INV_STEP[res], up = inv + 1;
+                const float inv = T.inv[res], up = inv + 1;
                 const int down = (int)((double)inv + 0.5 - 8);
-                for (int j = 0; j < 8; j++) { const int q = (int)(x[j * 128] * inv + up) - down; part += HCA_ENC_CODE_LEN[res][q & 15]; }
+                for (int j = 0; j < 8; j++) { const int q = (int)(x[j * 128] * inv + up) - down; part += T.clen[res * 16 + (q & 15)]; }
             }
         }
     }
@@ -135,18 +155,24 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
     else { atomicOr(&words[w], v >> (-shift)); atomicOr(&words[w + 1], v << (32 + shift)); }
 }
 
-__global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#define ENC_WAVES 4     // most frames (waves) per workgroup; they share the LDS tables and are otherwise independent
+__global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    const EncTab T = enc_tables_to_lds(smem_all, threadIdx.x, blockDim.x);
+    __syncthreads();                                       // the only workgroup barrier: tables are read-only from here on
+    uint8_t* smem = smem_all + ENC_TAB_BYTES + (threadIdx.x >> 6) * a.lds_per_wave;
     const HcaFormat* Fp = a.formats + a.format;
     EncFmt F;
     F.C = Fp->channels; F.frame_size = Fp->frame_size; F.total = Fp->total_bands; F.base = Fp->base_bands; F.stereo = Fp->stereo_bands;
     F.groups = Fp->hfr_group_count; F.bpg = Fp->bands_per_hfr_group; F.hfr_band_count = Fp->hfr_band_count;
     { uint32_t t = 0; for (uint32_t c = 0; c < 16; c++) t |= (uint32_t)(Fp->type[c] & 3) << (2 * c); F.types = t; }
-    const uint32_t C = F.C, lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t C = F.C, lane = threadIdx.x & 63, g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= a.frames) return;
     const uint32_t nwords = (F.frame_size + 3) / 4 + 1;
     EncLds L;
-    L.sp = (float*)smem; L.sc = L.sp + C * 1024; L.tin = L.sc + C * 1024; L.tt = L.tin + 128;
-    L.words = (uint32_t*)(L.tt + 128); L.havg = (float*)(L.words + nwords); L.ratio = L.havg + C * 8;
+    // the MDCT work buffers (tin, tt: 1 KB) and the output frame image (words) are never live together
+    L.sp = (float*)smem; L.sc = L.sp; L.tin = L.sp + C * 1024; L.tt = L.tin + 128;
+    L.words = (uint32_t*)L.tin; L.havg = (float*)(L.words + (nwords > 256 ? nwords : 256)); L.ratio = L.havg + C * 8;
     L.hfrs = (int*)(L.ratio + 8); L.hbits = L.hfrs + C * 8; L.dbits = L.hbits + C;
     L.sfac = (uint8_t*)(L.dbits + C); L.res = L.sfac + C * 128; L.inten = L.res + C * 128;
 
@@ -168,30 +194,38 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
             else return 0.0f;
             if (n >= (int64_t)st.enc_have) return 0.0f;
         } else if (n >= nsamp) return 0.0f;
-        const uint8_t* p = pcm + ((uint64_t)n * C + c) * 2;
-        const int v = (int)(int16_t)(p[0] | (p[1] << 8));
-        return (float)v * (float)(1.0f / 32768.0f);
+        int16_t v; __builtin_memcpy(&v, pcm + ((uint64_t)n * C + c) * 2, 2);
+        return (float)(int)v * (float)(1.0f / 32768.0f);
     };
 
-    // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553, 2481-2527
+    // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553, 2481-2527.  The four samples a lane folds for the next
+    //      transform are fetched while the current one runs.
+    float nx_hi, nx_lo, nx_plo, nx_phi;
+    {
+        const int64_t n0 = (int64_t)f * 1024; const int i = (int)lane;
+        nx_hi = sample(n0 + 64 + i, 0); nx_lo = sample(n0 + 63 - i, 0); nx_plo = sample(n0 - 128 + i, 0); nx_phi = sample(n0 - 1 - i, 0);
+    }
     for (uint32_t c = 0; c < C; c++) {
         for (uint32_t sf = 0; sf < 8; sf++) {
-            const int64_t n0 = (int64_t)f * 1024 + sf * 128;
             {
                 const int i = (int)lane;
-                const float w_hi = sample(n0 + 64 + i, c), w_lo = sample(n0 + 63 - i, c);
-                const float p_lo = sample(n0 - 128 + i, c), p_hi = sample(n0 - 128 + 127 - i, c);
-                const float ta = HCA_WINDOW[63 - i] * -w_hi;
-                const float tb = -HCA_WINDOW[64 + i] * w_lo;
-                const float tc = HCA_WINDOW[i] * p_lo;
-                const float td = -HCA_WINDOW[127 - i] * p_hi;
+                const float w_hi = nx_hi, w_lo = nx_lo, p_lo = nx_plo, p_hi = nx_phi;
+                const uint32_t sn = sf + 1 < 8 ? sf + 1 : 0, cn = sf + 1 < 8 ? c : c + 1;
+                if (cn < C) {
+                    const int64_t n1 = (int64_t)f * 1024 + sn * 128;
+                    nx_hi = sample(n1 + 64 + i, cn); nx_lo = sample(n1 + 63 - i, cn); nx_plo = sample(n1 - 128 + i, cn); nx_phi = sample(n1 - 1 - i, cn);
+                }
+                const float ta = T.win[63 - i] * -w_hi;
+                const float tb = -T.win[64 + i] * w_lo;
+                const float tc = T.win[i] * p_lo;
+                const float td = -T.win[127 - i] * p_hi;
                 L.tin[i] = ta - tb;
                 L.tin[64 + i] = tc - td;
             }
             wave_lds_sync();
             {
                 const int i = (int)lane;
-                const float x = L.tin[2 * i], y = L.tin[127 - 2 * i], s = HCA_ENC_SIN[7][i], co = HCA_ENC_COS[7][i];
+                const float x = L.tin[2 * i], y = L.tin[127 - 2 * i], s = T.esin[7 * 64 + i], co = T.ecos[7 * 64 + i];
                 const float xc = x * co, ys = y * s, xs = x * s, yc = y * co;
                 L.tt[2 * i] = xc + ys;
                 L.tt[2 * i + 1] = xs - yc;
@@ -205,7 +239,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 const int fp = (block * bsz + i) * 2, bp = fp + bsz;
                 const float A0 = L.tt[fp], A1 = L.tt[fp + 1], B0 = L.tt[bp], B1 = L.tt[bp + 1];
                 const float da = A0 - B0, db = A1 - B1;
-                const float s = HCA_ENC_SIN[half_bits][i], co = HCA_ENC_COS[half_bits][i];
+                const float s = T.esin[half_bits * 64 + i], co = T.ecos[half_bits * 64 + i];
                 float vf, vb;
                 if (comp == 0) { vf = A0 + B0; const float m1 = da * co, m2 = db * s; vb = m1 + m2; }
                 else { vf = A1 + B1; const float m1 = da * s, m2 = db * co; vb = m1 - m2; }
@@ -214,8 +248,8 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 L.tt[bp + comp] = vb;
                 wave_lds_sync();
             }
-            L.sp[(c * 8 + sf) * 128 + lane] = L.tt[HCA_ENC_SHUFFLE[lane]] * 0.125f;
-            L.sp[(c * 8 + sf) * 128 + 64 + lane] = L.tt[HCA_ENC_SHUFFLE[64 + lane]] * 0.125f;
+            L.sp[(c * 8 + sf) * 128 + lane] = L.tt[T.shuf[lane]] * 0.125f;
+            L.sp[(c * 8 + sf) * 128 + 64 + lane] = L.tt[T.shuf[64 + lane]] * 0.125f;
             wave_lds_sync();
         }
     }
@@ -236,7 +270,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 if (ratio < 0.5) ratio = 0.5f;
                 else if ((double)ratio > sqrt(2.0) / 2) ratio = (float)(sqrt(2.0) / 2);
                 int q = 1;
-                if (er > 0 || el > 0) { while (q < 13 && HCA_ENC_INTENSITY_BOUNDS[q] >= stored) q++; }
+                if (er > 0 || el > 0) { while (q < 13 && T.ibounds[q] >= stored) q++; }
                 else { q = 0; ratio = 1; }
                 L.inten[(c + 1) * 8 + lane] = (uint8_t)q;
                 L.ratio[lane] = ratio;
@@ -254,65 +288,74 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
         }
     }
 
-    // ---- CalculateScaleFactors + ScaleSpectra, hca.cpp:2625-2654
+    // ---- CalculateHfrGroupAverages, hca.cpp:2656-2674 (sequential sums: one lane per group).  It reads the unscaled
+    //      spectra of the bands above the coded range, so it runs before they are scaled in place.
+    const int hfr_start = (int)(F.stereo + F.base);
+    if (F.groups > 0) {
+        const int bpg = (int)F.bpg;
+        for (uint32_t c = 0; c < C; c++) {
+            if (F.type(c) == CRI_CH_SECONDARY) continue;
+            if (lane < F.groups) {
+                const int grp = (int)lane;
+                float sum = 0.0f; int count = 0;
+                for (int i = 0; i < bpg; i++) {
+                    const int band = hfr_start + grp * bpg + i;
+                    if (band >= 128) break;
+                    for (int sf = 0; sf < 8; sf++) sum += fabsf(L.sp[(c * 8 + sf) * 128 + band]);
+                    count += 8;
+                }
+                L.havg[c * 8 + grp] = sum / (float)count;
+            }
+        }
+        wave_lds_sync();
+    }
+
+    // ---- CalculateScaleFactors + ScaleSpectra, hca.cpp:2625-2654 (scaled in place: L.sc == L.sp)
     for (uint32_t c = 0; c < C; c++) {
         const uint32_t coded = F.coded(c);
         for (uint32_t b = lane; b < 128; b += 64) {
-            uint32_t s = 0;
-            if (b < coded) {
-                float mx = 0;
-                for (int sf = 0; sf < 8; sf++) { const float v = fabsf(L.sp[(c * 8 + sf) * 128 + b]); mx = (v < mx) ? mx : v; }
-                s = (uint32_t)enc_find_scalefactor(mx);
-            }
+            float x[8];
+            float mx = 0;
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) { x[sf] = L.sp[(c * 8 + sf) * 128 + b]; const float v = fabsf(x[sf]); mx = (v < mx) ? mx : v; }
+            uint32_t s = (uint32_t)enc_find_scalefactor(T, mx);
+            s = b < coded ? s : 0u;
             L.sfac[c * 128 + b] = (uint8_t)s;
+            const float es = T.escale[s];
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) {
-                float v = 0;
-                if (b < coded) {
-                    v = L.sp[(c * 8 + sf) * 128 + b] * HCA_ENC_SCALE[s];
-                    if (v > 0.9999999f) v = 0.9999999f; else if (v < -0.9999999f) v = -0.9999999f;
-                    if (s == 0) v = 0;
-                }
+                float v = x[sf] * es;
+                if (v > 0.9999999f) v = 0.9999999f; else if (v < -0.9999999f) v = -0.9999999f;
+                if (s == 0) v = 0;                         // also every band past the coded range
                 L.sc[(c * 8 + sf) * 128 + b] = v;
             }
         }
     }
     wave_lds_sync();
 
-    // ---- CalculateHfrGroupAverages + CalculateHfrScale, hca.cpp:2656-2706 (sequential sums: one lane per group)
+    // ---- CalculateHfrScale, hca.cpp:2676-2706
     if (F.groups > 0) {
-        const int start = (int)(F.stereo + F.base), bpg = (int)F.bpg;
+        const int bpg = (int)F.bpg;
         const int hb = (int)(F.hfr_band_count < F.total - F.hfr_band_count ? F.hfr_band_count : F.total - F.hfr_band_count);
         for (uint32_t c = 0; c < C; c++) {
             if (F.type(c) == CRI_CH_SECONDARY) continue;
             if (lane < F.groups) {
                 const int grp = (int)lane;
-                {
-                    float sum = 0.0f; int count = 0;
-                    for (int i = 0; i < bpg; i++) {
-                        const int band = start + grp * bpg + i;
-                        if (band >= 128) break;
-                        for (int sf = 0; sf < 8; sf++) sum += fabsf(L.sp[(c * 8 + sf) * 128 + band]);
-                        count += 8;
-                    }
-                    L.havg[c * 8 + grp] = sum / (float)count;
+                float sum = 0.0f; int count = 0;
+                for (int i = 0; i < bpg; i++) {
+                    const int band = grp * bpg + i;
+                    if (band >= hb) break;
+                    for (int sf = 0; sf < 8; sf++) sum += fabsf(L.sc[(c * 8 + sf) * 128 + (hfr_start - band - 1)]);
+                    count += 8;
                 }
-                {
-                    float sum = 0.0f; int count = 0;
-                    for (int i = 0; i < bpg; i++) {
-                        const int band = grp * bpg + i;
-                        if (band >= hb) break;
-                        for (int sf = 0; sf < 8; sf++) sum += fabsf(L.sc[(c * 8 + sf) * 128 + (start - band - 1)]);
-                        count += 8;
-                    }
-                    const float avg = sum / (float)count;
-                    float gs = L.havg[c * 8 + grp];
-                    if (avg > 0.0) {
-                        const double m = 1.0 / (double)avg, r2 = sqrt(2.0);
-                        gs = (float)((double)gs * (m < r2 ? m : r2));
-                    }
-                    L.havg[c * 8 + grp] = gs;
-                    L.hfrs[c * 8 + grp] = enc_find_scalefactor(gs);
+                const float avg = sum / (float)count;
+                float gs = L.havg[c * 8 + grp];
+                if (avg > 0.0) {
+                    const double m = 1.0 / (double)avg, r2 = sqrt(2.0);
+                    gs = (float)((double)gs * (m < r2 ? m : r2));
                 }
+                L.havg[c * 8 + grp] = gs;
+                L.hfrs[c * 8 + grp] = enc_find_scalefactor(T, gs);
             }
         }
         wave_lds_sync();
@@ -328,7 +371,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
             int low = 0, high = 255, mid_value = 0;
             while (low != high) {
                 const int mid = (low + high) / 2;
-                mid_value = enc_used_bits(F, L, lane, mid, 0);
+                mid_value = enc_used_bits(F, L, T, lane, mid, 0);
                 if (mid_value > avail) low = mid + 1; else high = mid;
             }
             noise_level = (low == 255 && mid_value > avail) ? -1 : low;
@@ -345,12 +388,12 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
         int low = 0, high = 127;
         while ((high - low > 1) || (low - high > 1)) {
             const int mid = (low + high) / 2;
-            const int v = enc_used_bits(F, L, lane, noise_level, mid);
+            const int v = enc_used_bits(F, L, T, lane, noise_level, mid);
             if (avail < v) high = mid - 1; else low = mid;
         }
         int level;
         if (low == high) level = low < 127 ? low : -1;
-        else level = enc_used_bits(F, L, lane, noise_level, high) > avail ? low : high;
+        else level = enc_used_bits(F, L, T, lane, noise_level, high) > avail ? low : high;
         if (level < 0) status = CRI_ERR_HCA_ENCODE; else eval_boundary = level;
     }
     uint8_t* dst = a.out + st.dst_offset + (uint64_t)f * F.frame_size;
@@ -364,7 +407,7 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
     for (uint32_t c = 0; c < C; c++)
         for (uint32_t i = lane; i < 128; i += 64) {
             int r = 0;
-            if (i < F.coded(c)) r = enc_resolution(L.sfac[c * 128 + i], (int)i < eval_boundary ? noise_level - 1 : noise_level);
+            if (i < F.coded(c)) r = enc_resolution(T, L.sfac[c * 128 + i], (int)i < eval_boundary ? noise_level - 1 : noise_level);
             L.res[c * 128 + i] = (uint8_t)r;
         }
     for (uint32_t i = lane; i < nwords; i += 64) L.words[i] = 0;
@@ -421,10 +464,10 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
                 if (i >= coded) continue;
                 const int r = L.res[c * 128 + i];
                 if (r == 0) continue;
-                const float inv = HCA_ENC_INV_STEP[r], up = inv + 1;
+                const float inv = T.inv[r], up = inv + 1;
                 const int down = (int)((double)inv + 0.5);
                 const int q = (int)(L.sc[(c * 8 + sf) * 128 + i] * inv + up) - down;
-                if (r < 8) { len[h] = HCA_ENC_CODE_LEN[r][(q + 8) & 15]; code[h] = HCA_ENC_CODE[r][(q + 8) & 15]; }
+                if (r < 8) { len[h] = T.clen[r * 16 + ((q + 8) & 15)]; code[h] = T.code[r * 16 + ((q + 8) & 15)]; }
                 else {
                     const uint32_t mb = (uint32_t)enc_maxbits(r) - 1, mag = (uint32_t)(q < 0 ? -q : q) & ((1u << mb) - 1);
                     if (q != 0) { code[h] = (mag << 1) | (q > 0 ? 0u : 1u); len[h] = mb + 1; } else { code[h] = 0; len[h] = mb; }
@@ -463,14 +506,31 @@ __global__ __launch_bounds__(64) void k_hca_encode(HcaEncArgs a) {
     for (uint32_t i = lane; i < F.frame_size; i += 64) dst[i] = (uint8_t)(L.words[i >> 2] >> (24 - 8 * (i & 3)));
 }
 
+// LDS of one frame (wave): spectra, MDCT work buffers / frame image, small per-channel arrays
+size_t hca_encode_lds_per_wave(uint32_t C, uint32_t frame_size) {
+    size_t nwords = (frame_size + 3) / 4 + 1;
+    if (nwords < 256) nwords = 256;
+    const size_t n = (size_t)C * 1024 * 4 + nwords * 4 + C * 8 * 4 + 8 * 4 + C * 8 * 4 + C * 4 * 2 + C * 128 * 2 + C * 8 + 64;
+    return (n + 15) & ~(size_t)15;
+}
+// frames per workgroup: as many as fit the 160 KB of LDS, at most ENC_WAVES (0: not even one fits)
+uint32_t hca_encode_waves(uint32_t C, uint32_t frame_size) {
+    const size_t room = 160 * 1024 - ENC_TAB_BYTES, per = hca_encode_lds_per_wave(C, frame_size);
+    const size_t w = room / per;
+    return (uint32_t)(w > ENC_WAVES ? ENC_WAVES : w);
+}
 size_t hca_encode_lds_bytes(uint32_t C, uint32_t frame_size) {
-    const size_t nwords = (frame_size + 3) / 4 + 1;
-    return (size_t)C * 1024 * 4 * 2 + 256 * 4 + nwords * 4 + C * 8 * 4 + 8 * 4 + C * 8 * 4 + C * 4 * 2 + C * 128 * 2 + C * 8 + 64;
+    const uint32_t w = hca_encode_waves(C, frame_size);
+    return ENC_TAB_BYTES + (w ? w : 1) * hca_encode_lds_per_wave(C, frame_size);
 }
 
 void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
     if (!a.frames) return;
-    hipLaunchKernelGGL(k_hca_encode, dim3(a.frames), dim3(64), hca_encode_lds_bytes(a.channels, a.frame_size), s, a);
+    HcaEncArgs b = a;
+    b.lds_per_wave = (uint32_t)hca_encode_lds_per_wave(a.channels, a.frame_size);
+    const uint32_t w = hca_encode_waves(a.channels, a.frame_size);
+    if (!w) return;
+    hipLaunchKernelGGL(k_hca_encode, dim3((a.frames + w - 1) / w), dim3(64 * w), hca_encode_lds_bytes(a.channels, a.frame_size), s, b);
 }
 
 }  // namespace cri

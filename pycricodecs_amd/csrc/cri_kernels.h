@@ -44,6 +44,7 @@ struct HcaEncArgs {
     const uint16_t* crc_mul;       // [6][16]: (x^bit * x^(8 * crc_chunk * 2^k)) mod P, for the log-step CRC combine
     uint32_t format, stream_begin, stream_end, frames, channels, frame_size;
     uint32_t crc_chunk;            // bytes of the (front-padded) frame each lane checksums
+    uint32_t lds_per_wave;         // LDS bytes of one frame's working set (set by launch_hca_encode)
 };
 size_t hca_encode_lds_bytes(uint32_t channels, uint32_t frame_size);
 void launch_hca_encode(const HcaEncArgs& a, hipStream_t s);
