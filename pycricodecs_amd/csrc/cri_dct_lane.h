@@ -9,23 +9,8 @@
 // Arithmetic is issued as packed fp32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes-worth of work per VALU
 // issue slot); registers are paired along bit 0 (pair k holds reg 2k, 2k+1).
 //
-// Include inside `namespace cri`, after <hip/hip_runtime.h> and cri_imdct_tables.h (HCA_DCT_REGSIGN).
+// Include inside `namespace cri`, after cri_device.h (f2, lane16_xor) and cri_imdct_tables.h (HCA_DCT_REGSIGN).
 #pragma once
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// value of the lane whose lane16 differs in bit X (X = 1, 2, 4, 8), via DPP
-template <int X> __device__ __forceinline__ float lane16_xor(float v) {
-    const int i = __float_as_int(v);
-    if (X == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    if (X == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    if (X == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x128, 0xF, 0xF, true));   // row_ror:8
-    const int t = __builtin_amdgcn_update_dpp(0, i, 0x104, 0xF, 0xF, true);                        // row_shl:4 (right for banks 0,2)
-    return __int_as_float(__builtin_amdgcn_update_dpp(t, i, 0x114, 0xF, 0xA, false));              // row_shr:4 into banks 1,3
-}
-template <int X> __device__ __forceinline__ f2 lane16_xor2(f2 v) { f2 r; r.x = lane16_xor<X>(v.x); r.y = lane16_xor<X>(v.y); return r; }
-
-__device__ __forceinline__ float fneg_if(float v, bool n) { return n ? -v : v; }
 
 struct DctLane {
     float s[11], c[11];        // per-lane twiddles (rotation stages 0-4: one each, stage 5: two, stage 6: four); c of stages 0-3 is role-folded

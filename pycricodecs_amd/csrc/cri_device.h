@@ -23,6 +23,22 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// packed fp32 pair (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 operate on these)
+// value of the lane whose lane16 differs in bit X (X = 1, 2, 4, 8), via DPP
+template <int X> __device__ __forceinline__ float lane16_xor(float v) {
+    const int i = __float_as_int(v);
+    if (X == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    if (X == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    if (X == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x128, 0xF, 0xF, true));   // row_ror:8
+    const int t = __builtin_amdgcn_update_dpp(0, i, 0x104, 0xF, 0xF, true);                        // row_shl:4 (right for banks 0,2)
+    return __int_as_float(__builtin_amdgcn_update_dpp(t, i, 0x114, 0xF, 0xA, false));              // row_shr:4 into banks 1,3
+}
+template <int X> __device__ __forceinline__ f2 lane16_xor2(f2 v) { f2 r; r.x = lane16_xor<X>(v.x); r.y = lane16_xor<X>(v.y); return r; }
+
+__device__ __forceinline__ float fneg_if(float v, bool n) { return n ? -v : v; }
+
 // stream lookup: largest s in [lo, hi) with streams[s].first_frame <= g
 __device__ __forceinline__ uint32_t find_stream(const HcaStream* streams, uint32_t lo, uint32_t hi, uint32_t g) {
     while (hi - lo > 1) {

@@ -42,19 +42,19 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
 // encoder's bottleneck: ~940 dependent loads per frame)
 struct EncTab {
     const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64] [8][64] [64] [64] [16] [16] [16]
-    const uint8_t *curve, *clen, *code, *shuf;                              // [64] [8][16] [8][16] [128]
+    const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
 };
 #define ENC_TAB_BYTES (512 + 2048 + 2048 + 256 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128)
 __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads) {
     float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 64;
     float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
     uint8_t* curve = (uint8_t*)(ib + 16); uint8_t* clen = curve + 64; uint8_t* code = clen + 128; uint8_t* shuf = code + 128;
-    for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[i] = HCA_ENC_SHUFFLE[i]; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
+    for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
     for (uint32_t i = tid; i < 64; i += nthreads) { deq[i] = HCA_DEQ_SCALE[i]; escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
     for (uint32_t i = tid; i < 16; i += nthreads) { dead[i] = HCA_ENC_DEAD_ZONE[i]; inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f; }
     EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
-    T.curve = curve; T.clen = clen; T.code = code; T.shuf = shuf;
+    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf;
     return T;
 }
 
@@ -70,6 +70,13 @@ __device__ __forceinline__ int enc_resolution(const EncTab& T, int sf, int noise
     return sf == 0 ? 0 : r;
 }
 __device__ __forceinline__ int enc_maxbits(int res) { return res > 7 ? res - 3 : (int)((0x44443320u >> (res * 4)) & 15); }
+
+// (u.x*c + u.y*s, u.x*s - u.y*c): the rotation of hca.cpp:2515-2520 / 2493-2496 as three packed operations
+__device__ __forceinline__ f2 enc_rot(f2 u, float sn, float cs) {
+    const f2 p = u.xx * f2{cs, sn};
+    const f2 q = u.yy * f2{sn, cs};
+    return p + f2{q.x, -q.y};
+}
 
 struct EncLds {
     float* sp;        // [C][8][128] spectra
@@ -198,60 +205,82 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         return (float)(int)v * (float)(1.0f / 32768.0f);
     };
 
-    // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553, 2481-2527.  The four samples a lane folds for the next
-    //      transform are fetched while the current one runs.
-    float nx_hi, nx_lo, nx_plo, nx_phi;
+    // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553 (window + fold), 2481-2527 (DCT-IV), in registers.
+    // Four transforms at a time: slot = lane >> 4 picks the transform, its 16 lanes hold the 64 complex points of the
+    // reference's in-place radix-2 network, point j = 4 * lane16 + r in f2 z[r].  Stages on bits 5..2 of j exchange with
+    // lane16 ^ 8, 4, 2, 1 (DPP), stages on bits 1, 0 pair registers.  The lane that holds the lower point of a pair keeps
+    // the sum, the other one rotates the difference; the sum/difference is fma(z, +-1, partner) (exact product).
     {
-        const int64_t n0 = (int64_t)f * 1024; const int i = (int)lane;
-        nx_hi = sample(n0 + 64 + i, 0); nx_lo = sample(n0 + 63 - i, 0); nx_plo = sample(n0 - 128 + i, 0); nx_phi = sample(n0 - 1 - i, 0);
-    }
-    for (uint32_t c = 0; c < C; c++) {
-        for (uint32_t sf = 0; sf < 8; sf++) {
-            {
-                const int i = (int)lane;
-                const float w_hi = nx_hi, w_lo = nx_lo, p_lo = nx_plo, p_hi = nx_phi;
-                const uint32_t sn = sf + 1 < 8 ? sf + 1 : 0, cn = sf + 1 < 8 ? c : c + 1;
-                if (cn < C) {
-                    const int64_t n1 = (int64_t)f * 1024 + sn * 128;
-                    nx_hi = sample(n1 + 64 + i, cn); nx_lo = sample(n1 + 63 - i, cn); nx_plo = sample(n1 - 128 + i, cn); nx_phi = sample(n1 - 1 - i, cn);
-                }
-                const float ta = T.win[63 - i] * -w_hi;
-                const float tb = -T.win[64 + i] * w_lo;
-                const float tc = T.win[i] * p_lo;
-                const float td = -T.win[127 - i] * p_hi;
-                L.tin[i] = ta - tb;
-                L.tin[64 + i] = tc - td;
-            }
-            wave_lds_sync();
-            {
-                const int i = (int)lane;
-                const float x = L.tin[2 * i], y = L.tin[127 - 2 * i], s = T.esin[7 * 64 + i], co = T.ecos[7 * 64 + i];
-                const float xc = x * co, ys = y * s, xs = x * s, yc = y * co;
-                L.tt[2 * i] = xc + ys;
-                L.tt[2 * i + 1] = xs - yc;
-            }
-            wave_lds_sync();
+        const uint32_t l16 = lane & 15, slot = lane >> 4;
+        const bool lowhalf_e = l16 < 8;                        // the lane's even inputs k = 8*l16 + 2r are < 64, its odd inputs 127 - k are >= 64
+        // window coefficients and sample positions (within the 256 samples [n0-128, n0+128)) of the lane's 8 folded inputs
+        float wA[8], wB[8]; int mA[8], mB[8];
 #pragma unroll
-            for (int stage = 0; stage < 6; stage++) {
-                const int half_bits = 5 - stage, bsz = 1 << (6 - stage), bh = 1 << half_bits;
-                const int bf = (int)lane >> 1, comp = (int)lane & 1;
-                const int block = bf >> half_bits, i = bf & (bh - 1);
-                const int fp = (block * bsz + i) * 2, bp = fp + bsz;
-                const float A0 = L.tt[fp], A1 = L.tt[fp + 1], B0 = L.tt[bp], B1 = L.tt[bp + 1];
-                const float da = A0 - B0, db = A1 - B1;
-                const float s = T.esin[half_bits * 64 + i], co = T.ecos[half_bits * 64 + i];
-                float vf, vb;
-                if (comp == 0) { vf = A0 + B0; const float m1 = da * co, m2 = db * s; vb = m1 + m2; }
-                else { vf = A1 + B1; const float m1 = da * s, m2 = db * co; vb = m1 - m2; }
-                wave_lds_sync();
-                L.tt[fp + comp] = vf;
-                L.tt[bp + comp] = vb;
-                wave_lds_sync();
-            }
-            L.sp[(c * 8 + sf) * 128 + lane] = L.tt[T.shuf[lane]] * 0.125f;
-            L.sp[(c * 8 + sf) * 128 + 64 + lane] = L.tt[T.shuf[64 + lane]] * 0.125f;
-            wave_lds_sync();
+        for (int q = 0; q < 8; q++) {
+            const int r = q & 3, odd = q >> 2;
+            const int k = odd ? 127 - 8 * (int)l16 - 2 * r : 8 * (int)l16 + 2 * r;
+            const bool low = k < 64;
+            mA[q] = low ? 192 + k : k - 64; mB[q] = 191 - k;
+            const float a = T.win[low ? 63 - k : k - 64];
+            wA[q] = low ? -a : a;                             // hca.cpp:2532: window * -sample
+            wB[q] = T.win[low ? 64 + k : 191 - k];
         }
+        (void)lowhalf_e;
+        const float sg8 = l16 & 8 ? -1.0f : 1.0f, sg4 = l16 & 4 ? -1.0f : 1.0f, sg2 = l16 & 2 ? -1.0f : 1.0f, sg1 = l16 & 1 ? -1.0f : 1.0f;
+        uint32_t opos[8];                                      // where the lane's 8 outputs go in the spectrum (inverse of the final shuffle)
+#pragma unroll
+        for (int q = 0; q < 8; q++) opos[q] = T.ishuf[8 * l16 + q];
+        float xs[16];                                          // the 16 samples of the next pass, in flight during the current one
+        auto fetch = [&](uint32_t pass) {
+            const uint32_t tr = pass * 4 + slot, c = tr >> 3, sf = tr & 7;
+            const int64_t nb = (int64_t)f * 1024 + sf * 128 - 128;
+#pragma unroll
+            for (int q = 0; q < 8; q++) { xs[2 * q] = sample(nb + mA[q], c); xs[2 * q + 1] = sample(nb + mB[q], c); }
+        };
+        fetch(0);
+#pragma unroll 1
+        for (uint32_t pass = 0; pass < 2 * C; pass++) {
+            const uint32_t tr = pass * 4 + slot, c = tr >> 3, sf = tr & 7;
+            float in[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const float pa = wA[q] * xs[2 * q], pb = wB[q] * xs[2 * q + 1]; in[q] = pa + pb; }   // a - b with b = -(w*x)
+            if (pass + 1 < 2 * C) fetch(pass + 1);
+            f2 z[4];
+            {
+                const float4 s7 = *(const float4*)(T.esin + 7 * 64 + 4 * l16), c7 = *(const float4*)(T.ecos + 7 * 64 + 4 * l16);
+                const float sn[4] = {s7.x, s7.y, s7.z, s7.w}, cs[4] = {c7.x, c7.y, c7.z, c7.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) z[r] = enc_rot(f2{in[r], in[4 + r]}, sn[r], cs[r]);
+            }
+#define ENC_CROSS(X, HB, SG) { \
+                const uint32_t ti = HB * 64 + ((l16 & (X - 1)) << 2); \
+                const float4 s4 = *(const float4*)(T.esin + ti), c4 = *(const float4*)(T.ecos + ti); \
+                const float sn[4] = {s4.x, s4.y, s4.z, s4.w}, cs[4] = {c4.x, c4.y, c4.z, c4.w}; \
+                const bool hi = (l16 & X) != 0; \
+                _Pragma("unroll") for (int r = 0; r < 4; r++) { \
+                    const f2 u = __builtin_elementwise_fma(z[r], f2{SG, SG}, lane16_xor2<X>(z[r])); \
+                    const f2 w = enc_rot(u, sn[r], cs[r]); \
+                    z[r] = f2{hi ? w.x : u.x, hi ? w.y : u.y}; \
+                } }
+            ENC_CROSS(8, 5, sg8) ENC_CROSS(4, 4, sg4) ENC_CROSS(2, 3, sg2) ENC_CROSS(1, 2, sg1)
+#undef ENC_CROSS
+            {   // bit 1 of j: (z0, z2) with twiddle [1][0], (z1, z3) with [1][1]
+                const float2 s1 = *(const float2*)(T.esin + 64), c1 = *(const float2*)(T.ecos + 64);
+                const f2 d0 = z[0] - z[2], d1 = z[1] - z[3];
+                z[0] = z[0] + z[2]; z[1] = z[1] + z[3];
+                z[2] = enc_rot(d0, s1.x, c1.x); z[3] = enc_rot(d1, s1.y, c1.y);
+            }
+            {   // bit 0 of j: (z0, z1), (z2, z3) with twiddle [0][0]
+                const float s0 = T.esin[0], c0 = T.ecos[0];
+                const f2 d0 = z[0] - z[1], d1 = z[2] - z[3];
+                z[0] = z[0] + z[1]; z[2] = z[2] + z[3];
+                z[1] = enc_rot(d0, s0, c0); z[3] = enc_rot(d1, s0, c0);
+            }
+            float* out = L.sp + (c * 8 + sf) * 128;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const f2 o = z[r] * f2{0.125f, 0.125f}; out[opos[2 * r]] = o.x; out[opos[2 * r + 1]] = o.y; }
+        }
+        wave_lds_sync();
     }
 
     // ---- EncodeIntensityStereo, hca.cpp:2561-2609 (sequential sums: one lane per subframe)
