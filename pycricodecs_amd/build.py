@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcricodecs_hip.so")
 SOURCES = ["cri_host.cpp", "cri_hca_dec.hip", "cri_hca_enc.hip", "cri_adx.hip", "cri_misc.hip", "cri_capi.cpp"]
-HEADERS = ["cri_host.h", "cri_kernels.h", "cri_types.h", "cri_tables.h", "cri_imdct_tables.h", "cri_device.h", "../../include/cricodecs_hip.h"]
+HEADERS = ["cri_host.h", "cri_kernels.h", "cri_types.h", "cri_tables.h", "cri_imdct_tables.h", "cri_device.h", "cri_dct_lane.h", "../../include/cricodecs_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + os.environ.get("CRI_HIPCC_EXTRA", "").split() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

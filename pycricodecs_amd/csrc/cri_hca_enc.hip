@@ -22,6 +22,14 @@
 
 namespace cri {
 
+// Developer instrumentation (-DCRI_ENC_PROFILE through CRI_HIPCC_EXTRA): cycles per phase of k_hca_encode, summed over frames
+#ifdef CRI_ENC_PROFILE
+__device__ unsigned long long g_enc_prof[16];
+#define ENC_MARK(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_enc_prof[k], t_ - prof_t); prof_t = t_; } } while (0)
+#else
+#define ENC_MARK(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -42,19 +50,22 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
 // encoder's bottleneck: ~940 dependent loads per frame)
 struct EncTab {
     const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64] [8][64] [64] [64] [16] [16] [16]
+    const uint16_t* crcmul;                                                 // [6][16] per launch (HcaEncArgs::crc_mul)
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
 };
-#define ENC_TAB_BYTES (512 + 2048 + 2048 + 256 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128)
-__device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads) {
+#define ENC_TAB_BYTES (512 + 2048 + 2048 + 256 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192)
+__device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads, const uint16_t* crc_mul) {
     float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 64;
     float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
     uint8_t* curve = (uint8_t*)(ib + 16); uint8_t* clen = curve + 64; uint8_t* code = clen + 128; uint8_t* shuf = code + 128;
+    uint16_t* cm = (uint16_t*)(shuf + 128);
+    for (uint32_t i = tid; i < 96; i += nthreads) cm[i] = crc_mul[i];
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
     for (uint32_t i = tid; i < 64; i += nthreads) { deq[i] = HCA_DEQ_SCALE[i]; escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
     for (uint32_t i = tid; i < 16; i += nthreads) { dead[i] = HCA_ENC_DEAD_ZONE[i]; inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f; }
     EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
-    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf;
+    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm;
     return T;
 }
 
@@ -165,7 +176,7 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 #define ENC_WAVES 4     // most frames (waves) per workgroup; they share the LDS tables and are otherwise independent
 __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-    const EncTab T = enc_tables_to_lds(smem_all, threadIdx.x, blockDim.x);
+    const EncTab T = enc_tables_to_lds(smem_all, threadIdx.x, blockDim.x, a.crc_mul);
     __syncthreads();                                       // the only workgroup barrier: tables are read-only from here on
     uint8_t* smem = smem_all + ENC_TAB_BYTES + (threadIdx.x >> 6) * a.lds_per_wave;
     const HcaFormat* Fp = a.formats + a.format;
@@ -189,22 +200,41 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     const HcaStream st = a.streams[lo];
     const uint32_t f = g - st.first_frame;
     const uint8_t* pcm = (st.src_in_scratch ? a.scratch : a.in) + st.src_offset;
+    // PcmToFloat (hca.cpp:2470-2479) of the sample at position rel (-128 .. 1023) relative to the frame's first sample,
+    // zero outside the stream.  Branch-free so that a lane's 16 loads of a pass issue back to back: the address is
+    // clamped into the readable range and the value selected afterwards.
+    const uint64_t F0 = (uint64_t)f * 1024;
     const int64_t nsamp = (int64_t)st.samples;
-    auto sample = [&](int64_t n, uint32_t c) -> float {      // PcmToFloat, hca.cpp:2470-2479 (+ zero history / zero tail)
-        if (n < 0) return 0.0f;
-        if (st.enc_loop) {                                   // the feeding sequence of hca.cpp:2990-3107 (see cri_types.h)
-            const int64_t m = n - (int64_t)st.enc_pre;
-            if (n < (int64_t)st.enc_pre_zero) return 0.0f;
-            if (m < 0) n = 0;
-            else if (m < nsamp) n = m;
-            else if (m - nsamp < (int64_t)st.enc_post) { n = (int64_t)st.enc_loop_src + (m - nsamp); if (n >= (int64_t)st.enc_loop_src_end) return 0.0f; }
-            else return 0.0f;
-            if (n >= (int64_t)st.enc_have) return 0.0f;
-        } else if (n >= nsamp) return 0.0f;
-        int16_t v; __builtin_memcpy(&v, pcm + ((uint64_t)n * C + c) * 2, 2);
-        return (float)(int)v * (float)(1.0f / 32768.0f);
+    // plain streams: readable rel range [rlo, rhi) of this frame and the address of rel = rlo
+    const int rlo = F0 >= 128 ? -128 : -(int)F0;
+    const int64_t hi64 = nsamp - (int64_t)F0;
+    const int rhi = hi64 > 1024 ? 1024 : (hi64 < -128 ? -128 : (int)hi64);
+    const uint8_t* fbase = pcm + (F0 + (int64_t)rlo) * C * 2;
+    const bool any_plain = rhi > rlo;
+    const bool have_any = st.enc_have > 0;
+    auto sample = [&](int rel, uint32_t c) -> float {
+        int16_t v = 0; bool ok;
+        if (!st.enc_loop) {                                  // wave-uniform
+            const int rc = rel < rlo ? rlo : (rel > rhi - 1 ? rhi - 1 : rel);
+            ok = rc == rel;
+            if (any_plain) __builtin_memcpy(&v, fbase + ((uint32_t)(rc - rlo) * C + c) * 2, 2);
+            ok = ok && any_plain;
+        } else {                                             // the feeding sequence of hca.cpp:2990-3107 (see cri_types.h)
+            const int64_t n = (int64_t)F0 + rel, m = n - (int64_t)st.enc_pre, e = m - nsamp;
+            const bool in_pre = m < 0, in_main = !in_pre && m < nsamp, in_post = !in_pre && !in_main && e < (int64_t)st.enc_post;
+            int64_t src = in_pre ? 0 : (in_main ? m : (int64_t)st.enc_loop_src + e);
+            ok = n >= (int64_t)st.enc_pre_zero && (in_pre || in_main || (in_post && src < (int64_t)st.enc_loop_src_end)) && src < (int64_t)st.enc_have;
+            src = ok ? src : 0;
+            if (have_any) __builtin_memcpy(&v, pcm + ((uint64_t)src * C + c) * 2, 2);
+            ok = ok && have_any;
+        }
+        const float x = (float)(int)v * (float)(1.0f / 32768.0f);
+        return ok ? x : 0.0f;
     };
 
+#ifdef CRI_ENC_PROFILE
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553 (window + fold), 2481-2527 (DCT-IV), in registers.
     // Four transforms at a time: slot = lane >> 4 picks the transform, its 16 lanes hold the 64 complex points of the
     // reference's in-place radix-2 network, point j = 4 * lane16 + r in f2 z[r].  Stages on bits 5..2 of j exchange with
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         float xs[16];                                          // the 16 samples of the next pass, in flight during the current one
         auto fetch = [&](uint32_t pass) {
             const uint32_t tr = pass * 4 + slot, c = tr >> 3, sf = tr & 7;
-            const int64_t nb = (int64_t)f * 1024 + sf * 128 - 128;
+            const int nb = (int)sf * 128 - 128;
 #pragma unroll
             for (int q = 0; q < 8; q++) { xs[2 * q] = sample(nb + mA[q], c); xs[2 * q + 1] = sample(nb + mB[q], c); }
         };
@@ -283,6 +313,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         wave_lds_sync();
     }
 
+    ENC_MARK(0);
     // ---- EncodeIntensityStereo, hca.cpp:2561-2609 (sequential sums: one lane per subframe)
     if (F.stereo > 0) {
         for (uint32_t c = 0; c + 1 < C; c++) {
@@ -317,6 +348,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         }
     }
 
+    ENC_MARK(1);
     // ---- CalculateHfrGroupAverages, hca.cpp:2656-2674 (sequential sums: one lane per group).  It reads the unscaled
     //      spectra of the bands above the coded range, so it runs before they are scaled in place.
     const int hfr_start = (int)(F.stereo + F.base);
@@ -390,6 +422,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         wave_lds_sync();
     }
 
+    ENC_MARK(2);
     // ---- rate loop: CalculateNoiseLevel, CalculateEvaluationBoundary (hca.cpp:2792-2866)
     enc_header_length(F, L, lane);
     const int avail = (int)F.frame_size * 8;
@@ -413,6 +446,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             enc_header_length(F, L, lane);
         }
     }
+    ENC_MARK(3);
     if (status == 0 && noise_level != 0) {
         int low = 0, high = 127;
         while ((high - low > 1) || (low - high > 1)) {
@@ -425,6 +459,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         else level = enc_used_bits(F, L, T, lane, noise_level, high) > avail ? low : high;
         if (level < 0) status = CRI_ERR_HCA_ENCODE; else eval_boundary = level;
     }
+    ENC_MARK(4);
     uint8_t* dst = a.out + st.dst_offset + (uint64_t)f * F.frame_size;
     if (status != 0) {
         if (lane == 0 && a.status) atomicMin(a.status + st.item, status);
@@ -482,6 +517,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             pos += 6 * F.groups;
         }
     }
+    ENC_MARK(5);
     // spectra: QuantizeSpectra (hca.cpp:2878-2892) + WriteSpectra (2920-2936), bands 2*lane, 2*lane+1 per lane
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
@@ -511,6 +547,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     }
     wave_lds_sync();
 
+    ENC_MARK(6);
     // ---- CRC16 over frame_size-2 bytes (hca.cpp:2961-2962), chunk per lane + log-step combine.
     // The message is front-padded with zero bytes to 64*m bytes (leading zeros do not change a zero-init CRC).
     {
@@ -525,14 +562,18 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         for (uint32_t k = 0; k < 6; k++) {
             const uint32_t partner = (uint32_t)__shfl_down((int)crc, 1 << k);
             uint32_t mul = 0;                                           // crc * x^(8*m*2^k) mod P
-            for (uint32_t bit = 0; bit < 16; bit++) if ((crc >> bit) & 1) mul ^= a.crc_mul[k * 16 + bit];
+#pragma unroll
+            for (uint32_t bit = 0; bit < 16; bit++) mul ^= (0u - ((crc >> bit) & 1u)) & T.crcmul[k * 16 + bit];
             if ((lane & ((2u << k) - 1)) == 0) crc = mul ^ partner;
         }
         crc = (uint32_t)__shfl((int)crc, 0);
         if (lane == 0) put_bits(L.words, (F.frame_size - 2) * 8, crc & 0xFFFF, 16);
     }
     wave_lds_sync();
-    for (uint32_t i = lane; i < F.frame_size; i += 64) dst[i] = (uint8_t)(L.words[i >> 2] >> (24 - 8 * (i & 3)));
+    // the frame image is big-endian words; whole dwords go out byte-swapped (unaligned dword stores), then the last bytes
+    for (uint32_t i = lane; 4 * i + 4 <= F.frame_size; i += 64) { const uint32_t w = __builtin_bswap32(L.words[i]); __builtin_memcpy(dst + 4 * i, &w, 4); }
+    if (lane < (F.frame_size & 3)) { const uint32_t i = (F.frame_size & ~3u) + lane; dst[i] = (uint8_t)(L.words[i >> 2] >> (24 - 8 * (i & 3))); }
+    ENC_MARK(7);
 }
 
 // LDS of one frame (wave): spectra, MDCT work buffers / frame image, small per-channel arrays
@@ -563,3 +604,11 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
 }
 
 }  // namespace cri
+
+#ifdef CRI_ENC_PROFILE
+extern "C" int cri_debug_enc_profile(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cri::g_enc_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cri::g_enc_prof), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
