@@ -212,22 +212,20 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     const uint8_t* fbase = pcm + (F0 + (int64_t)rlo) * C * 2;
     const bool any_plain = rhi > rlo;
     const bool have_any = st.enc_have > 0;
-    auto sample = [&](int rel, uint32_t c) -> float {
-        int16_t v = 0; bool ok;
-        if (!st.enc_loop) {                                  // wave-uniform
-            const int rc = rel < rlo ? rlo : (rel > rhi - 1 ? rhi - 1 : rel);
-            ok = rc == rel;
-            if (any_plain) __builtin_memcpy(&v, fbase + ((uint32_t)(rc - rlo) * C + c) * 2, 2);
-            ok = ok && any_plain;
-        } else {                                             // the feeding sequence of hca.cpp:2990-3107 (see cri_types.h)
-            const int64_t n = (int64_t)F0 + rel, m = n - (int64_t)st.enc_pre, e = m - nsamp;
-            const bool in_pre = m < 0, in_main = !in_pre && m < nsamp, in_post = !in_pre && !in_main && e < (int64_t)st.enc_post;
-            int64_t src = in_pre ? 0 : (in_main ? m : (int64_t)st.enc_loop_src + e);
-            ok = n >= (int64_t)st.enc_pre_zero && (in_pre || in_main || (in_post && src < (int64_t)st.enc_loop_src_end)) && src < (int64_t)st.enc_have;
-            src = ok ? src : 0;
-            if (have_any) __builtin_memcpy(&v, pcm + ((uint64_t)src * C + c) * 2, 2);
-            ok = ok && have_any;
-        }
+    // (the two stream kinds are separate straight-line code so that nothing but loads sits between the loads)
+    auto sample_plain = [&](int rel, uint32_t c) -> float {
+        const int rc = rel < rlo ? rlo : (rel > rhi - 1 ? rhi - 1 : rel);
+        int16_t v; __builtin_memcpy(&v, fbase + ((uint32_t)(rc - rlo) * C + c) * 2, 2);
+        const float x = (float)(int)v * (float)(1.0f / 32768.0f);
+        return rc == rel ? x : 0.0f;
+    };
+    auto sample_loop = [&](int rel, uint32_t c) -> float {   // the feeding sequence of hca.cpp:2990-3107 (see cri_types.h)
+        const int64_t n = (int64_t)F0 + rel, m = n - (int64_t)st.enc_pre, e = m - nsamp;
+        const bool in_pre = m < 0, in_main = !in_pre && m < nsamp, in_post = !in_pre && !in_main && e < (int64_t)st.enc_post;
+        int64_t src = in_pre ? 0 : (in_main ? m : (int64_t)st.enc_loop_src + e);
+        const bool ok = n >= (int64_t)st.enc_pre_zero && (in_pre || in_main || (in_post && src < (int64_t)st.enc_loop_src_end)) && src < (int64_t)st.enc_have;
+        src = ok ? src : 0;
+        int16_t v; __builtin_memcpy(&v, pcm + ((uint64_t)src * C + c) * 2, 2);
         const float x = (float)(int)v * (float)(1.0f / 32768.0f);
         return ok ? x : 0.0f;
     };
@@ -264,8 +262,21 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         auto fetch = [&](uint32_t pass) {
             const uint32_t tr = pass * 4 + slot, c = tr >> 3, sf = tr & 7;
             const int nb = (int)sf * 128 - 128;
+            if (!st.enc_loop) {
+                if (any_plain) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) { xs[2 * q] = sample(nb + mA[q], c); xs[2 * q + 1] = sample(nb + mB[q], c); }
+                    for (int q = 0; q < 8; q++) { xs[2 * q] = sample_plain(nb + mA[q], c); xs[2 * q + 1] = sample_plain(nb + mB[q], c); }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) xs[q] = 0.0f;
+                }
+            } else if (have_any) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { xs[2 * q] = sample_loop(nb + mA[q], c); xs[2 * q + 1] = sample_loop(nb + mB[q], c); }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) xs[q] = 0.0f;
+            }
         };
         fetch(0);
 #pragma unroll 1
