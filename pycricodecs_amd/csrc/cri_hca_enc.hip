@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     EncLds L;
     // the MDCT work buffers (tin, tt: 1 KB) and the output frame image (words) are never live together
     L.sp = (float*)smem; L.sc = L.sp; L.tin = L.sp + C * 1024; L.tt = L.tin + 128;
-    L.words = (uint32_t*)L.tin; L.havg = (float*)(L.words + (nwords > 256 ? nwords : 256)); L.ratio = L.havg + C * 8;
+    L.words = (uint32_t*)L.tin; L.havg = (float*)(L.words + (nwords > 320 ? nwords : 320)); L.ratio = L.havg + C * 8;
     L.hfrs = (int*)(L.ratio + 8); L.hbits = L.hfrs + C * 8; L.dbits = L.hbits + C;
     L.sfac = (uint8_t*)(L.dbits + C); L.res = L.sfac + C * 128; L.inten = L.res + C * 128;
 
@@ -258,34 +258,65 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         uint32_t opos[8];                                      // where the lane's 8 outputs go in the spectrum (inverse of the final shuffle)
 #pragma unroll
         for (int q = 0; q < 8; q++) opos[q] = T.ishuf[8 * l16 + q];
-        float xs[16];                                          // the 16 samples of the next pass, in flight during the current one
-        auto fetch = [&](uint32_t pass) {
-            const uint32_t tr = pass * 4 + slot, c = tr >> 3, sf = tr & 7;
-            const int nb = (int)sf * 128 - 128;
-            if (!st.enc_loop) {
-                if (any_plain) {
+        // PCM of a pass (one channel, 4 subframes + the 128 samples before them = 640 samples) goes through LDS: coalesced
+        // dword loads, every cache line requested once (lane-scattered 2-byte loads asked for each line 8 times and made
+        // this phase L2-request bound).  The next pass's dwords are in flight during the current pass.
+        int16_t* stg = (int16_t*)L.tin;                        // [640]
+        uint32_t dw[10];
+        bool fast_next = false;
+        auto pass_fast = [&](uint32_t pass) -> bool {          // mono / stereo, no loop mapping, window entirely inside the stream
+            const int first = (int)((pass * 4) & 7) * 128 - 128;
+            return !st.enc_loop && (C == 1 || C == 2) && first >= rlo && first + 640 <= rhi;
+        };
+        auto issue = [&](uint32_t pass) {
+            fast_next = pass_fast(pass);
+            if (!fast_next) return;
+            const int first = (int)((pass * 4) & 7) * 128 - 128;
+            const uint8_t* src = fbase + (uint32_t)(first - rlo) * C * 2;
+            const uint32_t nd = 320 * C;                       // dwords of the pass window
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { xs[2 * q] = sample_plain(nb + mA[q], c); xs[2 * q + 1] = sample_plain(nb + mB[q], c); }
+            for (int j = 0; j < 10; j++) { const uint32_t k = lane + 64 * j; dw[j] = 0; if (k < nd) dw[j] = ld_u32_unaligned(src + 4 * k); }
+        };
+        auto commit = [&](uint32_t pass) {
+            const uint32_t c = (pass * 4) >> 3;
+            if (fast_next) {
+                if (C == 2) {
+#pragma unroll
+                    for (int j = 0; j < 10; j++) stg[lane + 64 * j] = (int16_t)(dw[j] >> (16 * c));
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 16; q++) xs[q] = 0.0f;
+                    for (int j = 0; j < 5; j++) ((uint32_t*)stg)[lane + 64 * j] = dw[j];
                 }
-            } else if (have_any) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) { xs[2 * q] = sample_loop(nb + mA[q], c); xs[2 * q + 1] = sample_loop(nb + mB[q], c); }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; q++) xs[q] = 0.0f;
+            } else {                                           // stream edges, loop streams, more than two channels
+                const int first = (int)((pass * 4) & 7) * 128 - 128;
+                for (uint32_t i = lane; i < 640; i += 64) {
+                    const float x = st.enc_loop ? (have_any ? sample_loop(first + (int)i, c) : 0.0f) : (any_plain ? sample_plain(first + (int)i, c) : 0.0f);
+                    stg[i] = (int16_t)(int)(x * 32768.0f);     // exact round trip of the int16 sample
+                }
             }
         };
-        fetch(0);
+        ENC_MARK(8);
+        issue(0);
+        ENC_MARK(9);
 #pragma unroll 1
         for (uint32_t pass = 0; pass < 2 * C; pass++) {
             const uint32_t tr = pass * 4 + slot, c = tr >> 3, sf = tr & 7;
+            wave_lds_sync();
+            commit(pass);
+            wave_lds_sync();
+            ENC_MARK(10);
+            if (pass + 1 < 2 * C) issue(pass + 1);
+            ENC_MARK(11);
             float in[8];
+            {
+                const int16_t* sw = stg + slot * 128;
 #pragma unroll
-            for (int q = 0; q < 8; q++) { const float pa = wA[q] * xs[2 * q], pb = wB[q] * xs[2 * q + 1]; in[q] = pa + pb; }   // a - b with b = -(w*x)
-            if (pass + 1 < 2 * C) fetch(pass + 1);
+                for (int q = 0; q < 8; q++) {
+                    const float xa = (float)(int)sw[mA[q]] * (float)(1.0f / 32768.0f), xb = (float)(int)sw[mB[q]] * (float)(1.0f / 32768.0f);   // PcmToFloat, hca.cpp:2470-2479
+                    const float pa = wA[q] * xa, pb = wB[q] * xb;
+                    in[q] = pa + pb;                           // a - b with b = -(w*x)
+                }
+            }
             f2 z[4];
             {
                 const float4 s7 = *(const float4*)(T.esin + 7 * 64 + 4 * l16), c7 = *(const float4*)(T.ecos + 7 * 64 + 4 * l16);
@@ -319,7 +350,10 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             }
             float* out = L.sp + (c * 8 + sf) * 128;
 #pragma unroll
+            ENC_MARK(12);
+#pragma unroll
             for (int r = 0; r < 4; r++) { const f2 o = z[r] * f2{0.125f, 0.125f}; out[opos[2 * r]] = o.x; out[opos[2 * r + 1]] = o.y; }
+            ENC_MARK(13);
         }
         wave_lds_sync();
     }
@@ -590,7 +624,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
 // LDS of one frame (wave): spectra, MDCT work buffers / frame image, small per-channel arrays
 size_t hca_encode_lds_per_wave(uint32_t C, uint32_t frame_size) {
     size_t nwords = (frame_size + 3) / 4 + 1;
-    if (nwords < 256) nwords = 256;
+    if (nwords < 320) nwords = 320;                         // also the 640-sample PCM staging buffer of the MDCT
     const size_t n = (size_t)C * 1024 * 4 + nwords * 4 + C * 8 * 4 + 8 * 4 + C * 8 * 4 + C * 4 * 2 + C * 128 * 2 + C * 8 + 64;
     return (n + 15) & ~(size_t)15;
 }
