@@ -13,6 +13,7 @@
 // same order (sequential sums stay sequential, on one lane); bit allocation is integer work reduced across the wave;
 // the bitstream is assembled with a wave prefix sum over code lengths and LDS atomic ORs.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "cri_kernels.h"
 #include "cri_device.h"
 #include "../../include/cricodecs_hip.h"
@@ -24,10 +25,12 @@ namespace cri {
 
 // Developer instrumentation (-DCRI_ENC_PROFILE through CRI_HIPCC_EXTRA): cycles per phase of k_hca_encode, summed over frames
 #ifdef CRI_ENC_PROFILE
-__device__ unsigned long long g_enc_prof[16];
-#define ENC_MARK(k) do { if (lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_enc_prof[k], t_ - prof_t); prof_t = t_; } } while (0)
+__device__ unsigned long long g_enc_prof[1024][16];      // spread over 1024 slots so the atomics do not serialise on one address
+#define ENC_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
+#define ENC_PROF_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_enc_prof[g & 1023][k_], prof_acc[k_]); } while (0)
 #else
 #define ENC_MARK(k) do {} while (0)
+#define ENC_PROF_FLUSH() do {} while (0)
 #endif
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -138,6 +141,24 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const EncLds&
     wave_lds_sync();
 }
 
+// bits of the 8 spectra of one band at one resolution (the inner part of CalculateUsedBits, hca.cpp:2771-2786)
+__device__ __forceinline__ int enc_band_bits(const EncTab& T, const float x[8], int res) {
+    int part = 0;
+    if (res >= 8) {
+        const int bits = enc_maxbits(res) - 1;
+        const float dz = T.dead[res];
+#pragma unroll
+        for (int j = 0; j < 8; j++) part += bits + (fabsf(x[j]) >= dz ? 1 : 0);
+    } else {
+        const float inv = T.inv[res], up = inv + 1;
+        const int down = (int)((double)inv + 0.5 - 8);
+        const uint8_t* row = T.clen + res * 16;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int q = (int)(x[j] * inv + up) - down; part += row[q & 15]; }
+    }
+    return part;
+}
+
 // CalculateUsedBits, hca.cpp:2763-2790 (integer; reduced across the wave)
 __device__ __forceinline__ int enc_used_bits(const EncFmt& F, const EncLds& L, const EncTab& T, uint32_t lane, int noise_level, int eval_boundary) {
     int part = 0;
@@ -174,6 +195,8 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 }
 
 #define ENC_WAVES 4     // most frames (waves) per workgroup; they share the LDS tables and are otherwise independent
+// CT = 1 or 2: channel count known at compile time, the rate loop keeps the lane's bands in registers; CT = 0: any count
+template <int CT>
 __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     const EncTab T = enc_tables_to_lds(smem_all, threadIdx.x, blockDim.x, a.crc_mul);
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     F.C = Fp->channels; F.frame_size = Fp->frame_size; F.total = Fp->total_bands; F.base = Fp->base_bands; F.stereo = Fp->stereo_bands;
     F.groups = Fp->hfr_group_count; F.bpg = Fp->bands_per_hfr_group; F.hfr_band_count = Fp->hfr_band_count;
     { uint32_t t = 0; for (uint32_t c = 0; c < 16; c++) t |= (uint32_t)(Fp->type[c] & 3) << (2 * c); F.types = t; }
-    const uint32_t C = F.C, lane = threadIdx.x & 63, g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t C = CT ? (uint32_t)CT : F.C, lane = threadIdx.x & 63, g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= a.frames) return;
     const uint32_t nwords = (F.frame_size + 3) / 4 + 1;
     EncLds L;
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     };
 
 #ifdef CRI_ENC_PROFILE
-    unsigned long long prof_t = __builtin_readcyclecounter();
+    unsigned long long prof_acc[16] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553 (window + fold), 2481-2527 (DCT-IV), in registers.
     // Four transforms at a time: slot = lane >> 4 picks the transform, its 16 lanes hold the 64 complex points of the
@@ -469,7 +492,37 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
 
     ENC_MARK(2);
     // ---- rate loop: CalculateNoiseLevel, CalculateEvaluationBoundary (hca.cpp:2792-2866)
+    // With a compile-time channel count the lane's bands (i = lane, lane + 64 of every channel) sit in registers: their 8
+    // scaled spectra, scalefactor and "is coded" flag.
+    constexpr int NB = CT > 0 ? 2 * CT : 1;
+    float xr[NB][8]; int sfr[NB]; bool inr[NB];
+    auto load_bands = [&]() {
+        if constexpr (CT > 0) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const uint32_t c = b >> 1, i = lane + 64 * (b & 1);
+                inr[b] = i < F.coded(c);
+                sfr[b] = L.sfac[c * 128 + i];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xr[b][j] = L.sc[(c * 8 + j) * 128 + i];
+            }
+        }
+    };
+    auto header_bits = [&]() { int h = 16 + 16 + 16; for (uint32_t c = 0; c < C; c++) h += L.hbits[c]; return h; };
+    auto used_bits = [&](int noise, int eb) -> int {
+        if constexpr (CT > 0) {
+            int part = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int i = (int)lane + 64 * (b & 1);
+                const int bits = enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], i < eb ? noise - 1 : noise));
+                part += inr[b] ? bits : 0;
+            }
+            return header_bits() + wave_sum(part);
+        } else return enc_used_bits(F, L, T, lane, noise, eb);
+    };
     enc_header_length(F, L, lane);
+    load_bands();
     const int avail = (int)F.frame_size * 8;
     int noise_level = -1, eval_boundary = 0, status = 0;
     {
@@ -478,7 +531,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             int low = 0, high = 255, mid_value = 0;
             while (low != high) {
                 const int mid = (low + high) / 2;
-                mid_value = enc_used_bits(F, L, T, lane, mid, 0);
+                mid_value = used_bits(mid, 0);
                 if (mid_value > avail) low = mid + 1; else high = mid;
             }
             noise_level = (low == 255 && mid_value > avail) ? -1 : low;
@@ -489,19 +542,38 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             if (lane < C) { L.sfac[lane * 128 + highest + 1] = 0; L.sfac[lane * 128 + highest + 2] = 0; }
             wave_lds_sync();
             enc_header_length(F, L, lane);
+            load_bands();
         }
     }
     ENC_MARK(3);
     if (status == 0 && noise_level != 0) {
+        // only two resolutions per band occur in this search (noise_level and noise_level - 1): cost them once
+        int costA[NB], costB[NB];
+        if constexpr (CT > 0) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                costA[b] = inr[b] ? enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], noise_level)) : 0;
+                costB[b] = inr[b] ? enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], noise_level - 1)) : 0;
+            }
+        }
+        const int hb = header_bits();
+        auto bits_at = [&](int eb) -> int {
+            if constexpr (CT > 0) {
+                int part = 0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) part += ((int)lane + 64 * (b & 1)) < eb ? costB[b] : costA[b];
+                return hb + wave_sum(part);
+            } else return enc_used_bits(F, L, T, lane, noise_level, eb);
+        };
         int low = 0, high = 127;
         while ((high - low > 1) || (low - high > 1)) {
             const int mid = (low + high) / 2;
-            const int v = enc_used_bits(F, L, T, lane, noise_level, mid);
+            const int v = bits_at(mid);
             if (avail < v) high = mid - 1; else low = mid;
         }
         int level;
         if (low == high) level = low < 127 ? low : -1;
-        else level = enc_used_bits(F, L, T, lane, noise_level, high) > avail ? low : high;
+        else level = bits_at(high) > avail ? low : high;
         if (level < 0) status = CRI_ERR_HCA_ENCODE; else eval_boundary = level;
     }
     ENC_MARK(4);
@@ -619,6 +691,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     for (uint32_t i = lane; 4 * i + 4 <= F.frame_size; i += 64) { const uint32_t w = __builtin_bswap32(L.words[i]); __builtin_memcpy(dst + 4 * i, &w, 4); }
     if (lane < (F.frame_size & 3)) { const uint32_t i = (F.frame_size & ~3u) + lane; dst[i] = (uint8_t)(L.words[i >> 2] >> (24 - 8 * (i & 3))); }
     ENC_MARK(7);
+    ENC_PROF_FLUSH();
 }
 
 // LDS of one frame (wave): spectra, MDCT work buffers / frame image, small per-channel arrays
@@ -645,15 +718,23 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
     b.lds_per_wave = (uint32_t)hca_encode_lds_per_wave(a.channels, a.frame_size);
     const uint32_t w = hca_encode_waves(a.channels, a.frame_size);
     if (!w) return;
-    hipLaunchKernelGGL(k_hca_encode, dim3((a.frames + w - 1) / w), dim3(64 * w), hca_encode_lds_bytes(a.channels, a.frame_size), s, b);
+    const dim3 grid((a.frames + w - 1) / w), block(64 * w);
+    const size_t lds = hca_encode_lds_bytes(a.channels, a.frame_size);
+    if (a.channels == 1) hipLaunchKernelGGL(k_hca_encode<1>, grid, block, lds, s, b);
+    else if (a.channels == 2) hipLaunchKernelGGL(k_hca_encode<2>, grid, block, lds, s, b);
+    else hipLaunchKernelGGL(k_hca_encode<0>, grid, block, lds, s, b);
 }
 
 }  // namespace cri
 
 #ifdef CRI_ENC_PROFILE
 extern "C" int cri_debug_enc_profile(unsigned long long* out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(cri::g_enc_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cri::g_enc_prof), z, sizeof z) != hipSuccess) return -1; }
+    static unsigned long long h[1024][16];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(cri::g_enc_prof), sizeof h) != hipSuccess) return -1;
+        for (int k = 0; k < 16; k++) { out16[k] = 0; for (int s = 0; s < 1024; s++) out16[k] += h[s][k]; }
+    }
+    if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(cri::g_enc_prof), h, sizeof h) != hipSuccess) return -1; }
     return 0;
 }
 #endif
