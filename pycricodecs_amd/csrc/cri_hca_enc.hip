@@ -44,6 +44,16 @@ __device__ __forceinline__ int wave_excl_scan(int v, uint32_t lane) {
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
     return inc - v;
 }
+// inclusive prefix sum over the 64 lanes with DPP adds: row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast 15 / 31
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // lane 15 of the previous row into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // lane 31 into rows 2, 3
+    return v;
+}
 __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
     uint32_t t = (crc >> 8) ^ b;
     uint32_t tt = (t << 1) ^ (t << 2) ^ ((__builtin_popcount(t) & 1) ? 0x8003u : 0u);
@@ -635,7 +645,45 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         }
     }
     ENC_MARK(5);
-    // spectra: QuantizeSpectra (hca.cpp:2878-2892) + WriteSpectra (2920-2936), bands 2*lane, 2*lane+1 per lane
+    // spectra: QuantizeSpectra (hca.cpp:2878-2892) + WriteSpectra (2920-2936)
+    if constexpr (CT > 0) {
+        // bands lane and lane + 64 of each channel; per-band constants hoisted out of the subframe loop;
+        // one packed DPP scan (two 16-bit sums) places both halves of the spectrum
+        int rb[NB], downb[NB]; float invb[NB], upb[NB]; uint32_t mbb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int i = (int)lane + 64 * (b & 1);
+            rb[b] = inr[b] ? enc_resolution(T, sfr[b], i < eval_boundary ? noise_level - 1 : noise_level) : 0;
+            invb[b] = T.inv[rb[b]]; upb[b] = invb[b] + 1; downb[b] = (int)((double)invb[b] + 0.5);
+            mbb[b] = rb[b] >= 8 ? (uint32_t)enc_maxbits(rb[b]) - 1 : 1u;
+        }
+#pragma unroll 1
+        for (uint32_t sf = 0; sf < 8; sf++) {
+#pragma unroll
+            for (int c = 0; c < CT; c++) {
+                uint32_t code[2], len[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int b = 2 * c + h, r = rb[b];
+                    const int q = (int)(L.sc[(c * 8 + sf) * 128 + lane + 64 * h] * invb[b] + upb[b]) - downb[b];
+                    const uint32_t ti = (uint32_t)r * 16 + ((uint32_t)(q + 8) & 15);
+                    const uint32_t lt = T.clen[ti & 127], ct = T.code[ti & 127];
+                    const uint32_t mag = (uint32_t)(q < 0 ? -q : q) & ((1u << mbb[b]) - 1);
+                    const uint32_t lb = q != 0 ? mbb[b] + 1 : mbb[b], cb = q != 0 ? ((mag << 1) | (q > 0 ? 0u : 1u)) : 0u;
+                    len[h] = r == 0 ? 0u : (r < 8 ? lt : lb);
+                    code[h] = r == 0 ? 0u : (r < 8 ? ct : cb);
+                }
+                const uint32_t v = len[0] | (len[1] << 16);
+                const uint32_t incl = wave_incl_scan_dpp(v), excl = incl - v;
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), tot0 = tot & 0xFFFF;
+                // BitWriter drops writes that do not fit (IO.cpp:131-134); the rate loop guarantees they do
+                put_bits(L.words, pos + (excl & 0xFFFF), code[0], len[0]);
+                put_bits(L.words, pos + tot0 + (excl >> 16), code[1], len[1]);
+                pos += tot0 + (tot >> 16);
+            }
+        }
+    } else {
+    // bands 2*lane, 2*lane+1 per lane
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t coded = F.coded(c);
@@ -661,6 +709,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             put_bits(L.words, pos + off + len[0], code[1], len[1]);
             pos += (uint32_t)wave_sum((int)(len[0] + len[1]));
         }
+    }
     }
     wave_lds_sync();
 
