@@ -33,10 +33,9 @@ __device__ unsigned long long g_enc_prof[1024][16];      // spread over 1024 slo
 #define ENC_PROF_FLUSH() do {} while (0)
 #endif
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v);
+__device__ __forceinline__ int wave_sum(int v) {          // total of the 64 lanes, wave-uniform (SGPR)
+    return __builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)v), 63);
 }
 __device__ __forceinline__ int wave_excl_scan(int v, uint32_t lane) {
     int inc = v;
@@ -64,28 +63,42 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
 struct EncTab {
     const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64] [8][64] [64] [64] [16] [16] [16]
     const uint16_t* crcmul;                                                 // [6][16] per launch (HcaEncArgs::crc_mul)
+    const uint8_t* sfbase;                                                  // [32] entries of deq[0..62] that are <= 2^(j - 25)
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
 };
-#define ENC_TAB_BYTES (512 + 2048 + 2048 + 256 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192)
+#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32)
 __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads, const uint16_t* crc_mul) {
-    float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 64;
+    float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 72;
     float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
     uint8_t* curve = (uint8_t*)(ib + 16); uint8_t* clen = curve + 64; uint8_t* code = clen + 128; uint8_t* shuf = code + 128;
     uint16_t* cm = (uint16_t*)(shuf + 128);
+    uint8_t* sfb = (uint8_t*)(cm + 96);
     for (uint32_t i = tid; i < 96; i += nthreads) cm[i] = crc_mul[i];
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
-    for (uint32_t i = tid; i < 64; i += nthreads) { deq[i] = HCA_DEQ_SCALE[i]; escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
+    for (uint32_t i = tid; i < 64; i += nthreads) { escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
+    for (uint32_t i = tid; i < 72; i += nthreads) deq[i] = i < 63 ? HCA_DEQ_SCALE[i] : __uint_as_float(0x7FC00000u);   // NaN padding never compares <=
+    for (uint32_t j = tid; j < 32; j += nthreads) {
+        const float thr = __uint_as_float((j + 102u) << 23);   // 2^(j - 25)
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < 63; k++) n += HCA_DEQ_SCALE[k] <= thr ? 1u : 0u;
+        sfb[j] = (uint8_t)n;
+    }
     for (uint32_t i = tid; i < 16; i += nthreads) { dead[i] = HCA_ENC_DEAD_ZONE[i]; inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f; }
     EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
-    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm;
+    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb;
     return T;
 }
 
-__device__ __forceinline__ int enc_find_scalefactor(const EncTab& T, float v) {   // hca.cpp:2611-2623
-    uint32_t low = 0, high = 63;
-    while (low < high) { uint32_t mid = (low + high) / 2; if (T.deq[mid] <= v) low = mid + 1; else high = mid; }
-    return (int)low;
+// hca.cpp:2611-2623: the binary search over the ascending table returns the number of entries 0..62 that are <= v.  The
+// table has 128/53 = 2.4 entries per octave, so that count is sfbase[exponent of v] (entries <= 2^exponent, built exactly
+// at table-load time) plus at most three more compares -- two dependent LDS reads instead of six.
+__device__ __forceinline__ int enc_find_scalefactor(const EncTab& T, float v) {
+    int eb = (int)(__float_as_uint(v) >> 23) & 0xFF;
+    eb = eb < 102 ? 102 : (eb > 133 ? 133 : eb);            // the table spans 2^-23 .. 2^3.5
+    const int base = T.sfbase[eb - 102];
+    const float e0 = T.deq[base], e1 = T.deq[base + 1], e2 = T.deq[base + 2];   // deq[] is padded past 63 with +inf
+    return base + (e0 <= v ? 1 : 0) + (e1 <= v ? 1 : 0) + (e2 <= v ? 1 : 0);
 }
 __device__ __forceinline__ int enc_resolution(const EncTab& T, int sf, int noise) {   // hca.cpp:2752-2761
     int cp = noise - 5 * sf / 2 + 2;
