@@ -27,7 +27,7 @@ namespace cri {
 // k_hca_prepare
 // ------------------------------------------------------------------------------------------------------------
 size_t hca_prepare_lds_bytes(uint32_t chunk_rows, uint32_t n_cipher) {
-    return (size_t)chunk_rows * 256 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256 + 16;
+    return (size_t)chunk_rows * 260 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256 + 16;
 }
 
 // CRC-16 (poly 0x8005, MSB first) byte step without a table: T[t] = t*x^16 mod P = parity(t)*0x8003 ^ (t<<1) ^ (t<<2)
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
     const uint32_t R = a.rows, RC = a.prep_chunk_rows, lane = threadIdx.x, tile = blockIdx.x;
     const int fs = (int)F.frame_size;
     uint32_t* rows = (uint32_t*)smem;
-    uint8_t* cipher_lds = smem + (size_t)RC * 256;
+    uint8_t* cipher_lds = smem + (size_t)RC * 260;       // rows are 65 words apart: lane-strided and row-strided accesses both spread over the banks
     const bool cipher_in_lds = a.n_cipher <= 16;
     if (cipher_in_lds) for (uint32_t i = lane; i < a.n_cipher * 256; i += 64) cipher_lds[i] = a.cipher_tables[i];
 
@@ -81,24 +81,37 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
     wave_lds_sync();
     for (uint32_t r0 = 0; r0 < R; r0 += RC) {
         const uint32_t nr = R - r0 < RC ? R - r0 : RC;
-        // coalesced staging: 256 contiguous bytes of one frame per wave load
-        for (uint32_t fr = 0; fr < 64; fr++) {
-            const bool fv = __builtin_amdgcn_readlane((int)valid, fr) != 0;
-            const uint8_t* p = (const uint8_t*)readlane64((uint64_t)src, fr);
-            for (uint32_t r = lane; r < nr; r += 64) {
-                const uint32_t rr = r0 + r;
-                uint32_t v = 0;
-                if (fv) {
-                    if ((int)(4 * rr + 4) <= fs) v = ld_u32_unaligned(p + 4 * rr);
-                    else for (int k = 0; 4 * (int)rr + k < fs; k++) v |= (uint32_t)p[4 * rr + k] << (8 * k);
+        // coalesced staging: 256 contiguous bytes of one frame per wave load, 16 frames' loads in flight at a time
+        // (one load + one LDS write per frame in sequence made this kernel pay the HBM latency 64 times per chunk)
+        {
+            const uint32_t rr = r0 + lane;                                  // this lane's word of every frame (nr <= 64)
+            const bool whole = lane < nr && (int)(4 * rr + 4) <= fs, part = lane < nr && !whole && (int)(4 * rr) < fs;
+#pragma unroll 1
+            for (uint32_t fb = 0; fb < 64; fb += 16) {
+                uint32_t v[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                    const bool fv = __builtin_amdgcn_readlane((int)valid, fb + k) != 0;
+                    const uint8_t* p = (const uint8_t*)readlane64((uint64_t)src, fb + k);
+                    const uint32_t w = ld_u32_unaligned(p + 4 * (whole ? rr : 0u));     // always a readable address (frame 0 of the group for padding lanes)
+                    v[k] = fv && whole ? w : 0u;
                 }
-                rows[r * 64 + fr] = v;
+                if (__any(part)) {                                          // the last, partial word of a frame (frame_size % 4 != 0)
+#pragma unroll 1
+                    for (uint32_t k = 0; k < 16; k++) {
+                        const bool fv = __builtin_amdgcn_readlane((int)valid, fb + k) != 0;
+                        const uint8_t* p = (const uint8_t*)readlane64((uint64_t)src, fb + k);
+                        if (fv && part) { uint32_t t = 0; for (int q = 0; 4 * (int)rr + q < fs; q++) t |= (uint32_t)p[4 * rr + q] << (8 * q); v[k] = t; }
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) if (lane < nr) rows[lane * 65 + fb + k] = v[k];
             }
         }
         wave_lds_sync();
         if (valid) {
             for (uint32_t r = 0; r < nr; r++) {
-                const uint32_t raw = rows[r * 64 + lane];
+                const uint32_t raw = rows[r * 65 + lane];
                 uint32_t be = 0;
                 int nb = fs - 4 * (int)(r0 + r); nb = nb > 4 ? 4 : nb;
                 if (r0 + r == 0 && (raw & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4);   // hca.cpp:1162-1164
@@ -111,11 +124,11 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
                         be |= d << (24 - 8 * k);
                     }
                 }
-                rows[r * 64 + lane] = be;
+                rows[r * 65 + lane] = be;
             }
         }
         wave_lds_sync();
-        for (uint32_t r = 0; r < nr; r++) tb[(uint64_t)(r0 + r) * 64 + lane] = rows[r * 64 + lane];
+        for (uint32_t r = 0; r < nr; r++) tb[(uint64_t)(r0 + r) * 64 + lane] = rows[r * 65 + lane];
         wave_lds_sync();
     }
     tb[(uint64_t)R * 64 + lane] = 0;
