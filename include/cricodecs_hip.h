@@ -38,6 +38,9 @@ extern "C" {
 #define CRI_ERR_NOMEM (-302)
 #define CRI_ERR_HIP (-303)
 #define CRI_ERR_UNSUPPORTED (-304)
+#define CRI_ERR_AWB_HEADER (-401)   /* awb.py:37-38 "Invalid AWB header." */
+#define CRI_ERR_AWB_INTSIZE (-402)  /* awb.py:95-106 "Unknown int size." */
+#define CRI_ITEM_SKIPPED 1          /* per-item status of a job that was told to leave the item to another job */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Single-file entry points, host buffers in / host buffers out (malloc'ed; release with cri_free).
@@ -102,6 +105,18 @@ int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint
 int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** job);
 int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
                               const cri_adx_encode_params* params /* one for all items */, cri_job** job);
+
+/* AFS2 / AWB wave bank as the batch descriptor (replaces the per-file loop of PyCriCodecs/awb.py:54-88, AWB.extract /
+ * AWB.getfiles, and its header parse awb.py:32-52).  cri_awb_index is host-only: with offsets == NULL it returns the item
+ * count; otherwise offsets[n+1] (already aligned and clipped to len) and kinds[n].  cri_job_create_awb_decode builds one
+ * HCA decode job (key mixed with the bank's subkey, awb.py:72) and one ADX decode job over the SAME blob: upload the
+ * bank once, run both jobs (items of the other kind carry status CRI_ITEM_SKIPPED and produce no output). */
+#define CRI_AWB_OTHER 0
+#define CRI_AWB_HCA 1
+#define CRI_AWB_ADX 2
+int cri_awb_index(const uint8_t* awb, size_t len, uint32_t* n_items, uint32_t* align, uint16_t* subkey, uint32_t* header_size,
+                  uint64_t* offsets, uint8_t* kinds, uint32_t cap);
+int cri_job_create_awb_decode(const uint8_t* awb, size_t len, uint64_t key, cri_job** hca_job, cri_job** adx_job);
 int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
                               uint32_t force_no_looping, uint32_t quality, cri_job** job);
 int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,

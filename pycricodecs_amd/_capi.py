@@ -20,7 +20,7 @@ SYMBOLS = [
     "cri_job_create_hca_encode", "cri_job_create_hca_crypt", "cri_job_kind", "cri_job_items", "cri_job_input_bytes",
     "cri_job_output_bytes", "cri_job_output_offsets", "cri_job_host_status", "cri_job_scratch_bytes", "cri_job_units",
     "cri_job_units2", "cri_job_algorithmic_bytes", "cri_job_run", "cri_job_dominant_kernel", "cri_job_destroy", "cri_job_run_host", "cri_job_enable_events",
-    "cri_job_event_ms",
+    "cri_job_event_ms", "cri_awb_index", "cri_job_create_awb_decode",
 ]
 
 
@@ -73,6 +73,8 @@ def lib():
     L.cri_job_enable_events.argtypes = [vp, C.c_int]
     L.cri_job_event_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int]
     L.cri_job_destroy.argtypes = [vp]
+    L.cri_awb_index.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), u64p, u8p, C.c_uint32]
+    L.cri_job_create_awb_decode.argtypes = [vp, C.c_size_t, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.cri_job_destroy.restype = None
     _lib = L
     return L

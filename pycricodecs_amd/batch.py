@@ -68,6 +68,18 @@ class Job:
         return cls._finish(rc, h, blob, offs)
 
     @classmethod
+    def awb_decode(cls, awb, key=0):
+        """(HCA decode job, ADX decode job) over one AFS2 / AWB bank: both read the SAME blob (upload it once, e.g. with
+        hca_job.alloc(); pass that d_in to both run() calls).  Items of the other kind have status CRI_ITEM_SKIPPED (1)."""
+        from .awb import awb_index
+        offs, _kinds, _subkey = awb_index(awb)
+        hh, ha = C.c_void_p(), C.c_void_p()
+        rc = _capi.lib().cri_job_create_awb_decode(bytes(awb) if not isinstance(awb, bytes) else awb, len(awb), key & 0xFFFFFFFFFFFFFFFF, C.byref(hh), C.byref(ha))
+        if rc:
+            _capi.raise_for(rc)
+        return cls(hh, awb, offs), cls(ha, awb, offs)
+
+    @classmethod
     def adx_decode(cls, items):
         blob, offs, buf = cls._blob_args(items)
         h = C.c_void_p()

@@ -144,6 +144,9 @@ extern "C" const char* cri_strerror(int code) {
         case CRI_ERR_NOMEM: return "Out of memory.";
         case CRI_ERR_HIP: return "HIP runtime error or no gfx950 device available (this library has no CPU fallback).";
         case CRI_ERR_UNSUPPORTED: return "Input is valid for the reference but not yet supported by the device path.";
+        case CRI_ERR_AWB_HEADER: return "Invalid AWB header.";                     // awb.py:38
+        case CRI_ERR_AWB_INTSIZE: return "Unknown int size.";                      // awb.py:106
+        case CRI_ITEM_SKIPPED: return "Item is not handled by this job.";
     }
     if (code <= -211 && code >= -216) return "Decoding error, either an incorrect key or an unknown exception.";
     return "Unknown error.";
@@ -175,7 +178,7 @@ static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
 
 // ------------------------------------------------------------------------------------------------ HCA decode
 static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const uint64_t* keys, const uint16_t* subkeys,
-                             const uint32_t* header_sizes, cri_job** out) {
+                             const uint32_t* header_sizes, cri_job** out, const uint8_t* take = nullptr, uint8_t take_kind = 0) {
     if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_HCA_DECODE, offsets, n);
@@ -189,6 +192,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
+        if (take && take[i] != take_kind) { j->host_status[i] = CRI_ITEM_SKIPPED; continue; }
         const uint8_t* d = blob + offsets[i];
         size_t len = (size_t)(offsets[i + 1] - offsets[i]);
         HcaHeader h;
@@ -320,7 +324,7 @@ static void adx_lds_plan(AdxArgs& a, uint32_t max_bs, uint32_t max_spb, bool enc
 }
 
 // ------------------------------------------------------------------------------------------------ ADX decode
-extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out) {
+static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out, const uint8_t* take = nullptr, uint8_t take_kind = 0) {
     if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_ADX_DECODE, offsets, n);
@@ -331,6 +335,7 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
+        if (take && take[i] != take_kind) { j->host_status[i] = CRI_ITEM_SKIPPED; continue; }
         const uint8_t* d = blob + offsets[i];
         size_t len = (size_t)(offsets[i + 1] - offsets[i]);
         AdxHeader h;
@@ -372,6 +377,68 @@ extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* of
         (rc = j->upload_images())) { delete j; return rc; }
     *out = j;
     return 0;
+}
+
+extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out) {
+    return create_adx_decode(blob, offsets, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------ AWB (AFS2) front door
+// Header and offset table as PyCriCodecs/awb.py:32-52 reads them ("<4sBBHIHH": magic, version, offset int size, id int
+// size, file count, alignment, subkey; then ids, then count+1 offsets, each rounded up to the alignment); item ranges as
+// getfiles() yields them (awb.py:83-88): item k = [offset k, offset k+1), the first one starting at the aligned header size.
+extern "C" int cri_awb_index(const uint8_t* awb, size_t len, uint32_t* n_items, uint32_t* align_out, uint16_t* subkey,
+                             uint32_t* header_size, uint64_t* offsets, uint8_t* kinds, uint32_t cap) {
+    if (!awb || !n_items) return CRI_ERR_INVALID_ARG;
+    if (len < 16 || memcmp(awb, "AFS2", 4) != 0) return CRI_ERR_AWB_HEADER;
+    const uint32_t osz = awb[5], isz = le16(awb + 6), n = le32(awb + 8), align = le16(awb + 12);
+    if ((osz != 1 && osz != 2 && osz != 4 && osz != 8) || (isz != 1 && isz != 2 && isz != 4 && isz != 8)) return CRI_ERR_AWB_INTSIZE;
+    if (align == 0) return CRI_ERR_AWB_HEADER;               // the reference divides by it
+    const uint64_t table = 16 + (uint64_t)isz * n, hs0 = table + (uint64_t)osz * ((uint64_t)n + 1);
+    if (hs0 > len) return CRI_ERR_AWB_HEADER;
+    *n_items = n;
+    if (align_out) *align_out = align;
+    if (subkey) *subkey = (uint16_t)le16(awb + 14);
+    uint64_t hs = hs0 % align ? hs0 + (align - hs0 % align) : hs0;
+    if (header_size) *header_size = (uint32_t)hs;
+    if (!offsets) return 0;
+    if (cap < n) return CRI_ERR_INVALID_ARG;
+    uint64_t prev = 0;
+    for (uint32_t k = 0; k <= n; k++) {
+        const uint8_t* p = awb + table + (uint64_t)osz * k;
+        uint64_t o = 0;
+        for (uint32_t b = 0; b < osz; b++) o |= (uint64_t)p[b] << (8 * b);
+        if (o % align) o += align - o % align;
+        if (k == 0) o = hs;                                  // the reader starts at the aligned header size
+        if (o > len) o = len;                                // a short read at the end of the file
+        if (o < prev) return CRI_ERR_AWB_HEADER;
+        offsets[k] = prev = o;
+    }
+    if (kinds) for (uint32_t k = 0; k < n; k++) {
+        const uint8_t* d = awb + offsets[k];
+        const uint64_t l = offsets[k + 1] - offsets[k];
+        kinds[k] = CRI_AWB_OTHER;
+        if (l >= 4 && (be32(d) == 0x48434100u || be32(d) == 0xC8C3C100u)) kinds[k] = CRI_AWB_HCA;   // HCAType.HCA / HCAType.EHCA (awb.py:60)
+        else if (l >= 2 && d[0] == 0x80 && d[1] == 0x00) kinds[k] = CRI_AWB_ADX;
+    }
+    return 0;
+}
+
+extern "C" int cri_job_create_awb_decode(const uint8_t* awb, size_t len, uint64_t key, cri_job** hca_job, cri_job** adx_job) {
+    if (!awb || !hca_job || !adx_job) return CRI_ERR_INVALID_ARG;
+    *hca_job = *adx_job = nullptr;
+    uint32_t n = 0; uint16_t subkey = 0;
+    int rc = cri_awb_index(awb, len, &n, nullptr, &subkey, nullptr, nullptr, nullptr, 0);
+    if (rc) return rc;
+    std::vector<uint64_t> offsets((size_t)n + 1); std::vector<uint8_t> kinds(n ? n : 1);
+    rc = cri_awb_index(awb, len, &n, nullptr, &subkey, nullptr, offsets.data(), kinds.data(), n);
+    if (rc) return rc;
+    std::vector<uint64_t> keys(n ? n : 1, key); std::vector<uint16_t> subkeys(n ? n : 1, subkey);   // awb.py:72: HCA(i, key=key, subkey=self.subkey)
+    rc = create_hca_decode(awb, offsets.data(), n, keys.data(), subkeys.data(), nullptr, hca_job, kinds.data(), CRI_AWB_HCA);
+    if (rc) return rc;
+    rc = create_adx_decode(awb, offsets.data(), n, adx_job, kinds.data(), CRI_AWB_ADX);
+    if (rc) { cri_job_destroy(*hca_job); *hca_job = nullptr; }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ ADX encode

@@ -114,6 +114,41 @@ def main():
         ent["hca_q1_noloop_sha"] = sha(R.hca_encode(w, 1, 1))
         loops.append(ent)
     man["loops"] = loops
+    # AFS2 / AWB bank written by the reference's own AWBBuilder and read back by its AWB class (pure Python; its compiled
+    # extension is only stubbed for the import): header fields, item ranges, and the reference's decode of every item
+    import tempfile
+    import types
+    sys.modules.setdefault("CriCodecs", types.ModuleType("CriCodecs"))
+    sys.path.insert(0, "/root/reference")
+    from PyCriCodecs.awb import AWB as RefAWB, AWBBuilder as RefAWBBuilder
+    subkey = 0x1234
+    clips = []
+    for i, (n, ch, sr, kind) in enumerate([(2016, 2, 48000, "hca"), (1600, 2, 44100, "adx"), (3008, 1, 48000, "hca"), (992, 1, 22050, "adx"),
+                                           (4000, 2, 48000, "hca"), (2400, 2, 32000, "adx")]):
+        w = synth.wav(60 + i, n, ch, sr)
+        cb = R.hca_crypt(R.hca_encode(w, 1 + i % 3), 1, 56, KEY, subkey) if kind == "hca" else R.adx_encode(w)
+        clips.append(cb + b"\0" * (-len(cb) % 0x20))          # AWBBuilder.build_files only places files right when their sizes are aligned
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for i, cbytes in enumerate(clips):
+            pth = os.path.join(td, "%02d.bin" % i)
+            with open(pth, "wb") as f:
+                f.write(cbytes)
+            paths.append(pth)
+        outp = os.path.join(td, "bank.awb")
+        RefAWBBuilder(paths, subkey=subkey, version=2, id_intsize=2, align=0x20).build(outp)
+        bank = open(outp, "rb").read()
+        ref = RefAWB(outp)
+        items = list(ref.getfiles())
+        ref.stream.close()
+    put("bank_mixed.awb", bank)
+    ent = {"file": "bank_mixed.awb", "sha": sha(bank), "numfiles": ref.numfiles, "align": ref.align, "subkey": ref.subkey,
+           "headersize": ref.headersize, "ofs": [int(x) for x in ref.ofs], "items": []}
+    for it in items:
+        is_hca = it[:4] in (b"HCA\x00", b"\xc8\xc3\xc1\x00")
+        ent["items"].append({"len": len(it), "sha": sha(it), "kind": "hca" if is_hca else "adx",
+                             "decoded_sha": sha(R.hca_decode(it, KEY, subkey) if is_hca else R.adx_decode(it))})
+    man["awb"] = ent
     # generator-independent known answers
     man["known"] = {"crc16_123456789": 0xFEE8,
                     "adx_coefs": {"500,48000": [7400, -3342], "500,44100": [7334, -3283], "500,22050": [6569, -2634], "0,48000": [8192, -4096]},

@@ -73,3 +73,30 @@ def test_front_end_header_walk():
         HCA(b"nonsense-bytes-here")
     with pytest.raises(OverflowError):
         HCA(G.load("s0_3008_2_48000_q1.hca"), key=1 << 64)
+
+
+def test_awb_index_matches_reference_reader():
+    """cri_awb_index (host only) against what the reference's AWB class read from a bank its AWBBuilder wrote
+    (tests/golden/make_golden.py): header fields, aligned offsets, item bytes; the oracle decodes every item to the
+    reference's digest (HCA items with the bank's subkey mixed into the key, awb.py:72)."""
+    import golden_util as G
+    import oracle_lib as O
+    from pycricodecs_amd import awb
+    a = G.manifest()["awb"]
+    bank = G.load(a["file"])
+    assert G.sha(bank) == a["sha"]
+    offs, kinds, subkey = awb.awb_index(bank)
+    assert [int(x) for x in offs] == a["ofs"] and subkey == a["subkey"]
+    assert [{1: "hca", 2: "adx"}[int(k)] for k in kinds] == [i["kind"] for i in a["items"]]
+    for k, it in enumerate(a["items"]):
+        item = bank[int(offs[k]):int(offs[k + 1])]
+        assert len(item) == it["len"] and G.sha(item) == it["sha"]
+        dec = O.hca_decode(item, G.KEY, subkey) if it["kind"] == "hca" else O.adx_decode(item)
+        assert G.sha(dec) == it["decoded_sha"]
+    with pytest.raises(ValueError):
+        awb.awb_index(b"AFS3" + bank[4:])
+    with pytest.raises(ValueError):
+        awb.awb_index(bank[:5] + b"\x03" + bank[6:])          # offset int size 3: "Unknown int size."
+    with pytest.raises(ValueError):
+        awb.awb_index(bank[:40])
+

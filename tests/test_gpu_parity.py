@@ -354,6 +354,56 @@ def test_batch_adx_roundtrip(cc):
         assert diff(p, O.adx_decode(a)) is None
 
 
+def test_awb_front_door(cc, tmp_path):
+    """AFS2 bank -> one HCA decode job + one ADX decode job over the same blob; digests of the reference's per-item decode."""
+    from pycricodecs_amd import awb
+    a = MAN["awb"]
+    bank = G.load(a["file"])
+    b = awb.AWB(bank)
+    assert (b.numfiles, b.align, b.subkey, b.headersize, b.ofs) == (a["numfiles"], a["align"], a["subkey"], a["headersize"], a["ofs"])
+    assert [G.sha(x) for x in b.getfiles()] == [i["sha"] for i in a["items"]]
+    wavs = b.decode_all(KEY)
+    assert [G.sha(w) for w in wavs] == [i["decoded_sha"] for i in a["items"]]
+    with pytest.raises(ValueError):
+        b.decode_all(KEY + 1)                                  # wrong key: the HCA items fail their frame checks
+    # extract() writes the reference's file names
+    p = tmp_path / "sfx.awb"
+    p.write_bytes(bank)
+    awb.AWB(str(p)).extract(decode=True, key=KEY)
+    names = sorted(x.name for x in tmp_path.iterdir())
+    assert names == sorted(["sfx.awb"] + ["sfx_%d.%s" % (k, "wav" if i["kind"] == "hca" else "dat") for k, i in enumerate(a["items"])])
+    assert G.sha((tmp_path / "sfx_0.wav").read_bytes()) == a["items"][0]["decoded_sha"]
+
+
+def test_awb_large_mixed_bank(cc):
+    """A few hundred short clips of both codecs (the game-SFX shape of BASELINE configs[4]) against the oracle."""
+    import struct
+    from pycricodecs_amd import awb
+    rng = np.random.default_rng(5)
+    clips, kinds = [], []
+    for i in range(120):
+        n = int(rng.integers(2, 40)) * 160
+        ch = 1 + int(rng.integers(0, 2))
+        w = synth.wav(300 + i % 17, n, ch, 48000)
+        if i % 2:
+            clips.append(O.adx_encode(w)); kinds.append("adx")
+        else:
+            clips.append(O.hca_crypt(O.hca_encode(w, quality=1 + i % 3), 1, 56, KEY, 0x77)); kinds.append("hca")
+    align, n = 0x20, len(clips)
+    hs0 = 16 + 2 * n + 4 * (n + 1)
+    hs = hs0 + (-hs0 % align)
+    offs, pos, body = [hs0], hs, b""
+    for cb in clips:
+        cb = cb + b"\0" * (-len(cb) % align)
+        body += cb; pos += len(cb); offs.append(pos)
+    head = struct.pack("<4sBBHIHH", b"AFS2", 2, 4, 2, n, align, 0x77) + b"".join(struct.pack("<H", i) for i in range(n)) + b"".join(struct.pack("<I", o) for o in offs)
+    bank = head.ljust(hs, b"\0") + body
+    wavs = awb.AWB(bank).decode_all(KEY)
+    for cb, kind, wv in zip(clips, kinds, wavs):
+        ref = O.hca_decode(cb, KEY, 0x77) if kind == "hca" else O.adx_decode(cb)
+        assert diff(wv, ref) is None
+
+
 def test_drop_in_extension_module(cc):
     """The CPython module `CriCodecs` built from csrc/pyext gives the same bytes as the ctypes binding."""
     import importlib.util
