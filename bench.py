@@ -136,6 +136,57 @@ def secondary_measurements(args, dev, rank):
     return res
 
 
+def awb_mixed_measurement(args, dev, rank):
+    """BASELINE configs[4] shape at one GPU's share: an AFS2 bank of short clips (log-uniform 0.05-2 s, half ADX bs18/bd4,
+    half encrypted HCA), decoded by the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM."""
+    import struct
+    import numpy as np
+    import torch
+    import oracle_lib as O
+    from pycricodecs_amd import synth
+    from pycricodecs_amd.batch import Job
+    n, subkey, align = args.awb_clips, 0x2468, 0x20
+    rng = np.random.default_rng(77 + rank)
+    durs = np.exp(rng.uniform(np.log(0.05), np.log(2.0), 24))
+    uniq = []
+    for u, d in enumerate(durs):
+        w = synth.wav(7000 + u, max(32, int(48000 * d) // 32 * 32), 2, 48000)
+        uniq.append(("hca", O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, subkey)))
+        uniq.append(("adx", O.adx_encode(w)))
+    order = rng.integers(0, len(uniq), n)
+    hs0 = 16 + 2 * n + 4 * (n + 1)
+    hs = hs0 + (-hs0 % align)
+    offs, pos, parts = [hs0], hs, []
+    for i in order:
+        cb = uniq[i][1]
+        cb = cb + b"\0" * (-len(cb) % align)
+        parts.append(cb); pos += len(cb); offs.append(pos)
+    head = struct.pack("<4sBBHIHH", b"AFS2", 2, 4, 2, n, align, subkey) + np.arange(n, dtype="<u2").tobytes() + np.array(offs, dtype="<u4").tobytes()
+    bank = head.ljust(hs, b"\0") + b"".join(parts)
+    hj, aj = Job.awb_decode(bank, KEY)
+    d_in, ho, hscr, hst = hj.alloc(dev)
+    _, ao, ascr, ast = aj.alloc(dev, upload=False)
+    for _ in range(2):
+        hj.run(d_in, ho, hscr, hst); aj.run(d_in, ao, ascr, ast)
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        hj.run(d_in, ho, hscr, hst); aj.run(d_in, ao, ascr, ast)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert int((hst < 0).sum().item()) == 0 and int((ast < 0).sum().item()) == 0
+    k_h = next(i for i in range(n) if uniq[order[i]][0] == "hca"); k_a = next(i for i in range(n) if uniq[order[i]][0] == "adx")
+    ref = O.hca_decode(uniq[order[k_h]][1], KEY, subkey)
+    assert bytes(ho[int(hj.output_offsets[k_h]):int(hj.output_offsets[k_h]) + len(ref)].cpu().numpy()) == ref, "AWB HCA item differs from the oracle"
+    ref = O.adx_decode(uniq[order[k_a]][1])
+    assert bytes(ao[int(aj.output_offsets[k_a]):int(aj.output_offsets[k_a]) + len(ref)].cpu().numpy()) == ref, "AWB ADX item differs from the oracle"
+    return {"workload": "AFS2 bank of %d clips (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV" % n,
+            "bank_bytes": len(bank), "pcm_bytes": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
+            "hca_frames": int(hj.units), "adx_frames": int(aj.units), "frames_per_s": round((hj.units + aj.units) / dt, 1),
+            "clips_per_s": round(n / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +199,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--secondary-streams", type=int, default=1000)
+    ap.add_argument("--awb-clips", type=int, default=12500, help="clips of the mixed AWB secondary figure (100 000 / 8 GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -254,6 +306,8 @@ def main():
         del d_in, d_out, d_scratch, d_status
         torch.cuda.empty_cache()
         out["secondary"] = secondary_measurements(args, dev, rank)
+        torch.cuda.empty_cache()
+        out["secondary"]["awb_mixed_decode"] = awb_mixed_measurement(args, dev, rank)
     if rank == 0 and not args.no_cpu:
         if args.workload == "hca_decode":
             out["cpu_baseline"] = cpu_baseline_hca_decode(items[0])
