@@ -7,5 +7,5 @@ cd $GRAFT_REPO_ROOT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
 tail -2 $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --no-cpu > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python bench.py --no-cpu --no-secondary > $OUT/trace.log 2>&1   # headline workload only, so per-kernel averages are those of the bench line
 find $OUT/trace -name "*kernel_stats.csv" -exec head -8 {} \;
