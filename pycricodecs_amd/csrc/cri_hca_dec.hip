@@ -314,15 +314,27 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             feed_checkpoint(fd, bb);
             uint32_t sfw[4] = {0, 0, 0, 0};
             uint32_t mw[4] = {0, 0, 0, 0};
+            // far from the frame end (always, in a well-formed frame) the reader's end-of-frame rules cannot apply
+            const bool sf_fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
             if (blk * 16 < cs) {
 #pragma unroll
                 for (uint32_t k = 0; k < 16; k++) {               // hca.cpp:1310-1350, all lanes in lock step
                     const uint32_t i = blk * 16 + k;
                     const bool in = i < cs;
                     const bool direct = db >= 6 || i == 0;
-                    const uint32_t x = bb_read(bb, ring, (!in || db == 0) ? 0 : (direct ? 6 : (int)db));
-                    const bool esc = in && !direct && db > 0 && x == expected;
-                    const uint32_t y = bb_read(bb, ring, esc ? 6 : 0);
+                    uint32_t x, y; bool esc;
+                    if (sf_fast) {                                // delta and its possible 6-bit escape value in one peek
+                        const bool none = !in || db == 0;
+                        bb_refill(bb, ring);
+                        const uint32_t both = bb_peek<false>(bb, none ? 0 : (direct ? 6 : (int)db + 6));
+                        x = direct ? both : (both >> 6); y = both & 63;
+                        esc = in && !direct && db > 0 && x == expected;
+                        bb_skip(bb, none ? 0 : (direct ? 6 : (esc ? (int)db + 6 : (int)db)));
+                    } else {
+                        x = bb_read(bb, ring, (!in || db == 0) ? 0 : (direct ? 6 : (int)db));
+                        esc = in && !direct && db > 0 && x == expected;
+                        y = bb_read(bb, ring, esc ? 6 : 0);
+                    }
                     const int t = (int)value + ((int)x - (int)(expected >> 1));
                     if (in && db > 0 && !direct && !esc && (t < 0 || t >= 64) && status == 0) status = CRI_ERR_HCA_FRAME(5);
                     uint32_t v = direct ? x : (esc ? y : ((value - (expected >> 1) + x) & 0x3F));
