@@ -31,9 +31,18 @@ template <int X> __device__ __forceinline__ float lane16_xor(float v) {
     const int i = __float_as_int(v);
     if (X == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     if (X == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+#ifdef CRI_XOR8_SWIZZLE
+    if (X == 8) return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x201F));
+#endif
     if (X == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x128, 0xF, 0xF, true));   // row_ror:8
+#ifdef CRI_XOR4_DPP
     const int t = __builtin_amdgcn_update_dpp(0, i, 0x104, 0xF, 0xF, true);                        // row_shl:4 (right for banks 0,2)
     return __int_as_float(__builtin_amdgcn_update_dpp(t, i, 0x114, 0xF, 0xA, false));              // row_shr:4 into banks 1,3
+#else
+    // lane ^ 4 has no single DPP pattern (it would take two VALU moves); ds_swizzle's bit mode (and 0x1F, or 0, xor 4)
+    // does it in one instruction on the LDS crossbar, off the VALU the kernels are bound by
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x101F));
+#endif
 }
 template <int X> __device__ __forceinline__ f2 lane16_xor2(f2 v) { f2 r; r.x = lane16_xor<X>(v.x); r.y = lane16_xor<X>(v.y); return r; }
 
