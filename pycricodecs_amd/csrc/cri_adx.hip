@@ -461,30 +461,34 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
             } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
             else word = scale;
             if (!scale) scale = 1;
-            const float rcp = 1.0f / (float)scale;
+            // pass B (adx.cpp:254-271) is one serial chain of 32 steps per block, so its length in dependent instructions
+            // is what the kernel's time is made of.  delta / scale (C division, then a clamp to [-8, 7]) only needs the
+            // quotient up to 9: |delta| is capped at 9 * scale (< 2^24, exact in fp32) and floor((n + 0.5) / scale) comes
+            // out of one fma and a truncation -- the 0.5 keeps every exact quotient 0.5 / scale >= 1.2e-4 away from an
+            // integer, against a relative error of 2^-23.  Everything else is 24-bit multiplies and selects.
+            const float rcp = 1.0f / (float)scale, half_rcp = 0.5f * rcp;
+            const int32_t hs = (int32_t)(scale >> 1), cap = 9 * (int32_t)scale, iscale = (int32_t)scale;
             int32_t g1 = h1, g2 = h2, mine = 0;
+            int32_t c1g2 = __mul24(c1, g2);
 #pragma unroll
-            for (int k = 0; k < 32; k++) {                                             // pass B (adx.cpp:254-271)
+            for (int k = 0; k < 32; k++) {
                 const int32_t x0 = __builtin_amdgcn_readlane(x, k), x1 = __builtin_amdgcn_readlane(x, 32 + k);
-                const int32_t xk = half ? x1 : x0;
-                int32_t delta = ((int32_t)((uint32_t)xk << 12) - c0 * g1 - c1 * g2) >> 12;
-                delta = delta > 0 ? delta + (int32_t)(scale >> 1) : delta - (int32_t)(scale >> 1);
-                {
-                    const uint32_t an = (uint32_t)(delta < 0 ? -delta : delta);
-                    uint32_t q;
-                    if (an < (1u << 22)) {
-                        q = (uint32_t)((float)an * rcp);
-                        int32_t rem = (int32_t)an - (int32_t)(q * scale);
-                        if (rem < 0) { q--; rem += (int32_t)scale; }
-                        if (rem >= (int32_t)scale) q++;
-                    } else q = an / scale;
-                    delta = delta < 0 ? -(int32_t)q : (int32_t)q;
-                }
-                delta = clamp_sym(delta, 7);
-                int32_t sim = (int32_t)(((uint32_t)delta << 12) * scale + (uint32_t)(c0 * g1) + (uint32_t)(c1 * g2)) >> 12;
+                const int32_t xs = (int32_t)((uint32_t)(half ? x1 : x0) << 12);
+                const int32_t pred = __mul24(c0, g1) + c1g2;
+                const int32_t d = (xs - pred) >> 12;
+                const int32_t ad = d < 0 ? -d : d;
+                int32_t an = ad + hs;
+                an = an < cap ? an : cap;
+                int32_t q = (int32_t)__builtin_fmaf((float)an, rcp, half_rcp);
+                const bool neg = d < 0;
+                const int32_t qmax = neg ? 8 : 7;
+                q = q < qmax ? q : qmax;
+                const int32_t code = neg ? -q : q;
+                int32_t sim = (int32_t)(((uint32_t)__mul24(code, iscale) << 12) + (uint32_t)pred) >> 12;
                 sim = clamp_sym(sim, 0x7FFF);
-                g2 = g1; g1 = (int32_t)(int16_t)sim;
-                mine = (int)s == k ? delta : mine;
+                c1g2 = __mul24(c1, g1);
+                g2 = g1; g1 = sim;
+                mine = (int)s == k ? code : mine;
             }
             h1 = silent ? raw1 : g1; h2 = silent ? raw2 : g2;
             // two 4-bit codes per byte, first sample in the high nibble; even lanes hold the byte
