@@ -36,13 +36,13 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_hca_streams(unique, seconds, rank):
+def make_hca_streams(unique, seconds, rank, quality=1):
     import oracle_lib as O
     from pycricodecs_amd import synth
     out = []
     for u in range(unique):
         w = synth.wav(1000 * rank + u, int(48000 * seconds) // 32 * 32, 2, 48000)
-        out.append(O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY))
+        out.append(O.hca_crypt(O.hca_encode(w, quality), 1, 56, KEY))
     return out
 
 
@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--unique", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "adx_roundtrip"])
+    ap.add_argument("--quality", type=int, default=1, help="HCA quality of the decode workload: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--secondary-streams", type=int, default=1000)
@@ -219,11 +220,11 @@ def main():
     t_setup = time.time()
     extra = {}
     if args.workload == "hca_decode":
-        uniq = make_hca_streams(args.unique, args.seconds, rank)
+        uniq = make_hca_streams(args.unique, args.seconds, rank, args.quality)
         items = [uniq[i % len(uniq)] for i in range(args.streams)]
         job = Job.hca_decode(items, keys=[KEY] * len(items))
-        metric_cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality High, frame 682 B, key 0xCF222F1FE0748978) per GPU"
-                      % (args.streams, args.seconds), "streams_per_gpu": args.streams, "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
+        metric_cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality %s, frame %d B, key 0xCF222F1FE0748978) per GPU"
+                      % (args.streams, args.seconds, {0: "Highest", 1: "High", 2: "Middle", 3: "Low", 4: "Lowest"}.get(args.quality, "?"), int.from_bytes(uniq[0][0x1C:0x1E], "big")), "streams_per_gpu": args.streams, "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
                       "unique_streams": len(uniq), "parallelism": "file-sharded x%d, no collective" % world}
         unit_bytes = "frame_size + 2*1024*channels = 682 + 4096 = 4778 B per frame"
     else:

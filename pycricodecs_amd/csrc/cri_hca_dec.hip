@@ -801,8 +801,14 @@ __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
 
 struct TrLds {
     float* G;          // [C][128] gains of the current frame
-    float* hconv;      // [C][128] HFR scale of a reconstructed band
-    uint8_t* hlow;     // [C][128] source band of a reconstructed band
+    // formats with high-frequency reconstruction / intensity stereo only (!PLAIN):
+    float* hconv;      // [C][128] HFR scale of a reconstructed band (per frame)
+    float* S;          // [4][128] dequantised coded lines of the pass's four transforms (HFR and intensity sources)
+    float* conv;       // [128] HCA_SCALE_CONV
+    float* iratio;     // [16] HCA_INTENSITY_RATIO
+    uint8_t* sfb;      // [C][128] scalefactor bytes of the frame
+    uint8_t* hlow;     // [128] source band of a reconstructed band (format constant)
+    uint8_t* hgrp;     // [128] HFR group of a reconstructed band (format constant)
     uint8_t* inten;    // [C][8]
     float* D;          // [8][128] ring of DCT outputs in logical order
     uint16_t* pcm;     // [512] int16 staging of one pass
@@ -814,12 +820,14 @@ struct TrLds {
 
 // what the per-frame setup needs from the frame record, fetched one frame ahead so its latency hides behind the
 // previous frame's transforms
-template <int C> struct FramePre { uint32_t packed; int32_t status; uint32_t sf2[C]; };
-template <int C>
+template <int C> struct FramePre { uint32_t packed; int32_t status; uint32_t flags; uint32_t ib; uint32_t sf2[C]; };
+template <bool PLAIN, int C>
 __device__ __forceinline__ FramePre<C> tr_prefetch_frame(const uint8_t* rec, uint32_t lane) {
     FramePre<C> p;
     const uint32_t* tail = (const uint32_t*)(rec + HCA_REC_TAIL(C));
     p.packed = tail[0]; p.status = (int32_t)tail[1];
+    p.flags = 0; p.ib = 0;
+    if (!PLAIN) { p.flags = tail[2]; p.ib = rec[HCA_REC_INT(C, 0) + (lane & (C * 8 - 1))]; }   // intensity byte (channel lane >> 3, index lane & 7)
 #pragma unroll
     for (int c = 0; c < C; c++) p.sf2[c] = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
     return p;
@@ -851,45 +859,54 @@ __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, con
         *(float2*)(T.G + c * 128 + 2 * lane) = make_float2(g[0], g[1]);
     }
     if (!PLAIN) {
-        const uint8_t* rec = rec0 + (uint64_t)f * F.record_bytes;
-#pragma unroll 1
-        for (uint32_t c = 0; c < (uint32_t)C; c++) {
-            if (!(F.bands_per_hfr_group > 0 && F.type(c) != CRI_CH_SECONDARY)) continue;
-            const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
-            const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
-            const uint8_t* sfb = rec + HCA_REC_SF(C, c);
+        // scalefactor bytes to LDS: the HFR scale of band b needs the scalefactors of its group and of its source band
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int k = (int)lane + 64 * h;
-                if (k < nproc) {
-                    const int group = k / bpg;
-                    const int dec = k < limit * bpg ? k : limit * bpg;
-                    const int low = start - 1 - dec;
-                    int sc = (int)sfb[128 - groups + group] - (int)sfb[low] + 63;
+        for (int c = 0; c < C; c++) ((uint16_t*)T.sfb)[c * 64 + lane] = (uint16_t)pre.sf2[c];
+        wave_lds_sync();
+        if (F.bands_per_hfr_group > 0) {
+            const int start = (int)(F.stereo_bands + F.base_bands), groups = (int)F.hfr_group_count;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                if (F.type(c) == CRI_CH_SECONDARY) continue;
+                const uint8_t* sfb = T.sfb + c * 128;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int k = (int)lane + 64 * h, b = (start + k) & 127;
+                    int sc = (int)sfb[(128 - groups + T.hgrp[b]) & 127] - (int)sfb[T.hlow[b]] + 63;
                     sc = sc & ~(sc >> 31);
-                    T.hconv[c * 128 + start + k] = HCA_SCALE_CONV[sc & 127];
-                    T.hlow[c * 128 + start + k] = (uint8_t)low;
+                    if (k < nproc) T.hconv[c * 128 + b] = T.conv[sc & 127];
                 }
             }
         }
-        resolve_intensity(F, rec0, f, C, lane, T.inten);
+        // intensity indexes (hca.cpp:1361-1441): the prefetched byte, unless the frame is flagged "keep entries 1..7"
+        if (lane < C * 8) {
+            const uint32_t c = lane >> 3, k = lane & 7;
+            uint8_t v = (uint8_t)pre.ib;
+            if (k > 0 && ((pre.flags >> c) & 1u)) {          // rare: walk back to the nearest unflagged frame (zeros if none)
+                uint32_t ff = f;
+                while ((((const uint32_t*)(rec0 + (uint64_t)ff * F.record_bytes + HCA_REC_TAIL(C)))[2] >> c) & 1u) {
+                    if (ff == 0) { v = 0; break; }
+                    ff--;
+                    v = rec0[(uint64_t)ff * F.record_bytes + HCA_REC_INT(C, c) + k];
+                }
+            }
+            T.inten[lane] = v;
+        }
     }
     wave_lds_sync();
 }
 
 // the 8 spectral lines b = lane16*8 + r of (frame record, subframe, channel) after dequantisation, high-frequency
 // reconstruction and intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
-struct TrFetch { uint4 q, p; };      // quantised lines of (sf, c) for this lane's 8 bands, and of channel c-1 when c is a stereo secondary
+struct TrFetch { uint4 q; };         // quantised lines of (sf, c) for this lane's 8 bands
 template <bool PLAIN, int C>
 __device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* rec, uint32_t sf, uint32_t c, uint32_t l16) {
     TrFetch t;
     t.q = *(const uint4*)(rec + (HCA_REC_QC(C, sf, c) + l16 * 16));
-    t.p = make_uint4(0, 0, 0, 0);
-    if (!PLAIN && F.type(c) == CRI_CH_SECONDARY && F.stereo_bands > 0) t.p = *(const uint4*)(rec + (HCA_REC_QC(C, sf, c - 1) + l16 * 16));
     return t;
 }
 template <bool PLAIN, int C>
-__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const uint8_t* rec, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t l16, int nproc, f2 x[4]) {
+__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t slot, uint32_t l16, int nproc, f2 x[4]) {
     const bool secondary = F.type(c) == CRI_CH_SECONDARY;
     const uint32_t qw[4] = {ft.q.x, ft.q.y, ft.q.z, ft.q.w};
     if (PLAIN) {
@@ -903,26 +920,40 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
         }
         return;
     }
-    const uint32_t pw[4] = {ft.p.x, ft.p.y, ft.p.z, ft.p.w};
+    // Dequantise the coded lines into registers and into the pass's LDS row; high-frequency reconstruction reads its
+    // source band from that row, and a stereo secondary reads the primary's row (one slot down: same subframe, channel
+    // c - 1) for the bands it shares with it.  Everything is selects over unconditional LDS reads.
+    const float4 g0 = *(const float4*)(T.G + c * 128 + l16 * 8), g1 = *(const float4*)(T.G + c * 128 + l16 * 8 + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float own[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) own[r] = g[r] * (float)(int)(int16_t)(qw[r >> 1] >> (16 * (r & 1)));   // gain is 0 past the coded bands
+    float* srow = T.S + slot * 128;
+    *(float4*)(srow + l16 * 8) = make_float4(own[0], own[1], own[2], own[3]);
+    *(float4*)(srow + l16 * 8 + 4) = make_float4(own[4], own[5], own[6], own[7]);
+    wave_lds_sync();
+    const bool stereo = F.stereo_bands > 0, hfr = F.bands_per_hfr_group > 0;
+    const uint32_t cp = secondary && c > 0 ? c - 1 : c;                          // channel whose lines the shared bands come from
+    const float* prow = secondary && slot > 0 ? srow - 128 : srow;
     const int start = (int)(F.stereo_bands + F.base_bands);
-    const float rl = (F.stereo_bands > 0 && (secondary || F.type(c) == CRI_CH_PRIMARY))
-                         ? HCA_INTENSITY_RATIO[T.inten[(secondary ? c : c + 1) * 8 + sf] & 15] : 1.0f;
+    const float rl = (stereo && (secondary || F.type(c) == CRI_CH_PRIMARY)) ? T.iratio[T.inten[(secondary ? c : c + 1) * 8 + sf] & 15] : 1.0f;
     const float rr = 2.0f - rl;
+    const float4 p0 = *(const float4*)(prow + l16 * 8), p1 = *(const float4*)(prow + l16 * 8 + 4);
+    const float pv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const uint2 lowp = *(const uint2*)(T.hlow + l16 * 8);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t b = l16 * 8 + r;
-        const bool from_prev = secondary && b >= F.base_bands;           // intensity: R takes L's line (hca.cpp:1707-1711)
-        const uint32_t cs = from_prev ? c - 1 : c;
-        const uint32_t w = from_prev ? pw[r >> 1] : qw[r >> 1];
-        float v = 0.0f;
-        if (b < F.coded(cs)) v = T.G[cs * 128 + b] * (float)(int)(int16_t)(w >> (16 * (r & 1)));
-        else if (F.bands_per_hfr_group > 0 && F.type(cs) != CRI_CH_SECONDARY && (int)b >= start && (int)b < start + nproc) {
-            const uint32_t low = T.hlow[cs * 128 + b];
-            const float ql = (float)(int)*(const int16_t*)(rec + HCA_REC_QC(C, sf, cs) + low * 2);
-            v = T.hconv[cs * 128 + b] * (T.G[cs * 128 + low] * ql);
-        }
-        if (F.bands_per_hfr_group > 0 && F.type(cs) != CRI_CH_SECONDARY && (int)b == start + nproc - 1) v = 0.0f;   // hca.cpp:1681
-        if (F.stereo_bands > 0 && b >= F.base_bands && b < F.total_bands) {
+        const bool from_prev = secondary && b >= F.base_bands;                   // intensity: R takes L's line (hca.cpp:1707-1711)
+        const uint32_t cs = from_prev ? cp : c;
+        const float* row = from_prev ? prow : srow;
+        const bool cs_hfr = hfr && F.type(cs) != CRI_CH_SECONDARY;
+        const uint32_t low = ((r < 4 ? lowp.x : lowp.y) >> (8 * (r & 3))) & 0xFF;
+        const float hv = T.hconv[cs * 128 + b] * row[low & 127];                 // hca.cpp:1638-1683
+        float v = from_prev ? pv[r] : own[r];
+        v = b < F.coded(cs) ? v : ((cs_hfr && (int)b >= start && (int)b < start + nproc) ? hv : 0.0f);
+        if (cs_hfr && (int)b == start + nproc - 1) v = 0.0f;                     // hca.cpp:1681
+        if (stereo && b >= F.base_bands && b < F.total_bands) {
             if (from_prev) v = v * rr;
             else if (F.type(c) == CRI_CH_PRIMARY) v = v * rl;
         }
@@ -932,15 +963,17 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
 
 // One loop over "steps": step -1 (only when the run does not start the stream) is the halo -- the DCT of the previous
 // frame's last subframe, which only feeds the overlap ring -- and steps 0 .. nf*2C-1 are the passes of the run's frames.
+// (the !PLAIN variants carry ~11 KB of LDS per wave, which already limits them to 3.5 waves per SIMD: give them the registers)
 template <bool PLAIN, int C>
-__global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
+__global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x, slot = lane >> 4, l16 = lane & 15;
     TrLds T;
-    T.G = (float*)smem; T.hconv = T.G + C * 128; T.D = T.hconv + C * 128; T.pcm = (uint16_t*)(T.D + 8 * 128);
+    T.G = (float*)smem; T.D = T.G + C * 128; T.pcm = (uint16_t*)(T.D + 8 * 128);
     T.win = (float*)(T.pcm + 512); T.scale = T.win + 128; T.range = T.scale + 64; T.curve = (uint8_t*)(T.range + 16);
-    T.hlow = T.curve + 80; T.inten = T.hlow + C * 128;
+    T.hconv = (float*)(T.curve + 80); T.S = T.hconv + C * 128; T.conv = T.S + 512; T.iratio = T.conv + 128;   // !PLAIN only from here
+    T.sfb = (uint8_t*)(T.iratio + 16); T.hlow = T.sfb + C * 128; T.hgrp = T.hlow + 128; T.inten = T.hgrp + 128;
 
     // run -> stream, first frame
     uint32_t lo = a.stream_begin, hi = a.stream_end;
@@ -959,17 +992,29 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
     if (lane < 16) T.range[lane] = HCA_DEQ_RANGE[lane];
     T.curve[lane] = HCA_CURVE_TO_RES[lane]; if (lane < 2) T.curve[64 + lane] = HCA_CURVE_TO_RES[64 + lane];
     const uint32_t ath2 = ((const uint16_t*)(a.ath_tables + F.ath_index * 128))[lane];
-    wave_lds_sync();
     // bands reconstructed by HFR (format constant): stops when the high band leaves the spectrum or the low band index hits 0
     int nproc = 0;
-    if (!PLAIN && F.bands_per_hfr_group > 0) {
-        const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
-        const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
-        nproc = groups * bpg;
-        if (nproc > (int)F.total_bands - start) nproc = (int)F.total_bands - start;
-        if (nproc < 0) nproc = 0;
-        if (limit * bpg > start - 1 && nproc > start) nproc = start;
+    if (!PLAIN) {
+        T.conv[lane] = HCA_SCALE_CONV[lane]; T.conv[lane + 64] = HCA_SCALE_CONV[lane + 64];
+        if (lane < 16) T.iratio[lane] = HCA_INTENSITY_RATIO[lane];
+        T.hlow[lane] = 0; T.hlow[lane + 64] = 0; T.hgrp[lane] = 0; T.hgrp[lane + 64] = 0;
+        for (uint32_t i = lane; i < (uint32_t)C * 128; i += 64) T.hconv[i] = 0.0f;
+        wave_lds_sync();
+        if (F.bands_per_hfr_group > 0) {
+            const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
+            const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
+            nproc = groups * bpg;
+            if (nproc > (int)F.total_bands - start) nproc = (int)F.total_bands - start;
+            if (nproc < 0) nproc = 0;
+            if (limit * bpg > start - 1 && nproc > start) nproc = start;
+            for (int k = (int)lane; k < nproc; k += 64) {        // source band and group of every reconstructed band (hca.cpp:1650-1676)
+                const int dec = k < limit * bpg ? k : limit * bpg;
+                T.hlow[start + k] = (uint8_t)(start - 1 - dec);
+                T.hgrp[start + k] = (uint8_t)(k / bpg);
+            }
+        }
     }
+    wave_lds_sync();
     constexpr uint32_t PASSES = 2 * C;                     // passes per frame
     constexpr uint32_t SPAN = (4 / C) * 128;               // samples per channel completed by one pass
     const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
@@ -979,7 +1024,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
     const bool has_halo = f0 > 0;
     const uint32_t f_first = has_halo ? f0 - 1 : f0;
     const uint8_t* rec = rec0 + (uint64_t)f_first * F.record_bytes;         // record of the step's frame
-    FramePre<C> pre = tr_prefetch_frame<C>(rec, lane);
+    FramePre<C> pre = tr_prefetch_frame<PLAIN, C>(rec, lane);
     TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, rec, 7, slot < (uint32_t)C ? slot : 0, l16) : tr_fetch<PLAIN, C>(F, rec, slot / C, slot % C, l16);
     uint32_t f = f_first, pass = has_halo ? PASSES : 0;    // pass == PASSES marks the halo step
     uint32_t ring = 8;                                     // ring position of a normal step's slot 0
@@ -992,7 +1037,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
             const FramePre<C> cur_pre = pre;
             const int32_t status = __builtin_amdgcn_readfirstlane(cur_pre.status);
             if (status != 0) { if (!halo && lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
-            if (f + 1 < f_end) pre = tr_prefetch_frame<C>(rec + F.record_bytes, lane);
+            if (f + 1 < f_end) pre = tr_prefetch_frame<PLAIN, C>(rec + F.record_bytes, lane);
             tr_setup_frame<PLAIN, C>(F, T, rec0, f, lane, nproc, cur_pre, ath2);
         }
         const uint32_t t = halo ? 7 * C + slot : pass * 4 + slot, sf = t / C, c = t % C;
@@ -1003,7 +1048,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
             else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, rec + F.record_bytes, slot / C, slot % C, l16);
         }
         f2 x[4];
-        tr_load_spectra<PLAIN, C>(F, T, rec, cur, sf, halo && slot >= (uint32_t)C ? 0 : c, l16, nproc, x);
+        tr_load_spectra<PLAIN, C>(F, T, cur, sf, halo && slot >= (uint32_t)C ? 0 : c, slot, l16, nproc, x);
         dct4_inplace(x, L);
         const uint32_t dslot = halo ? ring - C + slot : ring + slot;
         float* d = T.D + (dslot & 7) * 128;
@@ -1070,13 +1115,16 @@ __global__ __launch_bounds__(64, 4) void k_hca_transform(HcaDecArgs a) {
     }
 }
 
-size_t hca_transform_lds_bytes(uint32_t C) { return (size_t)C * 128 * 4 * 2 + 8 * 128 * 4 + 1024 + 512 + 256 + 64 + 80 + C * 128 + 64; }
+size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
+    const size_t base = (size_t)C * 128 * 4 + 8 * 128 * 4 + 1024 + 512 + 256 + 64 + 80;
+    return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + C * 8 + 64;
+}
 
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
     if (!a.noise_fill && (a.channels == 1 || a.channels == 2 || a.channels == 4)) {
-        const size_t lds = hca_transform_lds_bytes(a.channels);
+        const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
 #define CRI_LAUNCH_TR(P, CH) hipLaunchKernelGGL((k_hca_transform<P, CH>), dim3(a.runs), dim3(64), lds, s, a)
         if (a.plain) { if (a.channels == 1) CRI_LAUNCH_TR(true, 1); else if (a.channels == 2) CRI_LAUNCH_TR(true, 2); else CRI_LAUNCH_TR(true, 4); }
         else { if (a.channels == 1) CRI_LAUNCH_TR(false, 1); else if (a.channels == 2) CRI_LAUNCH_TR(false, 2); else CRI_LAUNCH_TR(false, 4); }
