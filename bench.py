@@ -136,24 +136,27 @@ def secondary_measurements(args, dev, rank):
     return res
 
 
-def awb_mixed_measurement(args, dev, rank):
-    """BASELINE configs[4] shape at one GPU's share: an AFS2 bank of short clips (log-uniform 0.05-2 s, half ADX bs18/bd4,
-    half encrypted HCA), decoded by the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM."""
+def build_awb_bank(n_total, rank, world, seed=77):
+    """AFS2 bank of this rank's share of `n_total` short clips (BASELINE configs[4] shape: log-uniform 0.05-2 s, 48 kHz stereo,
+    half ADX bs18/bd4, half HCA High encrypted with the bank's subkey).  The global clip list is the same on every rank;
+    shares are longest-processing-time balanced by frame count (pycricodecs_amd.shard).  Returns (bank, uniq, order, subkey)."""
     import struct
     import numpy as np
-    import torch
     import oracle_lib as O
-    from pycricodecs_amd import synth
-    from pycricodecs_amd.batch import Job
-    n, subkey, align = args.awb_clips, 0x2468, 0x20
-    rng = np.random.default_rng(77 + rank)
+    from pycricodecs_amd import shard, synth
+    subkey, align = 0x2468, 0x20
+    rng = np.random.default_rng(seed)
     durs = np.exp(rng.uniform(np.log(0.05), np.log(2.0), 24))
     uniq = []
     for u, d in enumerate(durs):
         w = synth.wav(7000 + u, max(32, int(48000 * d) // 32 * 32), 2, 48000)
         uniq.append(("hca", O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, subkey)))
         uniq.append(("adx", O.adx_encode(w)))
-    order = rng.integers(0, len(uniq), n)
+    order_all = rng.integers(0, len(uniq), n_total)
+    wts = [shard.hca_weight(u[1]) if u[0] == "hca" else shard.adx_weight(u[1]) // 2 for u in uniq]
+    mine = shard.my_items([wts[i] for i in order_all], rank, world) if world > 1 else range(n_total)
+    order = [int(order_all[i]) for i in mine]
+    n = len(order)
     hs0 = 16 + 2 * n + 4 * (n + 1)
     hs = hs0 + (-hs0 % align)
     offs, pos, parts = [hs0], hs, []
@@ -161,30 +164,63 @@ def awb_mixed_measurement(args, dev, rank):
         cb = uniq[i][1]
         cb = cb + b"\0" * (-len(cb) % align)
         parts.append(cb); pos += len(cb); offs.append(pos)
-    head = struct.pack("<4sBBHIHH", b"AFS2", 2, 4, 2, n, align, subkey) + np.arange(n, dtype="<u2").tobytes() + np.array(offs, dtype="<u4").tobytes()
-    bank = head.ljust(hs, b"\0") + b"".join(parts)
+    head = struct.pack("<4sBBHIHH", b"AFS2", 2, 4, 2, n, align, subkey) + (np.arange(n) & 0xFFFF).astype("<u2").tobytes() + np.array(offs, dtype="<u4").tobytes()
+    return head.ljust(hs, b"\0") + b"".join(parts), uniq, order, subkey
+
+
+def awb_mixed_measurement(args, dev, rank, world=1, gather=False):
+    """Decode of a mixed AFS2 bank through the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM.
+    With world > 1 every rank decodes its LPT share of awb_clips x world clips and (gather=True) the decoded PCM of all
+    ranks is collected on rank 0 inside the timed region -- the only collective-like step of the whole path."""
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    from pycricodecs_amd import shard
+    from pycricodecs_amd.batch import Job
+    bank, uniq, order, subkey = build_awb_bank(args.awb_clips * world, rank, world)
+    n = len(order)
     hj, aj = Job.awb_decode(bank, KEY)
     d_in, ho, hscr, hst = hj.alloc(dev)
     _, ao, ascr, ast = aj.alloc(dev, upload=False)
-    for _ in range(2):
+
+    def step():
         hj.run(d_in, ho, hscr, hst); aj.run(d_in, ao, ascr, ast)
-    torch.cuda.synchronize()
-    steps = 5
+        if gather and world > 1:
+            shard.gather_bytes_to_root(ho[:hj.output_bytes]); shard.gather_bytes_to_root(ao[:aj.output_bytes])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    steps = max(args.steps, 1)
     t0 = time.perf_counter()
     for _ in range(steps):
-        hj.run(d_in, ho, hscr, hst); aj.run(d_in, ao, ascr, ast)
-    torch.cuda.synchronize()
+        step()
+    barrier()
     dt = (time.perf_counter() - t0) / steps
+    hca_units, adx_units = float(hj.units), float(aj.units)
+    if world > 1:
+        t = torch.tensor([dt, 0.0, 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        u = torch.tensor([hca_units, adx_units, float(n)], dtype=torch.float64, device=dev)
+        dist.all_reduce(u)
+        dt, hca_units, adx_units, n_all = float(t[0].item()), float(u[0].item()), float(u[1].item()), int(u[2].item())
+    else:
+        n_all = n
     assert int((hst < 0).sum().item()) == 0 and int((ast < 0).sum().item()) == 0
     k_h = next(i for i in range(n) if uniq[order[i]][0] == "hca"); k_a = next(i for i in range(n) if uniq[order[i]][0] == "adx")
     ref = O.hca_decode(uniq[order[k_h]][1], KEY, subkey)
     assert bytes(ho[int(hj.output_offsets[k_h]):int(hj.output_offsets[k_h]) + len(ref)].cpu().numpy()) == ref, "AWB HCA item differs from the oracle"
     ref = O.adx_decode(uniq[order[k_a]][1])
     assert bytes(ao[int(aj.output_offsets[k_a]):int(aj.output_offsets[k_a]) + len(ref)].cpu().numpy()) == ref, "AWB ADX item differs from the oracle"
-    return {"workload": "AFS2 bank of %d clips (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV" % n,
-            "bank_bytes": len(bank), "pcm_bytes": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
-            "hca_frames": int(hj.units), "adx_frames": int(aj.units), "frames_per_s": round((hj.units + aj.units) / dt, 1),
-            "clips_per_s": round(n / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)"}
+    return {"workload": "AFS2 bank(s) of %d clips%s (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV%s"
+                        % (n_all, " over %d GPUs, LPT-sharded" % world if world > 1 else "", ", PCM gathered on rank 0 (RCCL send/recv)" if gather and world > 1 else ""),
+            "bank_bytes_rank0": len(bank), "pcm_bytes_rank0": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
+            "hca_frames": int(hca_units), "adx_frames": int(adx_units), "frames_per_s": round((hca_units + adx_units) / dt, 1),
+            "clips_per_s": round(n_all / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)"}
 
 
 def main():
@@ -195,7 +231,8 @@ def main():
     ap.add_argument("--streams", type=int, default=10000)
     ap.add_argument("--unique", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "adx_roundtrip"])
+    ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "adx_roundtrip", "awb_mixed"])
+    ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
     ap.add_argument("--quality", type=int, default=1, help="HCA quality of the decode workload: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -216,6 +253,17 @@ def main():
 
     from pycricodecs_amd.batch import Job
     from pycricodecs_amd import synth
+
+    if args.workload == "awb_mixed":                          # BASELINE configs[4]; its own line, not the headline metric
+        r = awb_mixed_measurement(args, dev, rank, world, gather=not args.no_gather)
+        if rank == 0:
+            print(json.dumps({"metric": "audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", "value": r["frames_per_s"], "unit": "frames/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32+int32", "data": "synthetic (24 unique durations x 2 codecs, tiled)",
+                              "config": r}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     t_setup = time.time()
     extra = {}
@@ -303,13 +351,13 @@ def main():
                      "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kernel_ms.items()}},
     }
     # ---- secondary figures of the same hot path (smaller batches, few steps): HCA encode, ADX encode + decode (configs[1], [3])
-    if rank == 0 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary:     # (single-GPU run only: the other ranks of a scaling run must not wait)
         del d_in, d_out, d_scratch, d_status
         torch.cuda.empty_cache()
         out["secondary"] = secondary_measurements(args, dev, rank)
         torch.cuda.empty_cache()
         out["secondary"]["awb_mixed_decode"] = awb_mixed_measurement(args, dev, rank)
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         if args.workload == "hca_decode":
             out["cpu_baseline"] = cpu_baseline_hca_decode(items[0])
         else:

@@ -37,8 +37,15 @@ def _worker(rank, world, port, q):
     s = torch.tensor([sum(digest) % (1 << 31)], dtype=torch.int64)
     dist.all_reduce(s)
     full = sum(int.from_bytes(hashlib.sha256(O.hca_decode(h)).digest()[:4], "little") for h in items)
+    # the optional exchange step: every rank's decoded bytes on rank 0, in rank order
+    mine_pcm = b"".join(O.hca_decode(items[i]) for i in mine)
+    got, offs = shard.gather_bytes_to_root(torch.frombuffer(bytearray(mine_pcm), dtype=torch.uint8))
+    gathered_ok = None
     if rank == 0:
-        q.put((owned.tolist(), float(t.item()), float(tot.item()), sum(weights), int(s.item()), full))
+        expect = b"".join(b"".join(O.hca_decode(items[i]) for i in shard.my_items(weights, r, world)) for r in range(world))
+        gathered_ok = bytes(got.numpy()) == expect and offs[-1] == len(expect)
+    if rank == 0:
+        q.put((owned.tolist(), float(t.item()), float(tot.item()), sum(weights), int(s.item()), full, gathered_ok))
     dist.destroy_process_group()
 
 
@@ -49,11 +56,12 @@ def test_two_rank_sharding_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    owned, tmax, tot, total_w, s, full = q.get(timeout=180)
+    owned, tmax, tot, total_w, s, full, gathered_ok = q.get(timeout=180)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert owned == [1] * 12
+    assert gathered_ok is True                                 # variable-length gather to rank 0 (send/recv batch)
     assert tot == total_w
     assert tmax <= 0.6 * total_w                              # LPT keeps the heavier rank within 60 % of the total
     assert s % (1 << 31) == full % (1 << 31) or s == full     # checksum of checksums is world-size independent
