@@ -199,9 +199,9 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         uint32_t hs_arg = header_sizes ? header_sizes[i] : (len >= 8 ? be16(d + 6) : 0);
         int rc = hca_parse_header(d, len, hs_arg, h);
         if (rc) { j->host_status[i] = rc; continue; }
-        uint64_t total = (uint64_t)h.frame_count * 1024;
-        if (total < (uint64_t)h.delay + h.padding || total > 0xFFFFFFFFull) { j->host_status[i] = CRI_ERR_HCA_HEADER; continue; }
-        uint32_t spc = (uint32_t)(total - h.delay - h.padding);
+        const uint32_t total = h.frame_count * 1024u;           // 32-bit like the reference's sample count (hca.cpp:3369-3391): a huge frame count wraps
+        if (total < h.delay + h.padding) { j->host_status[i] = CRI_ERR_HCA_HEADER; continue; }
+        uint32_t spc = total - h.delay - h.padding;
         uint32_t frames = spc == 0 ? 0 : (uint32_t)std::min<uint64_t>(h.frame_count, ((uint64_t)h.delay + spc + 1023) / 1024);
         if ((uint64_t)hs_arg + (uint64_t)frames * h.frame_size > len) { j->host_status[i] = CRI_ERR_HCA_DECODE; continue; }
         // format

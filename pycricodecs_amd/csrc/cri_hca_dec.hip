@@ -316,11 +316,12 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             uint32_t mw[4] = {0, 0, 0, 0};
             // far from the frame end (always, in a well-formed frame) the reader's end-of-frame rules cannot apply
             const bool sf_fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
-            if (blk * 16 < cs) {
+            if (blk * 16 < cs || blk == 0) {
 #pragma unroll
                 for (uint32_t k = 0; k < 16; k++) {               // hca.cpp:1310-1350, all lanes in lock step
                     const uint32_t i = blk * 16 + k;
-                    const bool in = i < cs;
+                    // (with delta coding the first 6-bit value is read even when the channel codes no band at all, hca.cpp:1322-1324)
+                    const bool in = i < cs || (i == 0 && db > 0 && db < 6);
                     const bool direct = db >= 6 || i == 0;
                     uint32_t x, y; bool esc;
                     if (sf_fast) {                                // delta and its possible 6-bit escape value in one peek
@@ -944,7 +945,7 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t b = l16 * 8 + r;
-        const bool from_prev = secondary && b >= F.base_bands;                   // intensity: R takes L's line (hca.cpp:1707-1711)
+        const bool from_prev = secondary && stereo && b >= F.base_bands && b < F.total_bands;   // intensity: R takes L's line (hca.cpp:1707-1711)
         const uint32_t cs = from_prev ? cp : c;
         const float* row = from_prev ? prow : srow;
         const bool cs_hfr = hfr && F.type(cs) != CRI_CH_SECONDARY;

@@ -427,3 +427,63 @@ def test_drop_in_extension_module(cc):
         ext.HcaDecode(enc, 96, KEY + 2, 0)
     with pytest.raises(ValueError, match="Bitdepth"):
         ext.AdxEncode(w, 1, 18, 3, 500, 0, 4, False)
+
+
+# ------------------------------------------------------------------------------------------------ malformed inputs
+def _both(gpu_call, ora_call):
+    """Run the device path and the oracle on the same input: same accept/reject decision, same bytes when accepted."""
+    try:
+        ref = ora_call()
+    except O.OracleError:
+        ref = None
+    from pycricodecs_amd._capi import CriCodecsError
+    try:
+        got = gpu_call()
+    except CriCodecsError as e:
+        if e.code == -304:                                               # documented "valid but not on the device path" (e.g. > 64 ADX channels)
+            return "unsupported", ref
+        got = None
+    except (ValueError, NotImplementedError, RuntimeError):
+        got = None
+    return got, ref
+
+
+@pytest.mark.parametrize("kind", ["hca", "adx", "wav_adx", "wav_hca"])
+def test_header_mutation_fuzz(cc, kind):
+    """Random byte edits and truncations in the header region: the host planners must take the oracle's accept/reject
+    decision and produce its bytes (and, above all, must not read or write out of bounds doing so)."""
+    rng = np.random.default_rng({"hca": 1, "adx": 2, "wav_adx": 3, "wav_hca": 4}[kind])
+    w = synth.wav(77, 3008, 2, 48000)
+    base = {"hca": O.hca_encode(w, quality=2), "adx": O.adx_encode(w), "wav_adx": w, "wav_hca": w}[kind]
+    region = {"hca": 96, "adx": 40, "wav_adx": 44, "wav_hca": 44}[kind]
+    agree_ok = 0
+    import os
+    for it in range(int(os.environ.get("CRI_FUZZ_ITERS", "160"))):
+        b = bytearray(base)
+        if it % 8 == 7:
+            b = b[:int(rng.integers(0, len(b)))]                        # truncation
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                p = int(rng.integers(0, min(region, len(b))))
+                b[p] = int(rng.integers(0, 256)) if rng.random() < 0.5 else b[p] ^ (1 << int(rng.integers(0, 8)))
+            if kind == "hca" and it % 2 == 0:                            # half of the edits keep a valid header checksum
+                hs0 = int.from_bytes(base[6:8], "big")
+                b[6:8] = base[6:8]
+                b[hs0 - 2:hs0] = hca_forge.crc16(bytes(b[:hs0 - 2])).to_bytes(2, "big")
+        data = bytes(b)
+        if kind == "hca":
+            hs = int.from_bytes(data[6:8], "big") if len(data) >= 8 else 0
+            got, ref = _both(lambda: cc.HcaDecode(data, hs, 0, 0), lambda: O.hca_decode(data))
+        elif kind == "adx":
+            got, ref = _both(lambda: cc.AdxDecode(data), lambda: O.adx_decode(data))
+        elif kind == "wav_adx":
+            got, ref = _both(lambda: cc.AdxEncode(data, 4, 18, 3, 500, 0, 4, False), lambda: O.adx_encode(data))
+        else:
+            got, ref = _both(lambda: cc.HcaEncode(data, False, 1), lambda: O.hca_encode(data, quality=1))
+        if got == "unsupported":
+            continue
+        assert (got is None) == (ref is None), (kind, it, "device %s, oracle %s" % ("rejects" if got is None else "accepts", "rejects" if ref is None else "accepts"))
+        if ref is not None:
+            assert diff(got, ref) is None, (kind, it)
+            agree_ok += 1
+    assert agree_ok > 5
