@@ -378,7 +378,9 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 rec[HCA_REC_SF(C, c) + 127 - i] = srci < cs ? rec[HCA_REC_SF(C, c) + srci] : 0;
             }
         }
-        // unpack_intensity, hca.cpp:1361-1441
+        // unpack_intensity, hca.cpp:1361-1441.  Entries the reference leaves untouched (they keep the previous frame's
+        // value: the v2.0 "index 15" form for entries 1..7, the v3.0 delta form from the first out-of-range value on) are
+        // recorded as 0xFF; the transform resolves them by walking back through the stream's records.
         uint32_t inten_lo = 0, inten_hi = 0;
         if (type == CRI_CH_SECONDARY) {
             uint8_t iv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -387,9 +389,9 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             if (F.version <= 0x0200) {
                 iv[0] = (uint8_t)v;
                 const bool take = v < 15;
-                if (!take) flags |= 1u << c;                      // intensity[1..7] keep the previous frame's values
+                if (!take) flags |= 1u << c;
                 bb_skip(bb, take ? 4 : 0);
-                for (int k = 1; k < 8; k++) iv[k] = (uint8_t)bb_read(bb, ring, take ? 4 : 0);
+                for (int k = 1; k < 8; k++) { const uint32_t t = bb_read(bb, ring, take ? 4 : 0); iv[k] = take ? (uint8_t)t : (uint8_t)0xFF; }
             } else if (v < 15) {                                  // v3.0 forms; divergent but rare
                 bb_skip(bb, 4);
                 const uint32_t dbi = bb_read(bb, ring, 2);
@@ -398,13 +400,15 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 else {
                     const uint32_t bmax = (2u << dbi) - 1, bits = dbi + 1;
                     bool bad = false;
-                    for (int k = 1; k < 8 && !bad; k++) {
-                        const uint32_t delta = bb_read(bb, ring, (int)bits);
-                        if (delta == bmax) v = bb_read(bb, ring, 4);
-                        else { v = (v - (bmax >> 1) + delta) & 0xFF; if (v > 15) { bad = true; break; } }
-                        iv[k] = (uint8_t)v;
+                    for (int k = 1; k < 8; k++) {
+                        if (!bad) {
+                            const uint32_t delta = bb_read(bb, ring, (int)bits);
+                            if (delta == bmax) v = bb_read(bb, ring, 4);
+                            else { v = (v - (bmax >> 1) + delta) & 0xFF; if (v > 15) bad = true; }
+                        }
+                        iv[k] = bad ? (uint8_t)0xFF : (uint8_t)v;  // the reference returns at the first bad value
                     }
-                    if (bad) flags |= 1u << (16 + c);              // reference returns early here; entries stay stale
+                    if (bad) flags |= 1u << (16 + c);
                 }
             } else { bb_skip(bb, 4); for (int k = 0; k < 8; k++) iv[k] = 7; }
             inten_lo = iv[0] | (iv[1] << 8) | (iv[2] << 16) | ((uint32_t)iv[3] << 24);
@@ -662,22 +666,22 @@ __device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8
     }
 }
 
-// intensity indexes of frame f with the "nibble 15 keeps intensity[1..7]" rule resolved (hca.cpp:1367-1375):
-// a flagged frame takes entries 1..7 from the nearest earlier unflagged frame of the stream (zeros if none).
+// intensity indexes of frame f with the "entry keeps its previous value" cases resolved (hca.cpp:1367-1375, 1405-1408):
+// an entry recorded as 0xFF takes the value of the nearest earlier frame of the stream that set it (0 if none did).
+__device__ __forceinline__ uint8_t intensity_walk_back(const Fmt& F, const uint8_t* rec_stream0, uint32_t f, uint32_t C, uint32_t c, uint32_t k, uint8_t v) {
+    uint32_t ff = f;
+    while (v == 0xFF) {
+        if (ff == 0) { v = 0; break; }
+        ff--;
+        v = rec_stream0[(uint64_t)ff * F.record_bytes + HCA_REC_INT(C, c) + k];
+    }
+    return v;
+}
 __device__ __forceinline__ void resolve_intensity(const Fmt& F, const uint8_t* rec_stream0, uint32_t f, uint32_t C, uint32_t lane, uint8_t* inten) {
     if (lane < C * 8) {
         const uint32_t c = lane >> 3, k = lane & 7;
         const uint8_t* rec = rec_stream0 + (uint64_t)f * F.record_bytes;
-        uint8_t v = rec[HCA_REC_INT(C, c) + k];
-        if (k > 0) {
-            uint32_t ff = f;
-            while ((((const uint32_t*)(rec_stream0 + (uint64_t)ff * F.record_bytes + HCA_REC_TAIL(C)))[2] >> c) & 1u) {
-                if (ff == 0) { v = 0; break; }
-                ff--;
-                v = rec_stream0[(uint64_t)ff * F.record_bytes + HCA_REC_INT(C, c) + k];
-            }
-        }
-        inten[lane] = v;
+        inten[lane] = intensity_walk_back(F, rec_stream0, f, C, c, k, rec[HCA_REC_INT(C, c) + k]);
     }
 }
 
@@ -879,20 +883,9 @@ __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, con
                 }
             }
         }
-        // intensity indexes (hca.cpp:1361-1441): the prefetched byte, unless the frame is flagged "keep entries 1..7"
-        if (lane < C * 8) {
-            const uint32_t c = lane >> 3, k = lane & 7;
-            uint8_t v = (uint8_t)pre.ib;
-            if (k > 0 && ((pre.flags >> c) & 1u)) {          // rare: walk back to the nearest unflagged frame (zeros if none)
-                uint32_t ff = f;
-                while ((((const uint32_t*)(rec0 + (uint64_t)ff * F.record_bytes + HCA_REC_TAIL(C)))[2] >> c) & 1u) {
-                    if (ff == 0) { v = 0; break; }
-                    ff--;
-                    v = rec0[(uint64_t)ff * F.record_bytes + HCA_REC_INT(C, c) + k];
-                }
-            }
-            T.inten[lane] = v;
-        }
+        // intensity indexes (hca.cpp:1361-1441): the prefetched byte; 0xFF = "keeps its previous value" (rare), resolved by
+        // walking back through the stream's records
+        if (lane < C * 8) T.inten[lane] = intensity_walk_back(F, rec0, f, C, lane >> 3, lane & 7, (uint8_t)pre.ib);
     }
     wave_lds_sync();
 }

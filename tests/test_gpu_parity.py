@@ -194,6 +194,25 @@ def test_hca_v3_noise_fill(cc, q, ch, n):
     assert accepted > 0
 
 
+def test_v3_delta_intensity_keeps_stale_entries(cc):
+    """Found by tools/debug/frame_fuzz.py: a v3.0 delta-coded intensity list that runs out of range leaves the remaining
+    entries at the previous frame's values (the reference returns early and ignores the error, hca.cpp:1185, 1405-1408)."""
+    base = hca_forge.forge_v3(O.hca_encode(synth.wav(3, 4000, 2, 48000), 4), 0)
+    hs = int.from_bytes(base[6:8], "big")
+    hit = 0
+    for seed in (59, 11, 23, 35, 47, 71, 83, 95, 107, 119):
+        f = hca_forge.random_frames(base, seed, density=1.0 if seed % 2 else 0.35)
+        try:
+            ref = O.hca_decode(f)
+        except O.OracleError:
+            with pytest.raises(ValueError):
+                cc.HcaDecode(f, hs, 0, 0)
+            continue
+        hit += 1
+        assert diff(cc.HcaDecode(f, hs, 0, 0), ref) is None, seed
+    assert hit >= 1
+
+
 def test_hca_v3_noise_batch(cc):
     from pycricodecs_amd.batch import Job
     items = []
