@@ -9,9 +9,12 @@
 //                    unpack_intensity (1361-1441), calculate_resolution (1444-1494) and the bit parse of
 //                    dequantize_coefficients (1540-1571).  The variable-length parse is a serial chain per frame,
 //                    so it runs one LANE per frame (64 frames per wave) on a register bit buffer fed from the tile.
-//   k_hca_transform  calculate_gain (1498-1507), the float half of dequantize (1566), reconstruct_high_frequency
-//                    (1638-1683), apply_intensity_stereo (1696-1714), imdct_transform (1898-2019),
-//                    clHCA_ReadSamples16 (339-360) and HcaDecode's delay/trim (3401-3452).  One WAVE per frame.
+//   k_hca_transform<PLAIN, C>  calculate_gain (1498-1507), the float half of dequantize (1566),
+//                    reconstruct_high_frequency (1638-1683), apply_intensity_stereo (1696-1714), imdct_transform
+//                    (1898-2019), clHCA_ReadSamples16 (339-360) and HcaDecode's delay/trim (3401-3452).  One WAVE per run of
+//                    8 frames, four transforms at a time in registers (1, 2 or 4 channels).
+//   k_hca_transform_generic    the same for any channel count and for v3.0 noise reconstruction (1602-1635), one wave per
+//                    frame through LDS; k_hca_noise_scan gives it the generator state each frame starts from.
 // All float work is single IEEE binary32 operations in the reference's order (compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include "cri_kernels.h"
@@ -147,9 +150,9 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
 // k_hca_parse: one lane per frame
 // ------------------------------------------------------------------------------------------------------------
 // LDS per wave (8.9 KB): ostage uint32[16][65] (per-lane output words, transposed on flush), recoff uint64[64],
-// curve->resolution table, bit-feed ring uint32[RING_WORDS][64].  The per-band resolutions (4 bits each) live in the
-// tile's `resg` area of scratch: one uint64 (16 bands) per lane and 16-band block, written once by the scalefactor pass
-// and re-read (coalesced, L2-resident) by each of the 8 subframes.
+// curve->resolution table, bit-feed ring uint32[RING_WORDS][64].  The per-band code descriptions (one byte each: max bits |
+// short-code count << 4, see parse_symbol) live in the tile's `resg` area of scratch: one uint4 (16 bands) per lane and
+// 16-band block, written once by the scalefactor pass and re-read (coalesced, L2-resident) by each of the 8 subframes.
 //
 // Bit feed.  HBM latency under load is microseconds and the parse is an in-order serial chain, so words travel
 //   tile (global) --bulk request at a checkpoint--> VGPRs --landed at the NEXT checkpoint--> per-lane LDS ring
