@@ -149,6 +149,21 @@ def main():
         ent["items"].append({"len": len(it), "sha": sha(it), "kind": "hca" if is_hca else "adx",
                              "decoded_sha": sha(R.hca_decode(it, KEY, subkey) if is_hca else R.adx_decode(it))})
     man["awb"] = ent
+    # info() dictionaries of the reference's Python HCA class (pure Python header parse; the compiled extension stays stubbed)
+    from PyCriCodecs.hca import HCA as RefHCA
+    wl = synth.wav_bytes(synth.pcm16(0, 8992, 2, 48000), 48000, loop=(1000, 8000))
+    py_info = []
+    for label, data, key in [("hca plain", R.hca_encode(synth.wav(0, 3008, 2, 48000), 1), 0),
+                             ("hca encrypted", R.hca_crypt(R.hca_encode(synth.wav(0, 3008, 2, 48000), 1), 1, 56, KEY), KEY),
+                             ("hca encrypted, default key", R.hca_crypt(R.hca_encode(synth.wav(1, 2048, 1, 44100), 3), 1, 56, KEY), 0),
+                             ("hca looped", R.hca_encode(wl, 2), 0),
+                             ("hca v3 forged", hca_forge.forge_v3(R.hca_encode(synth.wav(5, 2500, 2, 48000), 1), 0), 0),
+                             ("wav", synth.wav(2, 1600, 2, 22050), 0), ("wav looped", wl, 0)]:
+        info = RefHCA(data, key=key).info()
+        name = "pyinfo_%02d.bin" % len(py_info)
+        put(name, data)
+        py_info.append({"label": label, "file": name, "key": key, "info": {k: (v if isinstance(v, (int, str, float, bool, type(None))) else repr(v)) for k, v in info.items()}})
+    man["py_info"] = py_info
     # generator-independent known answers
     man["known"] = {"crc16_123456789": 0xFEE8,
                     "adx_coefs": {"500,48000": [7400, -3342], "500,44100": [7334, -3283], "500,22050": [6569, -2634], "0,48000": [8192, -4096]},

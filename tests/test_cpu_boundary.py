@@ -100,3 +100,14 @@ def test_awb_index_matches_reference_reader():
     with pytest.raises(ValueError):
         awb.awb_index(bank[:40])
 
+
+
+def test_info_dictionaries_match_the_reference_class():
+    """HCA.info() of the mirror class against dictionaries captured from the reference's own PyCriCodecs.hca.HCA
+    (tests/golden/make_golden.py): plain / encrypted / default-key / looped / v3.0 HCA headers and WAV inputs."""
+    import golden_util as G
+    from pycricodecs_amd.hca import HCA
+    for ent in G.manifest()["py_info"]:
+        got = HCA(G.load(ent["file"]), key=ent["key"]).info()
+        got = {k: (v if isinstance(v, (int, str, float, bool, type(None))) else repr(v)) for k, v in got.items()}
+        assert got == ent["info"], ent["label"]
