@@ -553,6 +553,8 @@ static int create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->crypt.n_streams = (uint32_t)streams.size(); j->crypt.frames = frames_total;
+    j->crypt.max_frame_size = 0;
+    for (uint32_t fsz : frame_sizes) j->crypt.max_frame_size = std::max(j->crypt.max_frame_size, fsz);
     if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); frame_sizes.push_back(8); }
     if (cipher.empty()) cipher.assign(256, 0);
     int rc = 0;

@@ -73,6 +73,7 @@ struct CryptArgs {
     const uint8_t* cipher_tables;
     const uint32_t* first_frame;   // prefix over streams, n_streams + 1
     uint32_t n_streams, frames;
+    uint32_t max_frame_size;       // largest frame of the job (sizes the wave-per-frame kernel's LDS image)
 };
 void launch_hca_crypt(const CryptArgs& a, hipStream_t s);
 

@@ -85,8 +85,75 @@ __global__ void k_hca_crypt(CryptArgs a) {
     }
     dst[fs - 2] = (uint8_t)(crc >> 8); dst[fs - 1] = (uint8_t)crc;
 }
+// The same work with one WAVE per frame (the kernel above reads and writes single bytes 682 B apart across the lanes):
+// coalesced dword loads into an LDS image of the frame, byte substitution through an LDS copy of the table, CRC16 as one
+// contiguous chunk per lane + a six-step combine  crc(A || B) = crc(A) * x^(8 |B|) + crc(B)  (table-free carry-less
+// multiply modulo x^16 + x^15 + x^2 + 1), coalesced dword stores.  Used whenever the frame fits the LDS image.
+__device__ __forceinline__ uint32_t crc16_step_tf(uint32_t crc, uint32_t b) {
+    const uint32_t t = (crc >> 8) ^ b;
+    return ((crc << 8) & 0xFFFF) ^ (t << 1) ^ (t << 2) ^ ((__builtin_popcount(t) & 1) ? 0x8003u : 0u);
+}
+__device__ __forceinline__ uint32_t gf16_mulmod(uint32_t a, uint32_t b) {      // a * b mod P over GF(2), 16-bit operands
+    uint32_t r = 0;
+#pragma unroll
+    for (int bit = 15; bit >= 0; bit--) {
+        r = ((r << 1) ^ ((r & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+        r ^= (0u - ((b >> bit) & 1u)) & a;
+    }
+    return r;
+}
+__global__ __launch_bounds__(64) void k_hca_crypt_wpf(CryptArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    uint32_t lo = 0, hi = a.n_streams;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.first_frame[mid] <= g) lo = mid; else hi = mid; }
+    const HcaStream st = a.streams[lo];
+    const uint32_t fs = a.frame_sizes[lo], f = g - a.first_frame[lo];
+    const uint8_t* src = a.in + st.src_offset + (uint64_t)f * fs;
+    uint8_t* dst = a.out + st.dst_offset + (uint64_t)f * fs;
+    uint8_t* lut = smem; uint8_t* img = smem + 256;
+    ((uint32_t*)lut)[lane] = ((const uint32_t*)(a.cipher_tables + st.cipher * 256))[lane];
+    wave_lds_sync();
+    const uint32_t n = fs - 2;                                  // bytes under the checksum (hca.cpp:3322-3331); fs >= 8
+    for (uint32_t d = lane; 4 * d < fs; d += 64) {
+        uint32_t v = 0;
+        if (4 * d + 4 <= fs) v = ld_u32_unaligned(src + 4 * d);
+        else for (uint32_t k = 0; 4 * d + k < fs; k++) v |= (uint32_t)src[4 * d + k] << (8 * k);
+        uint32_t o = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t b = (v >> (8 * k)) & 0xFF;
+            o |= (4 * d + k < n ? (uint32_t)lut[b] : b) << (8 * k);
+        }
+        ((uint32_t*)img)[d] = o;
+    }
+    wave_lds_sync();
+    const uint32_t m = (n + 63) / 64, pad = 64 * m - n;         // front-padded with zero bytes (they do not change a zero-init CRC)
+    uint32_t crc = 0;
+    for (uint32_t k = 0; k < m; k++) {
+        const uint32_t j = lane * m + k;
+        crc = crc16_step_tf(crc, j >= pad ? (uint32_t)img[j - pad] : 0u);
+    }
+    uint32_t xp = 1;                                            // x^(8 m) mod P, wave-uniform
+    for (uint32_t i = 0; i < 8 * m; i++) xp = ((xp << 1) ^ ((xp & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 6; k++) {
+        const uint32_t partner = (uint32_t)__shfl_down((int)crc, 1 << k);
+        const uint32_t mul = gf16_mulmod(crc, xp);
+        if ((lane & ((2u << k) - 1)) == 0) crc = mul ^ partner;
+        xp = gf16_mulmod(xp, xp);
+    }
+    crc = (uint32_t)__shfl((int)crc, 0);
+    if (lane == 0) { img[fs - 2] = (uint8_t)(crc >> 8); img[fs - 1] = (uint8_t)crc; }
+    wave_lds_sync();
+    for (uint32_t d = lane; 4 * d + 4 <= fs; d += 64) { const uint32_t w = ((const uint32_t*)img)[d]; __builtin_memcpy(dst + 4 * d, &w, 4); }
+    if (lane < (fs & 3)) { const uint32_t i = (fs & ~3u) + lane; dst[i] = img[i]; }
+}
 void launch_hca_crypt(const CryptArgs& a, hipStream_t s) {
-    if (a.frames) hipLaunchKernelGGL(k_hca_crypt, dim3((a.frames + 63) / 64), dim3(64), 0, s, a);
+    if (!a.frames) return;
+    const size_t lds = 256 + (((size_t)a.max_frame_size + 3) & ~(size_t)3) + 16;
+    if (a.max_frame_size >= 8 && lds <= 64 * 1024) hipLaunchKernelGGL(k_hca_crypt_wpf, dim3(a.frames), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(k_hca_crypt, dim3((a.frames + 63) / 64), dim3(64), 0, s, a);
 }
 
 }  // namespace cri
