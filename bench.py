@@ -331,14 +331,16 @@ def main():
     # HBM bytes of the dominant kernel per launch: PMC counters cannot be collected from inside this process, so the
     # per-frame figure comes from the committed rocprofv3 counter passes of this same command (profiles/, tools/prof_traffic.sh)
     traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_traffic.json")
-    if args.workload == "hca_decode" and os.path.exists(tpath):
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    tpath = tfiles[-1] if tfiles else ""
+    if args.workload == "hca_decode" and args.quality == 1 and tpath:
         with open(tpath) as fh:
             tj = json.load(fh)
         if dom in tj.get("kernels", {}):
             traffic = int(round(tj["kernels"][dom]["hbm_bytes_per_frame"] * units))
-            traffic_src = "profiles/r01_e_traffic.json: %.0f B/frame (FETCH_SIZE x%.0f + WRITE_SIZE, separate --pmc passes) x %d frames" % (
-                tj["kernels"][dom]["hbm_bytes_per_frame"], tj["kernels"][dom]["fetch_correction"], units)
+            traffic_src = "profiles/%s: %.0f B/frame (FETCH_SIZE x%.0f + WRITE_SIZE, separate --pmc passes) x %d frames" % (
+                os.path.basename(tpath), tj["kernels"][dom]["hbm_bytes_per_frame"], tj["kernels"][dom]["fetch_correction"], units)
     out = {
         "metric": "audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline",
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
