@@ -6,8 +6,11 @@
 //   2676-2706, CalculateFrameHeaderLength 2708-2750, CalculateNoiseLevel 2809-2832 / CalculateEvaluationBoundary
 //   2852-2866 (both searches over CalculateUsedBits 2763-2790), CalculateFrameResolutions 2868-2876, QuantizeSpectra
 //   2878-2892 and PackFrame 2894-2963 (incl. the frame CRC16).
-// The frame feeding of Encode/HcaEncode (hca.cpp:2990-3107, non-looping) reduces to "frame f = samples
-// [1024f, 1024f+1024), zero past the end, with the 128 samples before it as the MDCT history" and is done by indexing.
+// The frame feeding of Encode/HcaEncode (hca.cpp:2990-3107) reduces to "frame f = samples [1024f, 1024f+1024) of the
+// input sequence, with the 128 samples before it as the MDCT history"; for looping input the sequence is zeros / the first
+// sample / the main audio / the post-loop audio / zeros (HcaStream::enc_*), and it is all done by indexing.
+// Up to four frames (waves) share a workgroup and its LDS copies of the tables; the MDCT runs in registers (packed fp32,
+// DPP exchanges), the rate loop on register-resident bands.
 //
 // Everything the reference evaluates in floating point is evaluated here with the same single IEEE operations in the
 // same order (sequential sums stay sequential, on one lane); bit allocation is integer work reduced across the wave;
@@ -118,8 +121,7 @@ __device__ __forceinline__ f2 enc_rot(f2 u, float sn, float cs) {
 struct EncLds {
     float* sp;        // [C][8][128] spectra
     float* sc;        // scaled spectra: the same buffer, scaled in place once the unscaled values are no longer needed
-    float* tin;       // [128] windowed MDCT input
-    float* tt;        // [128] DCT work buffer
+    float* tin;       // 1280 B: PCM staging of one MDCT pass (int16[640]); later the frame image `words` (same memory)
     uint32_t* words;  // frame as big-endian 32-bit words
     uint8_t* sfac;    // [C][128]
     uint8_t* res;     // [C][128]
@@ -234,8 +236,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     if (g >= a.frames) return;
     const uint32_t nwords = (F.frame_size + 3) / 4 + 1;
     EncLds L;
-    // the MDCT work buffers (tin, tt: 1 KB) and the output frame image (words) are never live together
-    L.sp = (float*)smem; L.sc = L.sp; L.tin = L.sp + C * 1024; L.tt = L.tin + 128;
+    // the MDCT's PCM staging buffer (tin) and the output frame image (words) are never live together
+    L.sp = (float*)smem; L.sc = L.sp; L.tin = L.sp + C * 1024;
     L.words = (uint32_t*)L.tin; L.havg = (float*)(L.words + (nwords > 320 ? nwords : 320)); L.ratio = L.havg + C * 8;
     L.hfrs = (int*)(L.ratio + 8); L.hbits = L.hfrs + C * 8; L.dbits = L.hbits + C;
     L.sfac = (uint8_t*)(L.dbits + C); L.res = L.sfac + C * 128; L.inten = L.res + C * 128;
@@ -286,7 +288,6 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     // the sum, the other one rotates the difference; the sum/difference is fma(z, +-1, partner) (exact product).
     {
         const uint32_t l16 = lane & 15, slot = lane >> 4;
-        const bool lowhalf_e = l16 < 8;                        // the lane's even inputs k = 8*l16 + 2r are < 64, its odd inputs 127 - k are >= 64
         // window coefficients and sample positions (within the 256 samples [n0-128, n0+128)) of the lane's 8 folded inputs
         float wA[8], wB[8]; int mA[8], mB[8];
 #pragma unroll
@@ -299,7 +300,6 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
             wA[q] = low ? -a : a;                             // hca.cpp:2532: window * -sample
             wB[q] = T.win[low ? 64 + k : 191 - k];
         }
-        (void)lowhalf_e;
         const float sg8 = l16 & 8 ? -1.0f : 1.0f, sg4 = l16 & 4 ? -1.0f : 1.0f, sg2 = l16 & 2 ? -1.0f : 1.0f, sg1 = l16 & 1 ? -1.0f : 1.0f;
         uint32_t opos[8];                                      // where the lane's 8 outputs go in the spectrum (inverse of the final shuffle)
 #pragma unroll
