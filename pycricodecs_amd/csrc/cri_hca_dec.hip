@@ -804,6 +804,8 @@ __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
 #define CRI_TABLE_QUAL static __device__ const
 #include "cri_imdct_tables.h"
 #define HCA_RUN 8
+#define TR_DSTRIDE 144     // floats between the DCT-output ring's rows: the four slots of a pass touch the same columns of four
+                           // rows, and a 128-float stride would put them all on the same LDS banks
 
 #include "cri_dct_lane.h"
 
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x, slot = lane >> 4, l16 = lane & 15;
     TrLds T;
-    T.G = (float*)smem; T.D = T.G + C * 128; T.pcm = (uint16_t*)(T.D + 8 * 128);
+    T.G = (float*)smem; T.D = T.G + C * 128; T.pcm = (uint16_t*)(T.D + 8 * TR_DSTRIDE);
     T.win = (float*)(T.pcm + 512); T.scale = T.win + 128; T.range = T.scale + 64; T.curve = (uint8_t*)(T.range + 16);
     T.hconv = (float*)(T.curve + 80); T.S = T.hconv + C * 128; T.conv = T.S + 512; T.iratio = T.conv + 128;   // !PLAIN only from here
     T.sfb = (uint8_t*)(T.iratio + 16); T.hlow = T.sfb + C * 128; T.hgrp = T.hlow + 128; T.inten = T.hgrp + 128;
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
         tr_load_spectra<PLAIN, C>(F, T, cur, sf, halo && slot >= (uint32_t)C ? 0 : c, slot, l16, nproc, x);
         dct4_inplace(x, L);
         const uint32_t dslot = halo ? ring - C + slot : ring + slot;
-        float* d = T.D + (dslot & 7) * 128;
+        float* d = T.D + (dslot & 7) * TR_DSTRIDE;
         if (!halo || slot < (uint32_t)C) {
 #pragma unroll
             for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r >> 1][r & 1];
@@ -1057,7 +1059,7 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
         if (halo) { pass = 0; f++; rec += F.record_bytes; continue; }
 
         // window + overlap-add (hca.cpp:1987-1992) against the predecessor (same channel, previous subframe)
-        const float* dp = T.D + ((dslot - C) & 7) * 128;
+        const float* dp = T.D + ((dslot - C) & 7) * TR_DSTRIDE;
         const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
         const uint32_t sfl = slot / C;                                             // subframe within this pass
         float o0[4], o1[4];
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
 }
 
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
-    const size_t base = (size_t)C * 128 * 4 + 8 * 128 * 4 + 1024 + 512 + 256 + 64 + 80;
+    const size_t base = (size_t)C * 128 * 4 + 8 * TR_DSTRIDE * 4 + 1024 + 512 + 256 + 64 + 80;
     return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + C * 8 + 64;
 }
 
