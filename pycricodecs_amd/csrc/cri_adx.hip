@@ -280,13 +280,29 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
                 blk[0] = (uint8_t)(word >> 8) | stale; blk[1] = (uint8_t)word;
                 h1 = o1; h2 = o2;
                 if (!scale) scale = 1;
-                const float rcp = 1.0f / (float)scale;
+                const float rcp = 1.0f / (float)scale, half_rcp = 0.5f * rcp;
+                // delta / scale is clamped to [~limit, limit] right after, so only quotients up to limit + 1 matter: with
+                // |delta| capped at (limit + 2) * scale (exact in fp32 for bitdepths <= 8) floor((n + 0.5) / scale) comes out
+                // of one fma and a truncation -- the 0.5 keeps exact quotients >= 1.2e-4 away from an integer, against an
+                // error below 129 * 2^-22.  (Same shortening of the serial chain as in k_adx_encode_wpf.)
+                const bool small = limit <= 127;
+                const int32_t hs = (int32_t)(scale >> 1), cap = (limit + 2) * (int32_t)scale, iscale = (int32_t)scale;
                 uint32_t acc = 0, have = 0, bytepos = 2;
                 for (uint32_t i = 0; i < spb; i++) {                       // pass B (adx.cpp:254-271)
                     const int32_t v = x[(uint64_t)i * C];
-                    int32_t delta = ((int32_t)((uint32_t)v << 12) - c0 * h1 - c1 * h2) >> 12;
-                    delta = delta > 0 ? delta + (int32_t)(scale >> 1) : delta - (int32_t)(scale >> 1);
-                    {   // delta /= scale (truncating), exact: float estimate + correction; |delta| < 2^22 here
+                    const int32_t pred = __mul24(c0, h1) + __mul24(c1, h2);
+                    int32_t delta = ((int32_t)((uint32_t)v << 12) - pred) >> 12;
+                    if (small) {
+                        const bool neg = delta < 0;
+                        int32_t an = (neg ? -delta : delta) + hs;
+                        an = an < cap ? an : cap;
+                        int32_t q = (int32_t)__builtin_fmaf((float)an, rcp, half_rcp);
+                        const int32_t qmax = neg ? limit + 1 : limit;
+                        q = q < qmax ? q : qmax;
+                        delta = neg ? -q : q;
+                    } else {
+                        delta = delta > 0 ? delta + hs : delta - hs;
+                        // delta /= scale (truncating), exact: float estimate + correction; |delta| < 2^22 here
                         const uint32_t an = (uint32_t)(delta < 0 ? -delta : delta);
                         uint32_t q;
                         if (an < (1u << 22)) {
@@ -296,11 +312,11 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
                             if (r >= (int32_t)scale) q++;
                         } else q = an / scale;
                         delta = delta < 0 ? -(int32_t)q : (int32_t)q;
+                        delta = clamp_sym(delta, limit);
                     }
-                    delta = clamp_sym(delta, limit);
-                    int32_t sim = (int32_t)(((uint32_t)delta << 12) * scale + (uint32_t)(c0 * h1) + (uint32_t)(c1 * h2)) >> 12;
+                    int32_t sim = (int32_t)(((uint32_t)__mul24(delta, iscale) << 12) + (uint32_t)pred) >> 12;
                     sim = clamp_sym(sim, 0x7FFF);
-                    h2 = h1; h1 = (int32_t)(int16_t)sim;
+                    h2 = h1; h1 = sim;
                     acc = (acc << bd) | ((uint32_t)delta & ((1u << bd) - 1)); have += bd;
                     while (have >= 8) { blk[bytepos++] = (uint8_t)(acc >> (have - 8)); have -= 8; }
                 }
