@@ -157,6 +157,9 @@ void cri_job_destroy(cri_job* job);
 /* Host-buffer convenience wrapper over a job: upload, run, download.  out_blob/out_offsets are malloc'ed
  * (cri_free); status[n] is caller-provided.  kind-specific arguments are passed through `job`. */
 int cri_job_run_host(cri_job* job, const uint8_t* blob, uint8_t** out_blob, int32_t* status);
+/* the same into a caller-owned buffer of cri_job_output_bytes(job) bytes (reuse it across calls: a fresh allocation of that
+ * size costs more in page faults than the copy itself) */
+int cri_job_run_host_into(cri_job* job, const uint8_t* blob, uint8_t* out, int32_t* status);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ SYMBOLS = [
     "cri_job_create_hca_encode", "cri_job_create_hca_crypt", "cri_job_kind", "cri_job_items", "cri_job_input_bytes",
     "cri_job_output_bytes", "cri_job_output_offsets", "cri_job_host_status", "cri_job_scratch_bytes", "cri_job_units",
     "cri_job_units2", "cri_job_algorithmic_bytes", "cri_job_run", "cri_job_dominant_kernel", "cri_job_destroy", "cri_job_run_host", "cri_job_enable_events",
-    "cri_job_event_ms", "cri_awb_index", "cri_job_create_awb_decode",
+    "cri_job_event_ms", "cri_awb_index", "cri_job_create_awb_decode", "cri_job_run_host_into",
 ]
 
 
@@ -70,6 +70,7 @@ def lib():
     L.cri_job_dominant_kernel.restype = C.c_char_p
     L.cri_job_run.argtypes = [vp, vp, vp, vp, vp, vp]
     L.cri_job_run_host.argtypes = [vp, vp, C.POINTER(u8p), i32p]
+    L.cri_job_run_host_into.argtypes = [vp, vp, vp, i32p]
     L.cri_job_enable_events.argtypes = [vp, C.c_int]
     L.cri_job_event_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int]
     L.cri_job_destroy.argtypes = [vp]

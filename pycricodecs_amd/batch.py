@@ -140,15 +140,16 @@ class Job:
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
     def run_host(self):
-        """Upload, run, download: returns (list of output bytes per item, status int32[n])."""
-        out = C.POINTER(C.c_uint8)()
+        """Upload, run, download: returns (list of outputs per item, status int32[n]).  The outputs are memoryviews into one
+        buffer owned by this Job and reused by its next run_host() call (copy what must outlive it with bytes(...))."""
+        n = max(self.output_bytes, 1)
+        if getattr(self, "_host_out", None) is None or self._host_out.size < n:
+            self._host_out = np.empty(n, dtype=np.uint8)
         status = (C.c_int32 * max(self.n, 1))()
-        rc = _capi.lib().cri_job_run_host(self._h, self.blob if self.blob else b"\0", C.byref(out), status)
+        rc = _capi.lib().cri_job_run_host_into(self._h, self.blob if self.blob else b"\0", self._host_out.ctypes.data, status)
         if rc:
             _capi.raise_for(rc)
-        blob = C.string_at(out, self.output_bytes)
-        _capi.lib().cri_free(out)
-        return self.split(blob), np.array(status[:self.n], dtype=np.int32)
+        return self.split(memoryview(self._host_out)), np.array(status[:self.n], dtype=np.int32)
 
     def item_length(self, blob, i):
         """True byte length of output item i (offsets are 64-byte aligned, so the item carries its own size)."""

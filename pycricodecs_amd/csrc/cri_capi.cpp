@@ -745,11 +745,11 @@ extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int m
     return n;
 }
 
-extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_blob, int32_t* status) {
-    if (!j || !blob || !out_blob) return CRI_ERR_INVALID_ARG;
+// Host buffers in, host buffers out: device allocations, H2D, the job, D2H.  `out` must hold cri_job_output_bytes(job).
+extern "C" int cri_job_run_host_into(cri_job* j, const uint8_t* blob, uint8_t* out, int32_t* status) {
+    if (!j || !blob || (!out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
     void *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr; int32_t* d_st = nullptr;
     int rc = 0;
-    uint8_t* host_out = nullptr;
     auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = CRI_ERR_HIP; return e == hipSuccess; };
     if (ok(hipMalloc(&d_in, j->in_bytes ? j->in_bytes : 1)) && ok(hipMalloc(&d_out, j->out_bytes ? j->out_bytes : 1)) &&
         ok(hipMalloc(&d_scr, j->scratch_bytes ? j->scratch_bytes : 1)) && ok(hipMalloc((void**)&d_st, (j->n ? j->n : 1) * sizeof(int32_t)))) {
@@ -758,9 +758,7 @@ extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_b
         ok(hipMemsetAsync(d_out, 0, j->out_bytes ? j->out_bytes : 1, nullptr));
         if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, nullptr);
         ok(hipDeviceSynchronize());
-        host_out = (uint8_t*)malloc(j->out_bytes ? j->out_bytes : 1);
-        if (!host_out) rc = rc ? rc : CRI_ERR_NOMEM;
-        else ok(hipMemcpy(host_out, d_out, j->out_bytes, hipMemcpyDeviceToHost));
+        if (j->out_bytes) ok(hipMemcpy(out, d_out, j->out_bytes, hipMemcpyDeviceToHost));
         if (status) {
             std::vector<int32_t> st(j->n ? j->n : 1, 0);
             ok(hipMemcpy(st.data(), d_st, j->n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -771,6 +769,14 @@ extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_b
     if (d_out) (void)hipFree(d_out);
     if (d_scr) (void)hipFree(d_scr);
     if (d_st) (void)hipFree(d_st);
+    return rc;
+}
+
+extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_blob, int32_t* status) {
+    if (!j || !blob || !out_blob) return CRI_ERR_INVALID_ARG;
+    uint8_t* host_out = (uint8_t*)malloc(j->out_bytes ? j->out_bytes : 1);
+    if (!host_out) return CRI_ERR_NOMEM;
+    const int rc = cri_job_run_host_into(j, blob, host_out, status);
     if (rc) { free(host_out); return rc; }
     *out_blob = host_out;
     return 0;
