@@ -270,6 +270,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.noise_fill = F.min_res == 0 ? 1 : 0;
+        if (a.noise_fill) a.plain = 0;                                 // noise reconstruction lives in the general variant of the transform
         a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
         b = e;

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     bb.pw = ring[0]; bb.rd = 1; bb.nw = ring[64];
     bb_refill(bb, ring); bb_refill(bb, ring);
     bb_skip(bb, 16);                                             // sync word, checked by k_hca_prepare
-    uint32_t packed = 0, flags = 0;
+    uint32_t packed = 0, flags = 0, draws = 0;
     {
         const uint32_t nl = bb_read(bb, ring, 9), eb = bb_read(bb, ring, 7);   // hca.cpp:1175-1178
         packed = (nl << 8) - eb;
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         uint32_t cs = coded, extra = 0;
         if (!(type == CRI_CH_SECONDARY || groups == 0 || F.version <= 0x0200)) { extra = groups; cs += extra; }
         uint32_t db = bb_read(bb, ring, 3), value = 0;
+        uint32_t n_noise = 0, n_valid = 0;                        // bands reconstruct_noise fills / draws from (hca.cpp:1489-1497)
         if (cs > 128) { status = status ? status : CRI_ERR_HCA_FRAME(5); cs = 0; }
         const uint32_t expected = (1u << db) - 1;
         // scalefactors + resolutions in blocks of 16 bands (the last block is padded with zeros)
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                         const int cp = noise + 1 - (int)((5 * v) >> 1);
                         res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)curve[cp] : 0u);
                         res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+                        n_noise += res == 0 ? 1u : 0u; n_valid += res != 0 ? 1u : 0u;       // (resolution 0 needs min_resolution 0: v3.0)
                     }
                     mw[k >> 2] |= band_meta(res) << (8 * (k & 3));
                 }
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             inten_hi = iv[4] | (iv[5] << 8) | (iv[6] << 16) | ((uint32_t)iv[7] << 24);
         }
         if (valid) { uint32_t* ip = (uint32_t*)(rec + HCA_REC_INT(C, c)); ip[0] = inten_lo; ip[1] = inten_hi; }
+        draws += (n_noise > 0 && n_valid > 0) ? 8 * n_noise : 0u;   // generator draws of this channel in the frame's 8 subframes (hca.cpp:1608-1633)
     }
     // ---- spectra: 8 subframes x C channels x coded symbols, serial per lane (hca.cpp:1194-1199, 1540-1571),
     //      in blocks of 16 symbols; bands past `coded` carry resolution 0 = no bits
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     }
     if (valid) {
         uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
-        tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags; tail[3] = (uint32_t)bb.pos;
+        tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags; tail[3] = draws;      // k_hca_noise_scan turns tail[3] into a prefix
     }
 }
 
@@ -769,22 +772,23 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
 }
 
 // Streams with min_resolution == 0 (v3.0): the noise generator runs on across the frames of a stream (hca.cpp:1616, 1633),
-// so every frame needs the number of draws all earlier frames made.  One wave per stream walks its records and leaves
-// that count in tail[3]; the transform then jumps the generator there (lcg_jump).
+// so every frame needs the number of draws all earlier frames made.  k_hca_parse leaves each frame's own count in tail[3];
+// one wave per stream turns them into exclusive prefixes, 64 frames per step (the transform then jumps the generator
+// there with lcg_jump).
 __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t C = F.channels, lane = threadIdx.x;
     const HcaStream st = a.streams[a.stream_begin + blockIdx.x];
-    const uint8_t* ath = a.ath_tables + F.ath_index * 128;
     uint32_t total = 0;
-    for (uint32_t f = 0; f < st.frames; f++) {
-        uint8_t* rec = a.scratch + st.scratch_offset + (uint64_t)f * F.record_bytes;
-        uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
-        if ((int32_t)tail[1] != 0) break;                  // nothing past a failed frame is decoded
-        if (lane == 0) tail[3] = total;
-        uint32_t per_sf = 0;
-        for (uint32_t c = 0; c < C; c++) per_sf += noise_lists(F, ath, rec, C, c, lane, nullptr, nullptr, nullptr);
-        total += 8 * per_sf;
+    for (uint32_t f0 = 0; f0 < st.frames; f0 += 64) {
+        const uint32_t f = f0 + lane;
+        uint32_t* tail = (uint32_t*)(a.scratch + st.scratch_offset + (uint64_t)(f < st.frames ? f : f0) * F.record_bytes + HCA_REC_TAIL(C));
+        const uint32_t own = f < st.frames ? tail[3] : 0u;
+        uint32_t incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); incl += (int)lane >= o ? t : 0u; }
+        if (f < st.frames) tail[3] = total + incl - own;
+        total += (uint32_t)__shfl((int)incl, 63);
     }
 }
 
@@ -820,6 +824,10 @@ struct TrLds {
     uint8_t* hlow;     // [128] source band of a reconstructed band (format constant)
     uint8_t* hgrp;     // [128] HFR group of a reconstructed band (format constant)
     uint8_t* inten;    // [C][8]
+    // v3.0 noise reconstruction (min_resolution == 0) only:
+    uint8_t* vlist;    // [C][128] valid bands in ascending order
+    uint8_t* nrank;    // [C][128] rank of a noise band among the channel's noise bands (0xFF: not a noise band)
+    uint32_t* nmeta;   // [C][4] = {noise_count, valid_count, draws of the lower channels in a subframe, draws of this channel}; then [per_sf, generator state at the frame's start]
     float* D;          // [8][128] ring of DCT outputs in logical order
     uint16_t* pcm;     // [512] int16 staging of one pass
     float* win;        // [128] synthesis window
@@ -830,14 +838,14 @@ struct TrLds {
 
 // what the per-frame setup needs from the frame record, fetched one frame ahead so its latency hides behind the
 // previous frame's transforms
-template <int C> struct FramePre { uint32_t packed; int32_t status; uint32_t flags; uint32_t ib; uint32_t sf2[C]; };
+template <int C> struct FramePre { uint32_t packed; int32_t status; uint32_t flags; uint32_t ib; uint32_t noise0; uint32_t sf2[C]; };
 template <bool PLAIN, int C>
 __device__ __forceinline__ FramePre<C> tr_prefetch_frame(const uint8_t* rec, uint32_t lane) {
     FramePre<C> p;
     const uint32_t* tail = (const uint32_t*)(rec + HCA_REC_TAIL(C));
     p.packed = tail[0]; p.status = (int32_t)tail[1];
-    p.flags = 0; p.ib = 0;
-    if (!PLAIN) { p.flags = tail[2]; p.ib = rec[HCA_REC_INT(C, 0) + (lane & (C * 8 - 1))]; }   // intensity byte (channel lane >> 3, index lane & 7)
+    p.flags = 0; p.ib = 0; p.noise0 = 0;
+    if (!PLAIN) { p.flags = tail[2]; p.noise0 = tail[3]; p.ib = rec[HCA_REC_INT(C, 0) + (lane & (C * 8 - 1))]; }   // intensity byte (channel lane >> 3, index lane & 7)
 #pragma unroll
     for (int c = 0; c < C; c++) p.sf2[c] = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
     return p;
@@ -888,6 +896,41 @@ __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, con
                 }
             }
         }
+        if (F.min_res == 0) {
+            // v3.0 noise reconstruction (hca.cpp:1489-1497 lists, 1602-1635 use): per channel the noise bands (scalefactor > 0,
+            // resolution 0) in band order and the valid bands; every (subframe, channel) draws noise_count numbers, in
+            // subframe-major order, from a generator whose state at the frame's start is jumped to from k_hca_noise_scan's count
+            uint32_t per_sf = 0;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint32_t sf2 = pre.sf2[c], coded = F.coded(c);
+                bool isn[2], isv[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t i = 2 * lane + h, v = (sf2 >> (8 * h)) & 0xFF;
+                    const int noise = (int)((ath2 >> (8 * h)) & 0xFF) + (int)((packed + i) >> 8);
+                    const int cp = noise + 1 - (int)((5 * v) >> 1);
+                    const int cpc = cp < 0 ? 0 : (cp > 65 ? 65 : cp);
+                    uint32_t res = T.curve[cpc];
+                    res = cp < 0 ? 15u : (cp > 65 ? 0u : res);
+                    res = res > F.max_res ? F.max_res : res;
+                    const bool live = i < coded && v > 0;
+                    isn[h] = live && res < 1; isv[h] = live && res >= 1;
+                }
+                const uint64_t below = (1ull << lane) - 1;
+                const uint64_t bn0 = __ballot(isn[0]), bn1 = __ballot(isn[1]), bv0 = __ballot(isv[0]), bv1 = __ballot(isv[1]);
+                const uint32_t nc = __popcll(bn0) + __popcll(bn1), vc = __popcll(bv0) + __popcll(bv1);
+                const uint32_t rn = __popcll(bn0 & below) + __popcll(bn1 & below), rv = __popcll(bv0 & below) + __popcll(bv1 & below);
+                T.nrank[c * 128 + 2 * lane] = isn[0] ? (uint8_t)rn : (uint8_t)0xFF;
+                T.nrank[c * 128 + 2 * lane + 1] = isn[1] ? (uint8_t)(rn + (isn[0] ? 1 : 0)) : (uint8_t)0xFF;
+                if (isv[0]) T.vlist[c * 128 + rv] = (uint8_t)(2 * lane);
+                if (isv[1]) T.vlist[c * 128 + rv + (isv[0] ? 1 : 0)] = (uint8_t)(2 * lane + 1);
+                const uint32_t nd = (nc > 0 && vc > 0) ? nc : 0;
+                if (lane == 0) { T.nmeta[c * 4] = nc; T.nmeta[c * 4 + 1] = vc; T.nmeta[c * 4 + 2] = per_sf; T.nmeta[c * 4 + 3] = nd; }
+                per_sf += nd;
+            }
+            if (lane == 0) { T.nmeta[C * 4] = per_sf; T.nmeta[C * 4 + 1] = lcg_jump(1u, __builtin_amdgcn_readfirstlane(pre.noise0)); }
+        }
         // intensity indexes (hca.cpp:1361-1441): the prefetched byte; 0xFF = "keeps its previous value" (rare), resolved by
         // walking back through the stream's records
         if (lane < C * 8) T.inten[lane] = intensity_walk_back(F, rec0, f, C, lane >> 3, lane & 7, (uint8_t)pre.ib);
@@ -931,6 +974,38 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
     *(float4*)(srow + l16 * 8) = make_float4(own[0], own[1], own[2], own[3]);
     *(float4*)(srow + l16 * 8 + 4) = make_float4(own[4], own[5], own[6], own[7]);
     wave_lds_sync();
+    if (F.min_res == 0) {                                                        // reconstruct_noise, hca.cpp:1602-1635
+        const uint32_t vc = T.nmeta[c * 4 + 1], nd = T.nmeta[c * 4 + 3];
+        const uint2 rk = *(const uint2*)(T.nrank + c * 128 + l16 * 8);             // ranks of the lane's 8 bands
+        uint32_t kfirst = 0xFF;
+#pragma unroll
+        for (int r = 7; r >= 0; r--) { const uint32_t k = ((r < 4 ? rk.x : rk.y) >> (8 * (r & 3))) & 0xFF; kfirst = k != 0xFF ? k : kfirst; }
+        const bool mine = nd > 0 && kfirst != 0xFF;
+        if (__any(mine)) {
+            // draw k+1 of (subframe, channel) belongs to its noise band of rank k; a lane's noise bands have consecutive ranks
+            const uint32_t base = lcg_jump(T.nmeta[C * 4 + 1], sf * T.nmeta[C * 4] + T.nmeta[c * 4 + 2]);
+            uint32_t rcur = lcg_jump(base, (kfirst & 0x7F) + 1);
+            bool started = false;
+            const uint8_t* sfb = T.sfb + c * 128;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t b = l16 * 8 + r, k = ((r < 4 ? rk.x : rk.y) >> (8 * (r & 3))) & 0xFF;
+                const bool isn = mine && k != 0xFF;
+                const uint32_t rnext = rcur * 0x343FDu + 0x269EC3u;
+                rcur = (isn && started) ? rnext : rcur;
+                started = started || isn;
+                const uint32_t vi = T.vlist[c * 128 + ((vc - 1 - (((rcur & 0x7FFF) * vc) >> 15)) & 127)];
+                int sc = (int)sfb[b] - (int)sfb[vi & 127] + 62;
+                sc = sc & ~(sc >> 31);
+                const float nv = T.conv[sc & 127] * srow[vi & 127];
+                own[r] = isn ? nv : own[r];
+            }
+        }
+        wave_lds_sync();                                                         // (valid bands are never rewritten: reads above saw coded values)
+        *(float4*)(srow + l16 * 8) = make_float4(own[0], own[1], own[2], own[3]);
+        *(float4*)(srow + l16 * 8 + 4) = make_float4(own[4], own[5], own[6], own[7]);
+        wave_lds_sync();
+    }
     const bool stereo = F.stereo_bands > 0, hfr = F.bands_per_hfr_group > 0;
     const uint32_t cp = secondary && c > 0 ? c - 1 : c;                          // channel whose lines the shared bands come from
     const float* prow = secondary && slot > 0 ? srow - 128 : srow;
@@ -973,6 +1048,7 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
     T.win = (float*)(T.pcm + 512); T.scale = T.win + 128; T.range = T.scale + 64; T.curve = (uint8_t*)(T.range + 16);
     T.hconv = (float*)(T.curve + 80); T.S = T.hconv + C * 128; T.conv = T.S + 512; T.iratio = T.conv + 128;   // !PLAIN only from here
     T.sfb = (uint8_t*)(T.iratio + 16); T.hlow = T.sfb + C * 128; T.hgrp = T.hlow + 128; T.inten = T.hgrp + 128;
+    T.nmeta = (uint32_t*)(T.inten + ((C * 8 + 15) & ~15)); T.vlist = (uint8_t*)(T.nmeta + C * 4 + 4); T.nrank = T.vlist + C * 128;
 
     // run -> stream, first frame
     uint32_t lo = a.stream_begin, hi = a.stream_end;
@@ -1116,13 +1192,13 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
 
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + 8 * TR_DSTRIDE * 4 + 1024 + 512 + 256 + 64 + 80;
-    return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + C * 8 + 64;
+    return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + ((C * 8 + 15) & ~15) + (C * 4 + 4) * 4 + 2 * C * 128 + 64;
 }
 
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
-    if (!a.noise_fill && (a.channels == 1 || a.channels == 2 || a.channels == 4)) {
+    if (a.channels == 1 || a.channels == 2 || a.channels == 4) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
 #define CRI_LAUNCH_TR(P, CH) hipLaunchKernelGGL((k_hca_transform<P, CH>), dim3(a.runs), dim3(64), lds, s, a)
         if (a.plain) { if (a.channels == 1) CRI_LAUNCH_TR(true, 1); else if (a.channels == 2) CRI_LAUNCH_TR(true, 2); else CRI_LAUNCH_TR(true, 4); }
