@@ -352,9 +352,16 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                         const int cp = noise + 1 - (int)((5 * v) >> 1);
                         res = cp < 0 ? 15u : (cp <= 65 ? (uint32_t)curve[cp] : 0u);
                         res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
-                        n_noise += res == 0 ? 1u : 0u; n_valid += res != 0 ? 1u : 0u;       // (resolution 0 needs min_resolution 0: v3.0)
                     }
                     mw[k >> 2] |= band_meta(res) << (8 * (k & 3));
+                }
+            }
+            if (F.min_res == 0) {                                 // v3.0 only: count the noise / valid bands from the block's bytes
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) {
+                    const bool live = blk * 16 + k < coded && ((sfw[k >> 2] >> (8 * (k & 3))) & 0xFF) != 0;
+                    const bool coded_res = ((mw[k >> 2] >> (8 * (k & 3))) & 0xFF) != 0;      // band_meta(0) == 0
+                    n_noise += live && !coded_res ? 1u : 0u; n_valid += live && coded_res ? 1u : 0u;
                 }
             }
             metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
