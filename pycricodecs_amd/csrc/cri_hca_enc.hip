@@ -220,7 +220,7 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 }
 
 #define ENC_WAVES 4     // most frames (waves) per workgroup; they share the LDS tables and are otherwise independent
-// CT = 1 or 2: channel count known at compile time, the rate loop keeps the lane's bands in registers; CT = 0: any count
+// CT = 1, 2, 4, 6, 8: channel count known at compile time, the rate loop keeps the lane's bands in registers; CT = 0: any count
 template <int CT>
 __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
@@ -782,9 +782,14 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
     if (!w) return;
     const dim3 grid((a.frames + w - 1) / w), block(64 * w);
     const size_t lds = hca_encode_lds_bytes(a.channels, a.frame_size);
-    if (a.channels == 1) hipLaunchKernelGGL(k_hca_encode<1>, grid, block, lds, s, b);
-    else if (a.channels == 2) hipLaunchKernelGGL(k_hca_encode<2>, grid, block, lds, s, b);
-    else hipLaunchKernelGGL(k_hca_encode<0>, grid, block, lds, s, b);
+    switch (a.channels) {                                      // register-resident rate loop for the usual layouts
+        case 1: hipLaunchKernelGGL(k_hca_encode<1>, grid, block, lds, s, b); break;
+        case 2: hipLaunchKernelGGL(k_hca_encode<2>, grid, block, lds, s, b); break;
+        case 4: hipLaunchKernelGGL(k_hca_encode<4>, grid, block, lds, s, b); break;
+        case 6: hipLaunchKernelGGL(k_hca_encode<6>, grid, block, lds, s, b); break;
+        case 8: hipLaunchKernelGGL(k_hca_encode<8>, grid, block, lds, s, b); break;
+        default: hipLaunchKernelGGL(k_hca_encode<0>, grid, block, lds, s, b); break;
+    }
 }
 
 }  // namespace cri
