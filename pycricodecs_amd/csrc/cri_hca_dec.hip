@@ -12,9 +12,9 @@
 //   k_hca_transform<PLAIN, C>  calculate_gain (1498-1507), the float half of dequantize (1566),
 //                    reconstruct_high_frequency (1638-1683), apply_intensity_stereo (1696-1714), imdct_transform
 //                    (1898-2019), clHCA_ReadSamples16 (339-360) and HcaDecode's delay/trim (3401-3452).  One WAVE per run of
-//                    8 frames, four transforms at a time in registers (1, 2 or 4 channels).
-//   k_hca_transform_generic    the same for any channel count and for v3.0 noise reconstruction (1602-1635), one wave per
-//                    frame through LDS; k_hca_noise_scan gives it the generator state each frame starts from.
+//                    8 frames, four transforms at a time in registers (1, 2, 4, 6 or 8 channels).
+//   k_hca_transform_generic    the same for any other channel layout, one wave per frame, spectra assembled in LDS
+//                    (the DCT is the same register network); k_hca_noise_scan gives it the generator state each frame starts from.
 // All float work is single IEEE binary32 operations in the reference's order (compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include "cri_kernels.h"
@@ -480,36 +480,20 @@ void launch_hca_parse(const HcaDecArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 // HCA transform: one wave per frame
 // ------------------------------------------------------------------------------------------------------------
-// LDS (floats): S[C][128] spectra / dct, G[C][128] gains, P[C][128] overlap tail, T[128] ping-pong partner.
+// LDS (floats): S[C][128] spectra, G[C][128] gains, D[2][C][TR_DSTRIDE] DCT outputs of this and the previous subframe.
 __device__ __forceinline__ int32_t cvt_trunc_x86(float v) {
     // (int)v as the x86-64 reference build evaluates it: out-of-range and NaN give INT_MIN
     return (v >= -2147483648.0f && v < 2147483648.0f) ? (int32_t)v : (int32_t)0x80000000;
 }
 
-// 128-point DCT-IV of hca.cpp:1898-1980 on LDS buffers x (in/out) and y (scratch); lane m owns pair m.
-__device__ __forceinline__ void imdct_dct4(float* x, float* y, uint32_t m, const float tw_s[7], const float tw_c[7]) {
-#pragma unroll
-    for (int i = 0; i < 7; i++) {                     // sum / difference stages
-        const uint32_t c = 64u >> i;
-        const uint32_t j = m >> (6 - i), k = m & (c - 1);
-        float p = x[2 * m], q = x[2 * m + 1];
-        y[2 * c * j + k] = p + q;
-        y[2 * c * j + c + k] = p - q;
-        wave_lds_sync();
-        float* t = x; x = y; y = t;
-    }
-#pragma unroll
-    for (int i = 0; i < 7; i++) {                     // rotation stages
-        const uint32_t c = 1u << i;
-        const uint32_t j = m >> i, k = m & (c - 1);
-        float p = x[2 * c * j + k], q = x[2 * c * j + c + k];
-        float ps = p * tw_s[i], qc = q * tw_c[i], pc = p * tw_c[i], qs = q * tw_s[i];
-        y[2 * c * j + k] = ps - qc;
-        y[2 * c * j + 2 * c - 1 - k] = pc + qs;
-        wave_lds_sync();
-        float* t = x; x = y; y = t;
-    }
-}
+#undef CRI_TABLE_QUAL
+#define CRI_TABLE_QUAL static __device__ const
+#include "cri_imdct_tables.h"
+#define HCA_RUN 8
+#define TR_DSTRIDE 144     // floats between the DCT-output ring's rows: the four slots of a pass touch the same columns of four
+                           // rows, and a 128-float stride would put them all on the same LDS banks
+
+#include "cri_dct_lane.h"
 
 struct TransformCtx {
     const Fmt* F; const uint8_t* ath; float* S; float* G; uint32_t C, lane;
@@ -701,9 +685,10 @@ __device__ __forceinline__ void resolve_intensity(const Fmt& F, const uint8_t* r
 __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     const Fmt F = load_fmt(a.formats + a.format);
-    const uint32_t C = F.channels, lane = threadIdx.x, g = blockIdx.x;
-    float* S = fsm; float* G = S + C * 128; float* P = G + C * 128; float* T = P + C * 128;
-    uint8_t* inten = (uint8_t*)(T + 128);           // [C][8]
+    const uint32_t C = F.channels, lane = threadIdx.x, g = blockIdx.x, slot = lane >> 4, l16 = lane & 15;
+    float* S = fsm; float* G = S + C * 128; float* D = G + C * 128;           // D[2][C][TR_DSTRIDE]
+    uint16_t* pcms = (uint16_t*)(D + 2 * C * TR_DSTRIDE);                      // [128][C] one subframe of interleaved PCM16
+    uint8_t* inten = (uint8_t*)(pcms + 128 * C);      // [C][8]
     uint32_t* ncnt = (uint32_t*)(inten + ((C * 8 + 15) & ~15u));          // [C][2]
     uint8_t* vlist = (uint8_t*)(ncnt + 2 * C); uint8_t* nrank = vlist + C * 128;
     const uint32_t si = find_stream(a.streams, a.stream_begin, a.stream_end, g);
@@ -715,15 +700,36 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     if (status != 0) { if (lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
     if (f > 0 && (int32_t)((const uint32_t*)(rec - F.record_bytes + HCA_REC_TAIL(C)))[1] != 0) return;
 
-    float tw_s[7], tw_c[7];
+    DctLane L;
+    dct_lane_init(L, l16, HCA_DCT_LANE_SIN, HCA_DCT_LANE_COS);
+    const uint2 dlogp = *(const uint2*)(HCA_DCT_LOGICAL + l16 * 8);          // 8 logical indexes, one byte each
+    float w_lo[4], w_hi[4], w_rlo[4], w_rhi[4];                              // window (hca.cpp:1987-1992) at i, i+64, 63-i, 127-i
 #pragma unroll
-    for (int i = 0; i < 7; i++) { tw_s[i] = HCA_IMDCT_SIN[i][lane]; tw_c[i] = HCA_IMDCT_COS[i][lane]; }
-    const float w0 = HCA_WINDOW[lane], w1 = HCA_WINDOW[lane + 64], w2 = HCA_WINDOW[127 - lane], w3 = HCA_WINDOW[63 - lane];
+    for (int m = 0; m < 4; m++) {
+        const int i = (int)l16 + 16 * m;
+        w_lo[m] = HCA_WINDOW[i]; w_hi[m] = HCA_WINDOW[i + 64]; w_rlo[m] = HCA_WINDOW[63 - i]; w_rhi[m] = HCA_WINDOW[127 - i];
+    }
     TransformCtx X; X.F = &F; X.ath = a.ath_tables + F.ath_index * 128; X.S = S; X.G = G; X.C = C; X.lane = lane;
     X.noise = a.noise_fill != 0; X.vlist = vlist; X.nrank = nrank; X.ncnt = ncnt;
     uint32_t rnd = 1;                                // hca.cpp:961 (random = 1 at decoder reset)
 
-    // overlap tail from the previous frame's last subframe (hca.cpp:1990-1991); zeros at stream start (hca.cpp:962)
+    // DCT-IV of the C spectra in S, four channels at a time (one per 16 lanes), into row set `set` of D
+    auto dct_rows = [&](uint32_t set) {
+        for (uint32_t c0 = 0; c0 < C; c0 += 4) {
+            const uint32_t c = c0 + slot, cc = c < C ? c : C - 1;
+            const float4 s0 = *(const float4*)(S + cc * 128 + l16 * 8), s1 = *(const float4*)(S + cc * 128 + l16 * 8 + 4);
+            f2 x[4] = {f2{s0.x, s0.y}, f2{s0.z, s0.w}, f2{s1.x, s1.y}, f2{s1.z, s1.w}};
+            dct4_inplace(x, L);
+            float* d = D + (set * C + cc) * TR_DSTRIDE;
+            if (c < C) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r >> 1][r & 1];
+            }
+        }
+        wave_lds_sync();
+    };
+
+    // overlap tail: the previous frame's last subframe (hca.cpp:1990-1991); zeros at stream start (hca.cpp:962)
     if (f > 0) {
         const uint8_t* prec = rec - F.record_bytes;
         resolve_intensity(F, rec0, f - 1, C, lane, inten);
@@ -735,15 +741,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
         }
         wave_lds_sync();
         frame_spectra(X, prec, 7, inten, rnd);
-        for (uint32_t c = 0; c < C; c++) {
-            imdct_dct4(S + c * 128, T, lane, tw_s, tw_c);
-            const float* dct = S + c * 128;
-            float p0 = w2 * dct[63 - lane], p1 = w3 * dct[lane];
-            P[c * 128 + lane] = p0; P[c * 128 + 64 + lane] = p1;
-        }
-        wave_lds_sync();
-    } else {
-        for (uint32_t c = 0; c < C; c++) { P[c * 128 + lane] = 0.0f; P[c * 128 + 64 + lane] = 0.0f; }
+        dct_rows(1);
     }
     resolve_intensity(F, rec0, f, C, lane, inten);
     frame_gains(X, rec);
@@ -752,29 +750,44 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
         rnd = lcg_jump(1, ((const uint32_t*)(rec + HCA_REC_TAIL(C)))[3]);
     }
     wave_lds_sync();
-    int16_t* pcm = (int16_t*)(a.out + st.dst_offset);
+    const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
+    uint8_t* dst = a.out + st.dst_offset;
     for (uint32_t sf = 0; sf < 8; sf++) {
         frame_spectra(X, rec, sf, inten, rnd);
-        for (uint32_t c = 0; c < C; c++) {
-            imdct_dct4(S + c * 128, T, lane, tw_s, tw_c);
-            const float* dct = S + c * 128;
-            // window + overlap-add (hca.cpp:1987-1992)
-            float a0 = w0 * dct[lane + 64] + P[c * 128 + lane];
-            float a1 = w1 * dct[127 - lane] - P[c * 128 + 64 + lane];
-            float p0 = w2 * dct[63 - lane], p1 = w3 * dct[lane];
-            P[c * 128 + lane] = p0; P[c * 128 + 64 + lane] = p1;
-            // PCM16 (hca.cpp:339-360) + delay / length trim (hca.cpp:3392-3425)
+        const uint32_t set = sf & 1;
+        dct_rows(set);
+        const bool have_prev = !(f == 0 && sf == 0);
+        for (uint32_t c0 = 0; c0 < C; c0 += 4) {
+            const uint32_t c = c0 + slot, cc = c < C ? c : C - 1;
+            const float* d = D + (set * C + cc) * TR_DSTRIDE;
+            const float* dp = D + ((set ^ 1) * C + cc) * TR_DSTRIDE;
+            // window + overlap-add (hca.cpp:1987-1992), PCM16 (hca.cpp:339-360)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t n = f * 1024 + sf * 128 + lane + 64 * h;
-                if (n >= st.delay && n - st.delay < st.samples) {
-                    int32_t q = cvt_trunc_x86((h ? a1 : a0) * 32768.0f);
-                    q = q > 32767 ? 32767 : (q < -32768 ? -32768 : q);
-                    pcm[(uint64_t)(n - st.delay) * C + c] = (int16_t)q;
-                }
+            for (int m = 0; m < 4; m++) {
+                const int i = (int)l16 + 16 * m;
+                const float t0 = w_rhi[m] * dp[63 - i], t1 = w_rlo[m] * dp[i];
+                const float p0 = have_prev ? t0 : 0.0f, p1 = have_prev ? t1 : 0.0f;
+                const float o0 = (w_lo[m] * d[i + 64] + p0) * 32768.0f;
+                const float o1 = (w_hi[m] * d[127 - i] - p1) * 32768.0f;
+                int32_t q0 = cvt_trunc_x86(o0), q1 = cvt_trunc_x86(o1);
+                q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
+                q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
+                if (c < C) { pcms[i * C + c] = (uint16_t)(int16_t)q0; pcms[(i + 64) * C + c] = (uint16_t)(int16_t)q1; }
             }
         }
         wave_lds_sync();
+        // 256*C contiguous bytes of interleaved PCM16 per subframe; delay / length trim of hca.cpp:3392-3425
+        const uint32_t n0 = f * 1024 + sf * 128;
+        if (dword_ok && n0 >= st.delay && n0 + 128 - st.delay <= st.samples) {
+            uint32_t* q = (uint32_t*)(dst + (uint64_t)(n0 - st.delay) * C * 2);
+            for (uint32_t k = 0; k < C; k++) q[k * 64 + lane] = ((const uint32_t*)pcms)[k * 64 + lane];
+        } else {
+            for (uint32_t e = lane; e < 128 * C; e += 64) {
+                const uint32_t n = n0 + e / C;
+                if (n >= st.delay && n - st.delay < st.samples) ((uint16_t*)dst)[(uint64_t)(n - st.delay) * C + e % C] = pcms[e];
+            }
+        }
+        // (pcms is next written after the syncs of the next subframe's spectra and DCT)
     }
 }
 
@@ -800,7 +813,8 @@ __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_hca_transform: register-resident IMDCT, wavefront shuffles for the butterflies (1, 2 or 4 channels)
+// k_hca_transform: register-resident IMDCT, wavefront shuffles for the butterflies (1, 2, 4 channels; 6, 8 when every
+// stereo pair starts on an even channel, so that a pair always shares a pass)
 // ------------------------------------------------------------------------------------------------------------
 // A wave owns a run of up to HCA_RUN consecutive frames of one stream and walks its 8*C transforms per frame four at a
 // time: transform slot j = lane >> 4, and the 16 lanes of a slot hold the 128 spectral lines of that transform, 8
@@ -811,14 +825,6 @@ __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
 // the DCT outputs of a transform and of its predecessor (same channel, previous subframe) from a small LDS ring; the
 // predecessor of a run's first subframe is recomputed from the previous frame's last subframe (a halo pass), so frames
 // stay independent.  PCM16 is assembled in LDS and stored 256 contiguous bytes per wave instruction.
-#undef CRI_TABLE_QUAL
-#define CRI_TABLE_QUAL static __device__ const
-#include "cri_imdct_tables.h"
-#define HCA_RUN 8
-#define TR_DSTRIDE 144     // floats between the DCT-output ring's rows: the four slots of a pass touch the same columns of four
-                           // rows, and a 128-float stride would put them all on the same LDS banks
-
-#include "cri_dct_lane.h"
 
 struct TrLds {
     float* G;          // [C][128] gains of the current frame
@@ -852,7 +858,7 @@ __device__ __forceinline__ FramePre<C> tr_prefetch_frame(const uint8_t* rec, uin
     const uint32_t* tail = (const uint32_t*)(rec + HCA_REC_TAIL(C));
     p.packed = tail[0]; p.status = (int32_t)tail[1];
     p.flags = 0; p.ib = 0; p.noise0 = 0;
-    if (!PLAIN) { p.flags = tail[2]; p.noise0 = tail[3]; p.ib = rec[HCA_REC_INT(C, 0) + (lane & (C * 8 - 1))]; }   // intensity byte (channel lane >> 3, index lane & 7)
+    if (!PLAIN) { p.flags = tail[2]; p.noise0 = tail[3]; p.ib = rec[HCA_REC_INT(C, 0) + (lane < C * 8 ? lane : 0)]; }   // intensity byte (channel lane >> 3, index lane & 7)
 #pragma unroll
     for (int c = 0; c < C; c++) p.sf2[c] = ((const uint16_t*)(rec + HCA_REC_SF(C, c)))[lane];
     return p;
@@ -1046,13 +1052,15 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
 // frame's last subframe, which only feeds the overlap ring -- and steps 0 .. nf*2C-1 are the passes of the run's frames.
 // (the !PLAIN variants carry ~11 KB of LDS per wave, which already limits them to 3.5 waves per SIMD: give them the registers)
 template <bool PLAIN, int C>
-__global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs a) {
+__global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transform(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x, slot = lane >> 4, l16 = lane & 15;
     TrLds T;
-    T.G = (float*)smem; T.D = T.G + C * 128; T.pcm = (uint16_t*)(T.D + 8 * TR_DSTRIDE);
-    T.win = (float*)(T.pcm + 512); T.scale = T.win + 128; T.range = T.scale + 64; T.curve = (uint8_t*)(T.range + 16);
+    constexpr uint32_t RING = C > 4 ? 16 : 8;              // rows of the DCT-output ring: a pass's four plus the C predecessors
+    constexpr uint32_t HALO_STEPS = (C + 3) / 4;
+    T.G = (float*)smem; T.D = T.G + C * 128; T.pcm = (uint16_t*)(T.D + RING * TR_DSTRIDE);
+    T.win = (float*)(T.pcm + (C > 4 ? 256 * C : 512)); T.scale = T.win + 128; T.range = T.scale + 64; T.curve = (uint8_t*)(T.range + 16);
     T.hconv = (float*)(T.curve + 80); T.S = T.hconv + C * 128; T.conv = T.S + 512; T.iratio = T.conv + 128;   // !PLAIN only from here
     T.sfb = (uint8_t*)(T.iratio + 16); T.hlow = T.sfb + C * 128; T.hgrp = T.hlow + 128; T.inten = T.hgrp + 128;
     T.nmeta = (uint32_t*)(T.inten + ((C * 8 + 15) & ~15)); T.vlist = (uint8_t*)(T.nmeta + C * 4 + 4); T.nrank = T.vlist + C * 128;
@@ -1108,43 +1116,50 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
     const uint8_t* rec = rec0 + (uint64_t)f_first * F.record_bytes;         // record of the step's frame
     FramePre<C> pre = tr_prefetch_frame<PLAIN, C>(rec, lane);
     TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, rec, 7, slot < (uint32_t)C ? slot : 0, l16) : tr_fetch<PLAIN, C>(F, rec, slot / C, slot % C, l16);
-    uint32_t f = f_first, pass = has_halo ? PASSES : 0;    // pass == PASSES marks the halo step
-    uint32_t ring = 8;                                     // ring position of a normal step's slot 0
+    uint32_t f = f_first, pass = has_halo ? PASSES : 0;    // pass >= PASSES marks the halo steps (four channels each)
+    uint32_t ring = RING;                                   // ring position of a normal step's slot 0
     const uint32_t f_end = f0 + nf;
 
 #pragma unroll 1
     while (f < f_end) {
-        const bool halo = pass == PASSES;
-        if (halo || pass == 0) {                           // entering a frame
+        const bool halo = pass >= PASSES;
+        const uint32_t hc = (pass - PASSES) * 4 + slot;    // halo step: channel of this slot
+        const bool hact = hc < (uint32_t)C;
+        if ((halo && pass == PASSES) || pass == 0) {       // entering a frame
             const FramePre<C> cur_pre = pre;
             const int32_t status = __builtin_amdgcn_readfirstlane(cur_pre.status);
             if (status != 0) { if (!halo && lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
             if (f + 1 < f_end) pre = tr_prefetch_frame<PLAIN, C>(rec + F.record_bytes, lane);
             tr_setup_frame<PLAIN, C>(F, T, rec0, f, lane, nproc, cur_pre, ath2);
         }
-        const uint32_t t = halo ? 7 * C + slot : pass * 4 + slot, sf = t / C, c = t % C;
+        const uint32_t t = halo ? 7 * C + (hact ? hc : 0) : pass * 4 + slot, sf = t / C, c = t % C;
         const TrFetch cur = ft;
-        {   // next step's lines: same frame's next pass, or the next frame's first pass
-            const bool last = halo || pass + 1 == PASSES;
-            if (!last) ft = tr_fetch<PLAIN, C>(F, rec, (t + 4) / C, (t + 4) % C, l16);
-            else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, rec + F.record_bytes, slot / C, slot % C, l16);
+        const bool last = halo ? pass + 1 == PASSES + HALO_STEPS : pass + 1 == PASSES;
+        {   // next step's lines: same frame's next step, or the next frame's first pass
+            if (!last) {
+                const uint32_t tn = halo ? 7 * C + (hc + 4 < (uint32_t)C ? hc + 4 : 0) : t + 4;
+                ft = tr_fetch<PLAIN, C>(F, rec, tn / C, tn % C, l16);
+            } else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, rec + F.record_bytes, slot / C, slot % C, l16);
         }
         f2 x[4];
-        tr_load_spectra<PLAIN, C>(F, T, cur, sf, halo && slot >= (uint32_t)C ? 0 : c, slot, l16, nproc, x);
+        tr_load_spectra<PLAIN, C>(F, T, cur, sf, c, slot, l16, nproc, x);
         dct4_inplace(x, L);
-        const uint32_t dslot = halo ? ring - C + slot : ring + slot;
-        float* d = T.D + (dslot & 7) * TR_DSTRIDE;
-        if (!halo || slot < (uint32_t)C) {
+        const uint32_t dslot = halo ? ring - C + hc : ring + slot;
+        float* d = T.D + (dslot & (RING - 1)) * TR_DSTRIDE;
+        if (!halo || hact) {
 #pragma unroll
             for (int r = 0; r < 8; r++) d[((r < 4 ? dlogp.x : dlogp.y) >> (8 * (r & 3))) & 0xFF] = x[r >> 1][r & 1];
         }
         wave_lds_sync();
-        if (halo) { pass = 0; f++; rec += F.record_bytes; continue; }
+        if (halo) {
+            if (last) { pass = 0; f++; rec += F.record_bytes; } else pass++;
+            continue;
+        }
 
         // window + overlap-add (hca.cpp:1987-1992) against the predecessor (same channel, previous subframe)
-        const float* dp = T.D + ((dslot - C) & 7) * TR_DSTRIDE;
+        const float* dp = T.D + ((dslot - C) & (RING - 1)) * TR_DSTRIDE;
         const bool have_prev = !(f == 0 && sf == 0);                               // hca.cpp:962: tail starts as zeros
-        const uint32_t sfl = slot / C;                                             // subframe within this pass
+        const uint32_t sfl = C > 4 ? (sf & 1) : slot / C;                          // staging row set: subframe within this pass / subframe parity
         float o0[4], o1[4];
         uint32_t big = 0;                                  // largest |value| bit pattern: >= 2^31 or NaN needs x86 cvttss2si semantics
 #pragma unroll
@@ -1170,24 +1185,31 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
             T.pcm[((sfl * 128 + i + 64) * C) + c] = (uint16_t)(int16_t)q1;
         }
         wave_lds_sync();
-        // 1 KB of interleaved PCM16 per pass; delay / length trim of hca.cpp:3392-3425
-        const uint32_t n0 = f * 1024 + pass * SPAN;
-        if (dword_ok && n0 >= st.delay && n0 + SPAN - st.delay <= st.samples) {              // whole pass inside the output
-            uint32_t* q = (uint32_t*)(dst + (uint64_t)(n0 - st.delay) * C * 2);
+        // interleaved PCM16 -- 1 KB per pass up to 4 channels, a whole subframe (256*C bytes) once its last channel is
+        // done beyond; delay / length trim of hca.cpp:3392-3425
+        const uint32_t sfd = C > 4 ? (pass * 4 + 4) / C - 1 : 0;                             // subframe completed by this pass
+        if (C <= 4 || (pass * 4 + 4) / C != (pass * 4) / C) {
+            constexpr uint32_t DW = C > 4 ? C : 4;                                           // dwords per lane
+            const uint32_t n0 = C > 4 ? f * 1024 + sfd * 128 : f * 1024 + pass * SPAN;
+            const uint32_t span = C > 4 ? 128 : SPAN;
+            const uint32_t* src = (const uint32_t*)T.pcm + (C > 4 ? (sfd & 1) * 64 * C : 0);
+            if (dword_ok && n0 >= st.delay && n0 + span - st.delay <= st.samples) {          // whole chunk inside the output
+                uint32_t* q = (uint32_t*)(dst + (uint64_t)(n0 - st.delay) * C * 2);
 #pragma unroll
-            for (int k = 0; k < 4; k++) q[k * 64 + lane] = ((const uint32_t*)T.pcm)[k * 64 + lane];
-        } else {
+                for (uint32_t k = 0; k < DW; k++) q[k * 64 + lane] = src[k * 64 + lane];
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
-                const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
-                const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
-                const uint32_t word = ((const uint32_t*)T.pcm)[dw];
-                const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
-                if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
-                else {
-                    if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
-                    if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
+                for (uint32_t q = 0; q < DW; q++) {
+                    const uint32_t dw = q * 64 + lane, e0 = 2 * dw, e1 = e0 + 1;
+                    const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
+                    const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
+                    const uint32_t word = src[dw];
+                    const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
+                    if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
+                    else {
+                        if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
+                        if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
+                    }
                 }
             }
         }
@@ -1198,21 +1220,27 @@ __global__ __launch_bounds__(64, PLAIN ? 4 : 3) void k_hca_transform(HcaDecArgs 
 }
 
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
-    const size_t base = (size_t)C * 128 * 4 + 8 * TR_DSTRIDE * 4 + 1024 + 512 + 256 + 64 + 80;
+    const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
     return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + ((C * 8 + 15) & ~15) + (C * 4 + 4) * 4 + 2 * C * 128 + 64;
 }
 
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
-    if (a.channels == 1 || a.channels == 2 || a.channels == 4) {
+    const bool in_regs = a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    if (in_regs) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
 #define CRI_LAUNCH_TR(P, CH) hipLaunchKernelGGL((k_hca_transform<P, CH>), dim3(a.runs), dim3(64), lds, s, a)
-        if (a.plain) { if (a.channels == 1) CRI_LAUNCH_TR(true, 1); else if (a.channels == 2) CRI_LAUNCH_TR(true, 2); else CRI_LAUNCH_TR(true, 4); }
-        else { if (a.channels == 1) CRI_LAUNCH_TR(false, 1); else if (a.channels == 2) CRI_LAUNCH_TR(false, 2); else CRI_LAUNCH_TR(false, 4); }
+        if (a.plain) switch (a.channels) {
+            case 1: CRI_LAUNCH_TR(true, 1); break; case 2: CRI_LAUNCH_TR(true, 2); break; case 4: CRI_LAUNCH_TR(true, 4); break;
+            case 6: CRI_LAUNCH_TR(true, 6); break; default: CRI_LAUNCH_TR(true, 8); break;
+        } else switch (a.channels) {
+            case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;
+            case 6: CRI_LAUNCH_TR(false, 6); break; default: CRI_LAUNCH_TR(false, 8); break;
+        }
 #undef CRI_LAUNCH_TR
     } else {
-        size_t lds = (size_t)(3 * a.channels + 1) * 128 * 4 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
+        size_t lds = (size_t)a.channels * (2 * 128 + 2 * TR_DSTRIDE) * 4 + a.channels * 256 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);
     }
 }

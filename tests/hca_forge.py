@@ -35,6 +35,17 @@ def forge_v1(hca: bytes, version: int = 0x0101) -> bytes:
     return bytes(b)
 
 
+def forge_comp(hca: bytes, track_count=None, channel_config=None, total=None, base=None, stereo=None, hfr=None) -> bytes:
+    """Rewrite fields of the comp chunk (at 0x18: track count, channel config, band counts) and fix the header CRC."""
+    b = bytearray(hca)
+    assert bytes(x & 0x7F for x in b[0x18:0x1C]) == b"comp"
+    for off, v in ((0x20, track_count), (0x21, channel_config), (0x22, total), (0x23, base), (0x24, stereo), (0x25, hfr)):
+        if v is not None:
+            b[off] = v
+    fix_header_crc(b)
+    return bytes(b)
+
+
 def random_frames(hca: bytes, seed: int, density: float = 1.0) -> bytes:
     """Replace every frame payload with seeded random bytes (sync forced, CRC fixed)."""
     b = bytearray(hca)
@@ -50,3 +61,25 @@ def random_frames(hca: bytes, seed: int, density: float = 1.0) -> bytes:
         fr = b"\xff\xff" + body.tobytes()
         b[o:o + fs] = fr + struct.pack(">H", crc16(fr))
     return bytes(b)
+
+
+def accepted_random_stream(hca: bytes, seed: int, density: float, accept):
+    """random_frames, with every frame that `accept` (a one-frame stream -> bool) turns down replaced by a copy of one it
+    takes, so that long multi-channel streams survive the decoder's per-frame checks.  None if no frame is accepted."""
+    b = bytearray(random_frames(hca, seed, density))
+    hs = struct.unpack(">H", b[6:8])[0]
+    fs = struct.unpack(">H", b[0x1C:0x1E])[0]
+    nfr = struct.unpack(">I", b[0x10:0x14])[0]
+    one = bytearray(b[:hs])
+    one[0x10:0x14] = struct.pack(">I", 1)
+    one[0x16:0x18] = b"\0\0"
+    fix_header_crc(one)
+    frames = [bytes(b[hs + f * fs:hs + (f + 1) * fs]) for f in range(nfr)]
+    ok = [accept(bytes(one) + fr) for fr in frames]
+    good = [fr for fr, k in zip(frames, ok) if k]
+    if not good:
+        return None
+    for f in range(nfr):
+        if not ok[f]:
+            frames[f] = good[f % len(good)]
+    return bytes(b[:hs]) + b"".join(frames)

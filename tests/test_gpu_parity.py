@@ -194,6 +194,47 @@ def test_hca_v3_noise_fill(cc, q, ch, n):
     assert accepted > 0
 
 
+@pytest.mark.parametrize("ch", [3, 4, 5, 6, 7, 8])
+def test_hca_multichannel_layouts(cc, ch):
+    """Streams longer than one run of 8 frames (the run's halo steps) for every channel count, then forged comp chunks:
+    joint-stereo bands, HFR groups, several tracks (stereo pairs starting on odd channels: 2 tracks x 3 channels) and
+    both channel configs (hca.cpp:887-970), v2.0 and v3.0 (noise reconstruction), with random frames under each layout."""
+    w = synth.wav(60 + ch, 10500, ch, 48000)
+    for q in (1, 3, 4):
+        h = O.hca_encode(w, q)
+        assert diff(cc.HcaDecode(h, int.from_bytes(h[6:8], "big"), 0, 0), O.hca_decode(h)) is None, q
+    base = O.hca_encode(w, 1)
+    hs = int.from_bytes(base[6:8], "big")
+    total, bb = base[0x22], base[0x23]
+    accepted = tried = 0
+
+    def takes(stream):
+        try:
+            O.hca_decode(stream)
+            return True
+        except O.OracleError:
+            return False
+    for tracks in (1, 2, 3):
+        if ch % tracks:
+            continue
+        for config in (0, 1):
+            for (stereo, hfr) in ((0, 0), (8, 0), (bb - 4, 0), (8, 4), (0, 3)):
+                nb = bb - stereo if hfr == 0 else bb - stereo - 16
+                f0 = hca_forge.forge_comp(base, track_count=tracks, channel_config=config, total=bb if hfr == 0 else total,
+                                          base=nb, stereo=stereo, hfr=hfr)
+                for seed in range(2):
+                    fb = hca_forge.forge_v3(f0, 0) if (seed + tracks + config) % 2 else f0       # half of them as v3.0 with noise reconstruction
+                    f = hca_forge.accepted_random_stream(fb, 100 * ch + seed, 0.3 if seed else 0.08, takes)
+                    tried += 1
+                    if f is None or not takes(f):
+                        with pytest.raises(ValueError):
+                            cc.HcaDecode(f if f is not None else hca_forge.random_frames(fb, 100 * ch + seed, 0.3), hs, 0, 0)
+                        continue
+                    accepted += 1
+                    assert diff(cc.HcaDecode(f, hs, 0, 0), O.hca_decode(f)) is None, (tracks, config, stereo, hfr, seed)
+    assert accepted >= tried // 2, (accepted, tried)
+
+
 def test_v3_delta_intensity_keeps_stale_entries(cc):
     """Found by tools/debug/frame_fuzz.py: a v3.0 delta-coded intensity list that runs out of range leaves the remaining
     entries at the previous frame's values (the reference returns early and ignores the error, hca.cpp:1185, 1405-1408)."""
