@@ -149,8 +149,8 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 // k_hca_parse: one lane per frame
 // ------------------------------------------------------------------------------------------------------------
-// LDS per wave (8.9 KB): ostage uint32[16][65] (per-lane output words, transposed on flush), recoff uint64[64],
-// curve->resolution table, bit-feed ring uint32[RING_WORDS][64].  The per-band code descriptions (one byte each: max bits |
+// LDS per wave (8.4 KB): bit-feed ring uint32[RING_WORDS][64], ostage uint32[16][66] (per-lane output words, transposed
+// on flush), curve->resolution table.  The per-band code descriptions (one byte each: max bits |
 // short-code count << 4, see parse_symbol) live in the tile's `resg` area of scratch: one uint4 (16 bands) per lane and
 // 16-band block, written once by the scalefactor pass and re-read (coalesced, L2-resident) by each of the 8 subframes.
 //
@@ -159,9 +159,9 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
 //   --one word prefetched per symbol--> 64-bit shift register.
 // Checkpoints sit every 16 symbols (at most 16*12 bits = 6 words consumed in between); a checkpoint requests up to
 // FEED_MAX = 6 words to refill the ring to RING_WORDS = 16, so after landing the ring always holds >= 10 words.
-#define RING_WORDS 16
+#define RING_WORDS 16       // (+ one spare row: the sink of feed_land)
 #define FEED_MAX 6
-size_t hca_parse_lds_bytes(uint32_t channels) { (void)channels; return (size_t)16 * 65 * 4 + 64 * 8 + 96 + (size_t)RING_WORDS * 256; }
+size_t hca_parse_lds_bytes(uint32_t channels) { (void)channels; return (size_t)(RING_WORDS + 1) * 256 + 16 * 66 * 4 + 96; }
 
 struct BitFeed {
     const uint32_t* next;    // next word of this lane in the tile (stride 64 words)
@@ -169,36 +169,48 @@ struct BitFeed {
     uint32_t* ring;          // LDS ring base of this lane (slot stride 64 words)
     uint32_t wr;             // words landed in the ring
     uint32_t nfl;            // words in flight
+    uint32_t live;           // bit k: fl[k] is a word of the frame (otherwise it reads as 0: past the frame end)
     uint32_t fl[FEED_MAX];
 };
 struct BitBuf {
-    uint64_t buf;            // next bits, MSB aligned
-    int avail;               // valid bits in buf
+    uint32_t hi, lo;         // frame words k and k+1 (big-endian): a 64-bit window the reader moves through
+    uint32_t off;            // bits of the window already consumed: < 32 after a refill, and a refill precedes at most 24 more
     int pos;                 // absolute bit position in the frame (hca.cpp clData.bit)
     int size;                // frame size in bits
-    uint32_t rd;             // index of the next ring word to move into pw
-    uint32_t pw, nw;         // w[rd-1] (not yet merged), w[rd] (LDS read issued one step earlier)
+    uint32_t rd;             // ring index of nw (= k + 2)
+    uint32_t nw;             // frame word k + 2 (LDS read issued one refill earlier)
 };
 
-__device__ __forceinline__ void feed_checkpoint(BitFeed& f, const BitBuf& b) {
+// A checkpoint is two halves with the pending record stores in between (see PendingFlush): the loads asked for at the
+// previous checkpoint land in the ring, the stores of the last two blocks go out, the next loads are asked for.  vmcnt
+// counts loads and stores together and in order, so the wait at the next checkpoint covers those stores too -- by then
+// they have had a whole block of parsing to complete.  Both halves are branch-free: a word that was not asked for is
+// parked in the ring's spare row, a load past the lane's frame reads a word nobody uses.
+__device__ __forceinline__ void feed_land(BitFeed& f) {
 #pragma unroll
-    for (uint32_t k = 0; k < FEED_MAX; k++) if (k < f.nfl) f.ring[((f.wr + k) & (RING_WORDS - 1)) * 64] = f.fl[k];
+    for (uint32_t k = 0; k < FEED_MAX; k++) {
+        const bool on = k < f.nfl;
+        f.ring[(on ? ((f.wr + k) & (RING_WORDS - 1)) : (uint32_t)RING_WORDS) * 64] = ((f.live >> k) & 1) ? f.fl[k] : 0u;
+    }
     f.wr += f.nfl;
+}
+__device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b) {
     const uint32_t room = RING_WORDS - (f.wr - b.rd);
     const uint32_t n = room < FEED_MAX ? room : FEED_MAX;
+    const int adv = (int)n < f.rows_left ? (int)n : f.rows_left;                 // words of the frame among the n (the rest read as 0)
 #pragma unroll
-    for (uint32_t k = 0; k < FEED_MAX; k++) if (k < n) f.fl[k] = (int)k < f.rows_left ? f.next[k * 64] : 0u;
-    const int adv = (int)n < f.rows_left ? (int)n : f.rows_left;
+    for (uint32_t k = 0; k < FEED_MAX; k++) f.fl[k] = f.next[((int)k < adv ? k : 0u) * 64];
+    f.live = (1u << adv) - 1;
     f.next += (size_t)adv * 64; f.rows_left -= adv;
     f.nfl = n;
 }
+__device__ __forceinline__ void feed_checkpoint(BitFeed& f, const BitBuf& b) { feed_land(f); feed_request(f, b); }
 // one refill opportunity per symbol; branch-free, the LDS read issued here is consumed by the NEXT call
 __device__ __forceinline__ void bb_refill(BitBuf& b, const uint32_t* ring) {
-    const bool need = b.avail <= 32;
-    const uint64_t add = (uint64_t)b.pw << (need ? 32 - b.avail : 0);
-    b.buf |= need ? add : 0ull;
-    b.avail += need ? 32 : 0;
-    b.pw = need ? b.nw : b.pw;
+    const bool need = b.off >= 32;                   // the window's first word is used up: slide by one word
+    b.hi = need ? b.lo : b.hi;
+    b.lo = need ? b.nw : b.lo;
+    b.off &= 31;
     b.rd += need ? 1u : 0u;
     b.nw = ring[(b.rd & (RING_WORDS - 1)) * 64];
 }
@@ -207,14 +219,15 @@ __device__ __forceinline__ void bb_refill(BitBuf& b, const uint32_t* ring) {
 // from its byte start -- the reference then serves it from a window that is too narrow (its shift count wraps).
 template <bool CHECKED>
 __device__ __forceinline__ uint32_t bb_peek(const BitBuf& b, int n) {
-    const uint32_t v = ((uint32_t)(b.buf >> 32) >> 1) >> (31 - n);          // n == 0 gives 0
+    const uint32_t w = (uint32_t)(((((uint64_t)b.hi << 32) | b.lo) << b.off) >> 32);    // the next 32 bits
+    const uint32_t v = __builtin_amdgcn_ubfe(w, 32 - n, n);                 // their top n (v_bfe_u32: n == 0 gives 0)
     if (!CHECKED) return v;
     const int left = b.size - b.pos;
     const int off = n + (b.pos & 7);
     const bool zero = (n > left) | ((left < 24) & ((off >= 17) | ((off >= 9) & (left < 16))));
     return zero ? 0u : v;
 }
-__device__ __forceinline__ void bb_skip(BitBuf& b, int n) { b.buf <<= n; b.avail -= n; b.pos += n; }
+__device__ __forceinline__ void bb_skip(BitBuf& b, int n) { b.off += n; b.pos += n; }
 __device__ __forceinline__ uint32_t bb_read(BitBuf& b, const uint32_t* ring, int n) { bb_refill(b, ring); uint32_t v = bb_peek<true>(b, n); bb_skip(b, n); return v; }
 
 // One spectral symbol (hca.cpp:1546-1563).  `meta` = bits | nshort << 4 describes the band's code: `bits` = most bits a
@@ -231,21 +244,19 @@ __device__ __forceinline__ int parse_symbol(BitBuf& bb, uint32_t meta) {
     const bool is_short = code < 2 * ns;
     const uint32_t sym = is_short ? (code >> 1) : (code - ns);
     const uint32_t len = bits - (is_short ? 1u : 0u);
-    const uint32_t m = (sym + 1) >> 1;
-    bb.buf <<= len; bb.avail -= (int)len;
+    bb.off += len;
     if (CHECKED) bb.pos += (int)len;
-    return (sym & 1) ? (int)m : -(int)m;
+    return (int)((sym >> 1) ^ (uint32_t)__builtin_amdgcn_sbfe(sym, 0, 1));       // = -(value): 0, -1, 1, -2, 2, ...
 }
-// refill for up to two symbols (24 bits): afterwards at least 32 bits are valid
-__device__ __forceinline__ void pair_refill(BitBuf& b, const uint32_t* ring) {
-    const bool need = b.avail <= 32;
-    const uint32_t pwm = need ? b.pw : 0u;
-    b.buf |= (uint64_t)pwm << ((32 - b.avail) & 63);
-    b.avail += need ? 32 : 0;
-    b.pw = need ? b.nw : b.pw;
-    b.rd += need ? 1u : 0u;
-    b.nw = ring[(b.rd & (RING_WORDS - 1)) * 64];
+// two symbols' negated values -> their int16 pair
+__device__ __forceinline__ uint32_t pack_negated(int n0, int n1) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const uint32_t p = __builtin_amdgcn_perm((uint32_t)n1, (uint32_t)n0, 0x05040100u);   // n1.lo16 : n0.lo16
+    const s2 z = {0, 0};
+    return __builtin_bit_cast(uint32_t, z - __builtin_bit_cast(s2, p));                  // v_pk_sub_i16
 }
+// refill for up to two symbols (24 bits)
+__device__ __forceinline__ void pair_refill(BitBuf& b, const uint32_t* ring) { bb_refill(b, ring); }
 // code description of a band of resolution res (see parse_symbol)
 __device__ __forceinline__ uint32_t band_meta(uint32_t res) {
     const uint32_t bits = res > 7 ? res - 3 : (0x44443320u >> (res * 4)) & 15;      // 0,2,3,3,4,4,4,4,5,...,12
@@ -253,27 +264,45 @@ __device__ __forceinline__ uint32_t band_meta(uint32_t res) {
     return bits | (ns << 4);
 }
 
-// transposed flush of the 16 staged words of every lane: frame fr's words go to its record + byte_off, 64 B per frame
-__device__ __forceinline__ void flush16(const uint32_t* ostage, const uint64_t* recoff, uint8_t* scratch, uint32_t lane, uint32_t byte_off, uint32_t nwords) {
+// transposed flush of the 16 staged words of every lane: frame fr's words go to its record + byte_off, 64 B per frame.
+// The records of a tile's frames are consecutive (cri_capi.cpp lays a format group's records out in frame order), so
+// a lane owns a quarter (16 B) of one frame's 64 B per step: `recq` = tile's records + (lane >> 2) * record_bytes +
+// (lane & 3) * 16, four steps of 16 frames.  OST = 66 keeps the four gathered LDS words of a half-wave on distinct banks.
+#define OST 66
+__device__ __forceinline__ void flush16(const uint32_t* ostage, uint8_t* recq, uint32_t rb16, uint32_t nvalid, uint32_t lane, uint32_t byte_off, uint32_t nwords) {
     wave_lds_sync();
-    const uint32_t w = lane & 15;
-#pragma unroll 4
-    for (uint32_t it = 0; it < 16; it++) {
-        const uint32_t fr = it * 4 + (lane >> 4);
-        const uint64_t ro = recoff[fr];
-        if (ro != ~0ull && w < nwords) ((uint32_t*)(scratch + ro + byte_off))[w] = ostage[w * 65 + fr];
+    const uint32_t wq = (lane & 3) * 4, fq = lane >> 2;
+    const bool all = nvalid == 64 && nwords == 16;                // (wave-uniform) the usual case: no per-lane masks
+#pragma unroll
+    for (uint32_t it = 0; it < 4; it++) {
+        const uint32_t fr = it * 16 + fq;
+        const uint32_t* src = ostage + wq * OST + fr;
+        const uint4 v = make_uint4(src[0], src[OST], src[2 * OST], src[3 * OST]);
+        uint4* dst = (uint4*)(recq + (size_t)it * rb16 + byte_off);
+        if (all) *dst = v;
+        else if (fr < nvalid && wq < nwords) *dst = v;
     }
     wave_lds_sync();
 }
+
+// The staged words are stored one checkpoint later than they are complete: right after the feed's loads have landed and
+// before the next ones are asked for (feed_land), so that no checkpoint waits on stores it has just issued.
+struct PendingFlush {
+    uint32_t byte_off, nwords;               // nwords == 0: nothing pending (wave-uniform)
+    __device__ __forceinline__ void set(uint32_t off, uint32_t n) { byte_off = off; nwords = n; }
+    __device__ __forceinline__ void run(const uint32_t* ostage, uint8_t* recq, uint32_t rb16, uint32_t nvalid, uint32_t lane) {
+        if (nwords) flush16(ostage, recq, rb16, nvalid, lane, byte_off, nwords);
+        nwords = 0;
+    }
+};
 
 __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t R = a.rows, C = F.channels, lane = threadIdx.x, tile = blockIdx.x;
-    uint32_t* ostage = (uint32_t*)smem;
-    uint64_t* recoff = (uint64_t*)(smem + 16 * 65 * 4);
-    uint8_t* curve = (uint8_t*)(recoff + 64);          // 96 bytes reserved, the ring follows
-    uint32_t* ring = (uint32_t*)(curve + 96) + lane;
+    uint32_t* ring = (uint32_t*)smem + lane;           // [RING_WORDS + 1][64]
+    uint32_t* ostage = (uint32_t*)(smem + (RING_WORDS + 1) * 256);   // [16][OST]
+    uint8_t* curve = (uint8_t*)(ostage + 16 * OST);    // 96 bytes reserved
     for (uint32_t i = lane; i < 66; i += 64) curve[i] = HCA_CURVE_TO_RES[i];
 
     const uint32_t g = tile * 64 + lane;
@@ -281,21 +310,24 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint32_t si = a.stream_begin, f = 0;
     if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
     const HcaStream st = a.streams[si];
-    const uint64_t ro = st.scratch_offset + (uint64_t)f * F.record_bytes;
-    uint8_t* rec = a.scratch + ro;
-    recoff[lane] = valid ? ro : ~0ull;
+    // the records of a format group are consecutive in frame order (cri_capi.cpp): frame g's starts at group base + g * record_bytes
+    uint8_t* tile_rec = a.scratch + a.streams[a.stream_begin].scratch_offset + (uint64_t)tile * 64 * F.record_bytes;
+    uint8_t* rec = tile_rec + (uint64_t)lane * F.record_bytes;
+    uint8_t* recq = tile_rec + (uint64_t)(lane >> 2) * F.record_bytes + (lane & 3) * 16;
+    const uint32_t rb16 = 16 * F.record_bytes;
+    const uint32_t nvalid = a.frames - tile * 64 < 64 ? a.frames - tile * 64 : 64;
     int status = valid ? ((const int32_t*)(a.scratch + a.fstat_offset))[g] : 0;
     // every lane parses (frames that failed sync/CRC and the zero padding of the last tile parse to ignored output)
     uint4* metag = (uint4*)(a.scratch + a.resg_offset) + (uint64_t)tile * C * 8 * 64 + lane;
 
+    PendingFlush pend; pend.set(0, 0);
     BitFeed fd;
     fd.next = (const uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64 + lane;
-    fd.rows_left = (int)R + 1; fd.ring = ring; fd.wr = 0; fd.nfl = 0;
+    fd.rows_left = (int)R + 1; fd.ring = ring; fd.wr = 0; fd.nfl = 0; fd.live = 0;
     BitBuf bb;
-    bb.buf = 0; bb.avail = 0; bb.pos = 0; bb.size = (int)F.frame_size * 8; bb.rd = 0; bb.pw = 0; bb.nw = 0;
+    bb.hi = 0; bb.lo = 0; bb.off = 0; bb.pos = 0; bb.size = (int)F.frame_size * 8; bb.rd = 0; bb.nw = 0;
     feed_checkpoint(fd, bb); feed_checkpoint(fd, bb); feed_checkpoint(fd, bb);   // prime: 12 words landed, 4 in flight
-    bb.pw = ring[0]; bb.rd = 1; bb.nw = ring[64];
-    bb_refill(bb, ring); bb_refill(bb, ring);
+    bb.hi = ring[0]; bb.lo = ring[64]; bb.nw = ring[128]; bb.rd = 2;
     bb_skip(bb, 16);                                             // sync word, checked by k_hca_prepare
     uint32_t packed = 0, flags = 0, draws = 0;
     {
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         const uint32_t expected = (1u << db) - 1;
         // scalefactors + resolutions in blocks of 16 bands (the last block is padded with zeros)
         for (uint32_t blk = 0; blk < 8; blk++) {
-            feed_checkpoint(fd, bb);
+            feed_land(fd); feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);
             uint32_t sfw[4] = {0, 0, 0, 0};
             uint32_t mw[4] = {0, 0, 0, 0};
             // far from the frame end (always, in a well-formed frame) the reader's end-of-frame rules cannot apply
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             }
             metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 #pragma unroll
-            for (uint32_t q = 0; q < 4; q++) ostage[((blk & 3) * 4 + q) * 65 + lane] = sfw[q];
+            for (uint32_t q = 0; q < 4; q++) ostage[((blk & 3) * 4 + q) * OST + lane] = sfw[q];
             if ((blk & 3) == 3) {
                 if (blk == 7) {                                   // the high end also carries the HFR scales
                     // derived HFR scales of v3.0 (hca.cpp:1353-1355); the entry one past the decoded range reads as 0.
@@ -376,14 +408,15 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                         for (uint32_t k = 0; k < groups; k++) {
                             const uint32_t v = bb_read(bb, ring, 6);
                             const uint32_t di = 128 - groups + k;
-                            sfst[(((di >> 2) & 15) * 65 + lane) * 4 + (di & 3)] = (uint8_t)v;
+                            sfst[(((di >> 2) & 15) * OST + lane) * 4 + (di & 3)] = (uint8_t)v;
                         }
                     }
                 }
-                flush16(ostage, recoff, a.scratch, lane, HCA_REC_SF(C, c) + (blk >> 2) * 64, 16);
+                pend.set(HCA_REC_SF(C, c) + (blk >> 2) * 64, 16);
             }
         }
         if (extra) {                                              // v3.0: scalefactors[127 - i] = scalefactors[cs - i]
+            pend.run(ostage, recq, rb16, nvalid, lane);
             __syncthreads();                                      // (global data written by other lanes: drain the stores)
             if (valid) for (uint32_t i = 0; i < extra; i++) {
                 const uint32_t srci = cs - i;
@@ -431,41 +464,53 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     }
     // ---- spectra: 8 subframes x C channels x coded symbols, serial per lane (hca.cpp:1194-1199, 1540-1571),
     //      in blocks of 16 symbols; bands past `coded` carry resolution 0 = no bits
+    //      The code descriptions of a block are loaded one block ahead, before the pending stores: every vector memory
+    //      operation a block waits for (feed_land) is then a whole block old.
+    uint4 mv_next = metag[0];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): nothing is pending when the loop is entered, so the
+                                                                  // waits the compiler places inside it stay exact counts
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t nblk = (F.coded(c) + 15) >> 4;
             for (uint32_t blk = 0; blk < nblk; blk++) {
-                feed_checkpoint(fd, bb);
-                const uint4 mv = metag[(c * 8 + blk) * 64];
+                feed_land(fd);
+                const uint4 mv = mv_next;
+                {
+                    uint32_t nb = blk + 1, nc = c;
+                    if (nb >= nblk) { nb = 0; nc = c + 1 == C ? 0 : c + 1; }
+                    mv_next = metag[(nc * 8 + nb) * 64];
+                }
+                feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);
                 const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
                 uint32_t words[8];
                 if (fast) {
-                    const int avail0 = bb.avail; const uint32_t rd0 = bb.rd;
+                    const uint32_t off0 = bb.off, rd0 = bb.rd;
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
                         pair_refill(bb, ring);
                         const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
                         const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
-                        words[k] = ((uint32_t)v0 & 0xFFFF) | ((uint32_t)v1 << 16);
+                        words[k] = pack_negated(v0, v1);
                     }
-                    bb.pos += avail0 - bb.avail + 32 * (int)(bb.rd - rd0);
+                    bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
                 } else {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
                         pair_refill(bb, ring);
                         const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
                         const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
-                        words[k] = ((uint32_t)v0 & 0xFFFF) | ((uint32_t)v1 << 16);
+                        words[k] = pack_negated(v0, v1);
                     }
                 }
 #pragma unroll
-                for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * 65 + lane] = words[k];
+                for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * OST + lane] = words[k];
                 if ((blk & 1) || blk + 1 == nblk)
-                    flush16(ostage, recoff, a.scratch, lane, HCA_REC_QC(C, sf, c) + (blk >> 1) * 64, (blk & 1) ? 16 : 8);
+                    pend.set(HCA_REC_QC(C, sf, c) + (blk >> 1) * 64, (blk & 1) ? 16 : 8);
             }
         }
     }
+    pend.run(ostage, recq, rb16, nvalid, lane);
     if (valid) {
         uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
         tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags; tail[3] = draws;      // k_hca_noise_scan turns tail[3] into a prefix

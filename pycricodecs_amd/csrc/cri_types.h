@@ -45,7 +45,9 @@ struct HcaStream {
 // Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):
 //   int16 qc[8][C][128]  | uint8 scalefactors[C][128] | uint8 intensity[C][8] | uint32 tail[4]
 //   tail = { packed_noise_level, status (0 or CRI_ERR_HCA_FRAME), flags (bit c: channel c reuses intensity[1..7]), bits_read }
-static inline uint32_t hca_record_bytes(uint32_t channels) { return ((channels * (2048u + 128u + 8u) + 16u) + 255u) & ~255u; }
+// (an odd number of 128-byte lines: k_hca_parse stores the same 64 B of 16 consecutive records per instruction, and with an
+//  even line stride those would land on a quarter of the L2 channels)
+static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels * (2048u + 128u + 8u) + 16u) + 127u) >> 7) | 1u) << 7; }
 #define HCA_REC_QC(C, sf, c) ((((sf) * (C)) + (c)) * 256u)
 #define HCA_REC_SF(C, c) ((C) * 2048u + (c) * 128u)
 #define HCA_REC_INT(C, c) ((C) * 2176u + (c) * 8u)
