@@ -13,6 +13,8 @@
 //                    reconstruct_high_frequency (1638-1683), apply_intensity_stereo (1696-1714), imdct_transform
 //                    (1898-2019), clHCA_ReadSamples16 (339-360) and HcaDecode's delay/trim (3401-3452).  One WAVE per run of
 //                    8 frames, four transforms at a time in registers (1, 2, 4, 6 or 8 channels).
+//   k_hca_transform_plain      formats without HFR / joint stereo / noise fill, 1, 2 or 4 channels (the usual case): each 16-lane
+//                    slot follows one channel through consecutive subframes, so window + overlap-add stay in the DCT's lanes.
 //   k_hca_transform_generic    the same for any other channel layout, one wave per frame, spectra assembled in LDS
 //                    (the DCT is the same register network); k_hca_noise_scan gives it the generator state each frame starts from.
 // All float work is single IEEE binary32 operations in the reference's order (compiled with -ffp-contract=off).
@@ -1264,6 +1266,229 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_hca_transform_plain: formats without HFR / joint stereo / noise fill, 1, 2 or 4 channels -- overlap-add in the
+// DCT's own lanes
+// ------------------------------------------------------------------------------------------------------------
+// In the in-place DCT-IV a lane's register pair j holds the outputs d[k] and d[127-k] (k < 64, HCA_DCT_LOGICAL), and the
+// window/overlap-add of hca.cpp:1987-1992, written for those two, reads
+//     out[63-k] = w[63-k]*d[127-k] + w[64+k]*prev[k]        out[64+k] = w[64+k]*d[127-k] - w[63-k]*prev[k]
+// where prev[k] is the same position of the same channel's previous subframe.  So when a transform slot (16 lanes) always
+// follows the same channel through consecutive subframes, the overlap state is four registers per lane, the window is
+// eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of HCA_RUN
+// frames, but its 4 slots ("units") are 4/C groups x C channels: each group takes a contiguous part of the run and walks
+// it frame by frame, subframe by subframe, after one halo pass (the subframe before its first one).
+struct PlainPre { uint2 ps; uint32_t sf2[4]; };       // setup inputs of the four units' frames: lane v < 4 holds unit v's {packed, status}
+
+#ifndef CRI_PLAIN_WAVES
+#define CRI_PLAIN_WAVES 4
+#endif
+template <int C>
+__global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
+    const Fmt F = load_fmt(a.formats + a.format);
+    const uint32_t lane = threadIdx.x, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
+    float* G = (float*)smem;                               // [4][128] gains of each unit's frame
+    uint16_t* pcm = (uint16_t*)(G + 512);                  // [NG][128][C] one pass of PCM16
+    float* scale = (float*)(pcm + 512); float* range = scale + 64; uint8_t* curve = (uint8_t*)(range + 16);   // 80 bytes
+
+    uint32_t lo = a.stream_begin, hi = a.stream_end;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= blockIdx.x) lo = mid; else hi = mid; }
+    const HcaStream st = a.streams[lo];
+    const uint32_t f0 = (blockIdx.x - st.first_run) * HCA_RUN;
+    const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
+    const uint8_t* rec0 = a.scratch + st.scratch_offset;
+    const uint32_t h = (nf + NG - 1) / NG;                 // frames per group (the last groups may get fewer, or none)
+
+    DctLane L;
+    dct_lane_init(L, l16, HCA_DCT_LANE_SIN, HCA_DCT_LANE_COS);
+    const uint2 dlogp = *(const uint2*)(HCA_DCT_LOGICAL + l16 * 8);
+    // per-lane constants kept in LDS (12 registers otherwise): {w[63-k], w[64+k]} x 4 and the staging index of out[64+k] x 4
+    // (out[63-k] sits at po_sum - that; byte offsets)
+    float* wtab = (float*)(curve + 80) + lane * 8;         // [64][8]
+    uint32_t* potab = (uint32_t*)(curve + 80 + 2048) + lane * 4;   // [64][4]
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t k = ((j < 2 ? dlogp.x : dlogp.y) >> (16 * (j & 1))) & 0xFF;      // register 2j: k < 64 (register 2j+1: 127 - k)
+        wtab[2 * j] = HCA_WINDOW[63 - k]; wtab[2 * j + 1] = HCA_WINDOW[64 + k];
+        potab[j] = ((g * 128 + 64 + k) * C + c) * 2;       // byte offsets
+    }
+    const uint32_t po_sum = ((2 * g * 128 + 127) * C + 2 * c) * 2;
+    uint8_t* pcmb = (uint8_t*)pcm;
+    scale[lane] = HCA_DEQ_SCALE[lane];
+    if (lane < 16) range[lane] = HCA_DEQ_RANGE[lane];
+    curve[lane] = HCA_CURVE_TO_RES[lane]; if (lane < 2) curve[64 + lane] = HCA_CURVE_TO_RES[64 + lane];
+    const uint32_t ath2 = ((const uint16_t*)(a.ath_tables + F.ath_index * 128))[lane];
+    const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
+    uint8_t* dst = a.out + st.dst_offset;
+
+    // unit v (any lane can name it: the setup works on all four): first frame, frame count
+    auto unit_first = [&](uint32_t v) { return f0 + (v / C) * h; };
+    auto unit_count = [&](uint32_t v) { const uint32_t fb = unit_first(v); return fb < f0 + nf ? (f0 + nf - fb < h ? f0 + nf - fb : h) : 0u; };
+    // frame of unit v in step s (s = -1: the halo frame); frames that do not exist are replaced by the run's first frame, which
+    // is always there, and their results are dropped
+    auto unit_frame = [&](uint32_t v, int s, bool& live) {
+        const uint32_t fb = unit_first(v), n = unit_count(v);
+        live = s < 0 ? (n > 0 && fb > 0) : ((uint32_t)s < n);
+        return live ? fb + (uint32_t)s : f0;              // (fb + (uint32_t)-1 = fb - 1)
+    };
+    auto load_pre = [&](int s) {
+        PlainPre p;
+        {
+            bool live; const uint32_t f = unit_frame(lane & 3, s, live);
+            p.ps = *(const uint2*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_TAIL(C));
+            p.ps.y = live ? p.ps.y : 0u;
+        }
+#pragma unroll
+        for (uint32_t v = 0; v < 4; v++) {
+            bool live; const uint32_t f = unit_frame(v, s, live);
+            p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(C, v % C)))[lane];
+        }
+        return p;
+    };
+    // gains of the four units' frames (hca.cpp:1444-1507), two bands per lane; false if one of the frames is bad
+    auto setup = [&](const PlainPre& p) {
+#pragma unroll
+        for (uint32_t v = 0; v < 4; v++) {
+            const int32_t status = (int32_t)__builtin_amdgcn_readlane(p.ps.y, v);
+            if (status != 0) { if (lane == 0 && a.status) atomicMin(a.status + st.item, status); return false; }
+        }
+#pragma unroll
+        for (uint32_t v = 0; v < 4; v++) {
+            const uint32_t packed = __builtin_amdgcn_readlane(p.ps.x, v), sf2 = p.sf2[v], coded = F.coded(v % C);
+            float gn[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const uint32_t i = 2 * lane + hh, sv = (sf2 >> (8 * hh)) & 0xFF;
+                const int noise = (int)((ath2 >> (8 * hh)) & 0xFF) + (int)((packed + i) >> 8);
+                const int cp = noise + 1 - (int)((5 * sv) >> 1);
+                const int cpc = cp < 0 ? 0 : (cp > 65 ? 65 : cp);
+                uint32_t res = curve[cpc];
+                res = cp < 0 ? 15u : (cp > 65 ? 0u : res);
+                res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
+                res = sv > 0 ? res : 0u;
+                const float gain = scale[sv & 63] * range[res & 15];
+                gn[hh] = i < coded ? gain : 0.0f;
+            }
+            *(float2*)(G + v * 128 + 2 * lane) = make_float2(gn[0], gn[1]);
+        }
+        wave_lds_sync();
+        return true;
+    };
+    // row 0 of this lane's unit's quantised lines in the frame of step s: bands l16*8 .. +7; subframe sf is sf*C*256 bytes on
+    auto row0 = [&](int s) {
+        bool live; const uint32_t f = unit_frame(u, s, live);
+        return rec0 + (uint64_t)f * F.record_bytes + (HCA_REC_QC(C, 0, c) + l16 * 16);
+    };
+    auto dct_pass = [&](const uint4& q, f2 x[4]) {
+        const float4 g0 = *(const float4*)(G + u * 128 + l16 * 8), g1 = *(const float4*)(G + u * 128 + l16 * 8 + 4);
+        const f2 gg[4] = {f2{g0.x, g0.y}, f2{g0.z, g0.w}, f2{g1.x, g1.y}, f2{g1.z, g1.w}};
+        const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = gg[k] * f2{(float)(int)(int16_t)(qw[k] & 0xFFFF), (float)((int)qw[k] >> 16)};   // gains are 0 past the coded bands
+        dct4_inplace(x, L);
+    };
+
+    float prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // hca.cpp:962: the overlap tail starts as zeros
+    PlainPre pre = load_pre(-1);
+    const uint8_t* rows = row0(-1);                        // rows of the current step's frame
+    uint4 q = *(const uint4*)(rows + 7 * C * 256);
+    const uint32_t last_count = unit_count(3);             // frames of the last group: steps below it have every group at work
+    const uint32_t group_dwords = h * 512 * C;             // output dwords between the frames of consecutive groups
+    // step -1 is the halo: the subframe before each group's first one (its frame's subframe 7) only feeds the overlap state
+#pragma unroll 1
+    for (int s = -1; s < (int)h; s++) {
+        const uint8_t* next_rows = s + 1 < (int)h ? row0(s + 1) : rows;
+        {
+            const PlainPre cur = pre;
+            if (s + 1 < (int)h) pre = load_pre(s + 1);
+            wave_lds_sync();                               // (the previous pass has read G)
+            if (!setup(cur)) return;                       // (a group's halo frame is one of the run's own, except the first group's)
+        }
+#pragma unroll 1
+        for (uint32_t sf = s < 0 ? 7 : 0; sf < 8; sf++) {
+            const uint4 qc = q;
+            q = *(const uint4*)(sf < 7 ? rows + (sf + 1) * (C * 256) : next_rows);
+            f2 x[4];
+            dct_pass(qc, x);
+            if (s < 0) {
+                bool live; unit_frame(u, -1, live);
+#pragma unroll
+                for (int j = 0; j < 4; j++) prev[j] = live ? x[j].x : 0.0f;
+                continue;
+            }
+            // window + overlap-add (hca.cpp:1987-1992), PCM16 (hca.cpp:339-360)
+            f2 o[4];
+            float big = 0.0f;
+            const float4 w0 = *(const float4*)wtab, w1 = *(const float4*)(wtab + 4);
+            const float wa[4] = {w0.x, w0.z, w1.x, w1.z}, wb[4] = {w0.y, w0.w, w1.y, w1.w};
+            const uint4 pov = *(const uint4*)potab;
+            const uint32_t po[4] = {pov.x, pov.y, pov.z, pov.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float dy = x[j].y, pv = prev[j];
+                const f2 t = f2{wa[j], wb[j]} * f2{dy, dy};          // w[63-k]*d[127-k], w[64+k]*d[127-k]
+                const f2 r = f2{wb[j], wa[j]} * f2{pv, pv};          // w[64+k]*prev[k],  w[63-k]*prev[k]
+                o[j] = (t + f2{r.x, -r.y}) * f2{32768.0f, 32768.0f};
+                prev[j] = x[j].x;
+                big = __builtin_fmaxf(big, __builtin_fmaxf(__builtin_fabsf(o[j].x), __builtin_fabsf(o[j].y)));
+            }
+            // (|value| >= 2^31 needs x86 cvttss2si semantics; values here are finite: gains and lines are)
+            if (__builtin_expect(__any(!(big < 2147483648.0f)), 0)) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float ox = o[j].x, oy = o[j].y;
+                    asm volatile("" : "+v"(ox), "+v"(oy));          // keep this path's arithmetic inside the branch
+                    int32_t q0 = cvt_trunc_x86(ox), q1 = cvt_trunc_x86(oy);
+                    q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
+                    q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
+                    *(uint16_t*)(pcmb + (po_sum - po[j])) = (uint16_t)(int16_t)q0;
+                    *(uint16_t*)(pcmb + po[j]) = (uint16_t)(int16_t)q1;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    typedef short s2 __attribute__((ext_vector_type(2)));
+                    const s2 pk = __builtin_amdgcn_cvt_pk_i16((int32_t)o[j].x, (int32_t)o[j].y);     // saturating
+                    *(uint16_t*)(pcmb + (po_sum - po[j])) = (uint16_t)pk.x;
+                    *(uint16_t*)(pcmb + po[j]) = (uint16_t)pk.y;
+                }
+            }
+            wave_lds_sync();
+            // 256*C contiguous bytes per group; delay / length trim of hca.cpp:3392-3425
+            const uint32_t n00 = (f0 + (uint32_t)s) * 1024 + sf * 128;   // first sample (per channel) of group 0's subframe
+            if (dword_ok && (uint32_t)s < last_count && n00 >= st.delay && n00 + (NG - 1) * h * 1024 + 128 - st.delay <= st.samples) {
+                uint32_t* q0 = (uint32_t*)(dst + (uint64_t)(n00 - st.delay) * C * 2) + lane;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) q0[(k / C) * group_dwords + (k % C) * 64] = ((const uint32_t*)pcm)[k * 64 + lane];
+            } else {
+#pragma unroll 1
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t gk = k / C;                           // group of dwords k*64 .. k*64+63
+                    bool live; const uint32_t f = unit_frame(gk * C, s, live);
+                    if (!live) continue;
+                    const uint32_t n0 = f * 1024 + sf * 128;
+                    const uint32_t dw = (k - gk * C) * 64 + lane;        // dword within the group's 64*C
+                    const uint32_t word = ((const uint32_t*)pcm)[k * 64 + lane];
+                    const uint32_t e0 = 2 * dw, e1 = e0 + 1;
+                    const uint32_t na = n0 + e0 / C, nb = n0 + e1 / C;
+                    const bool va = na >= st.delay && na - st.delay < st.samples, vb = nb >= st.delay && nb - st.delay < st.samples;
+                    const uint64_t oa = ((uint64_t)(na - st.delay) * C + e0 % C) * 2, ob = ((uint64_t)(nb - st.delay) * C + e1 % C) * 2;
+                    if (va && vb && dword_ok) *(uint32_t*)(dst + oa) = word;
+                    else {
+                        if (va) *(uint16_t*)(dst + oa) = (uint16_t)word;
+                        if (vb) *(uint16_t*)(dst + ob) = (uint16_t)(word >> 16);
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+        rows = next_rows;
+    }
+}
+
+#define HCA_PLAIN_LDS (2048 + 1024 + 256 + 64 + 80 + 2048 + 1024)
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
     return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + ((C * 8 + 15) & ~15) + (C * 4 + 4) * 4 + 2 * C * 128 + 64;
@@ -1277,7 +1502,9 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
 #define CRI_LAUNCH_TR(P, CH) hipLaunchKernelGGL((k_hca_transform<P, CH>), dim3(a.runs), dim3(64), lds, s, a)
         if (a.plain) switch (a.channels) {
-            case 1: CRI_LAUNCH_TR(true, 1); break; case 2: CRI_LAUNCH_TR(true, 2); break; case 4: CRI_LAUNCH_TR(true, 4); break;
+            case 1: hipLaunchKernelGGL(k_hca_transform_plain<1>, dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); break;
+            case 2: hipLaunchKernelGGL(k_hca_transform_plain<2>, dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); break;
+            case 4: hipLaunchKernelGGL(k_hca_transform_plain<4>, dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); break;
             case 6: CRI_LAUNCH_TR(true, 6); break; default: CRI_LAUNCH_TR(true, 8); break;
         } else switch (a.channels) {
             case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;
