@@ -41,6 +41,16 @@ __device__ __forceinline__ uint32_t crc16_step(uint32_t crc, uint32_t b) {
     uint32_t tt = (t << 1) ^ (t << 2) ^ ((__builtin_popcount(t) & 1) ? 0x8003u : 0u);
     return ((crc << 8) & 0xFFFF) ^ tt;
 }
+// the same for 16 message bits at once: crc' = t * x^16 mod P with t = crc ^ bits.  P = (x + 1)(x^15 + x + 1): modulo the
+// second factor x^16 = x^2 + x, so t * (x^2 + x) folds its three top bits back as h ^ h << 1; modulo x + 1 the remainder
+// is the parity of t, which decides whether x^15 + x + 1 (0x8003) is added.
+__device__ __forceinline__ uint32_t crc16_step16(uint32_t crc, uint32_t bits16) {
+    const uint32_t t = crc ^ bits16;
+    const uint32_t u = (t << 1) ^ (t << 2), h = u >> 15;
+    const uint32_t r = (u & 0x7FFF) ^ h ^ (h << 1);
+    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)__builtin_popcount(r ^ t), 0, 1);     // all ones if the parities differ
+    return r ^ (m & 0x8003u);
+}
 
 
 // Format parameters held in registers (scalar) for the whole kernel: reading them through the HcaFormat pointer inside the
@@ -120,13 +130,24 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
                 uint32_t be = 0;
                 int nb = fs - 4 * (int)(r0 + r); nb = nb > 4 ? 4 : nb;
                 if (r0 + r == 0 && (raw & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4);   // hca.cpp:1162-1164
+                if (nb == 4) {                                    // (wave-uniform) whole word: the checksum takes 16 bits per step
+                    const uint32_t sw = __builtin_amdgcn_perm(raw, raw, 0x00010203u);     // bytes in stream order, first byte on top
+                    crc = crc16_step16(crc16_step16(crc, sw >> 16), sw & 0xFFFF);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k < nb) {
+                    for (int k = 0; k < 4; k++) {
                         const uint32_t b = (raw >> (8 * k)) & 0xFF;
-                        crc = crc16_step(crc, b);
                         const uint32_t d = cipher_in_lds ? ct[b] : __ldg(ct + b);
                         be |= d << (24 - 8 * k);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k < nb) {
+                            const uint32_t b = (raw >> (8 * k)) & 0xFF;
+                            crc = crc16_step(crc, b);
+                            const uint32_t d = cipher_in_lds ? ct[b] : __ldg(ct + b);
+                            be |= d << (24 - 8 * k);
+                        }
                     }
                 }
                 rows[r * 65 + lane] = be;
