@@ -40,6 +40,8 @@ extern "C" {
 #define CRI_ERR_UNSUPPORTED (-304)
 #define CRI_ERR_AWB_HEADER (-401)   /* awb.py:37-38 "Invalid AWB header." */
 #define CRI_ERR_AWB_INTSIZE (-402)  /* awb.py:95-106 "Unknown int size." */
+#define CRI_ERR_USM_HEADER (-411)   /* usm.py:129-130 "Unsupported file type" (no CRID chunk first) */
+#define CRI_ERR_USM_CHUNK (-412)    /* usm.py:189 "Unsupported chunk type", or a chunk header cut short by the end of the file */
 #define CRI_ITEM_SKIPPED 1          /* per-item status of a job that was told to leave the item to another job */
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -93,7 +95,8 @@ int cri_device_available(void);
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct cri_job cri_job;
 
-enum { CRI_JOB_ADX_DECODE = 1, CRI_JOB_ADX_ENCODE = 2, CRI_JOB_HCA_DECODE = 3, CRI_JOB_HCA_ENCODE = 4, CRI_JOB_HCA_CRYPT = 5 };
+enum { CRI_JOB_ADX_DECODE = 1, CRI_JOB_ADX_ENCODE = 2, CRI_JOB_HCA_DECODE = 3, CRI_JOB_HCA_ENCODE = 4, CRI_JOB_HCA_CRYPT = 5,
+       CRI_JOB_USM_DEMUX = 6, CRI_JOB_SFA_PACK = 7 };
 
 typedef struct cri_adx_encode_params {
     uint32_t bitdepth, blocksize, encoding_mode, highpass_frequency, filter, adx_version, force_no_looping;
@@ -119,6 +122,32 @@ int cri_awb_index(const uint8_t* awb, size_t len, uint32_t* n_items, uint32_t* a
 int cri_job_create_awb_decode(const uint8_t* awb, size_t len, uint64_t key, cri_job** hca_job, cri_job** adx_job);
 int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
                               uint32_t force_no_looping, uint32_t quality, cri_job** job);
+
+/* USM audio (@SFA) streams: the chunk layer either side of the ADX / HCA codecs (PyCriCodecs/usm.py).  The container's
+ * tables (CRID / @UTF), video and subtitles stay with the caller.
+ *  cri_usm_audio_mask     the 32-byte audio mask of a key (USM.init_key, usm.py:47-118 = USMBuilder.init_key 1179-1252).
+ *  cri_usm_index          host-only walk over the chunk headers (USM.demux, usm.py:134-190): with chunks == NULL it returns
+ *                         the count.  payload_offset/payload_len describe chunk data from its data offset on, padding included.
+ *  cri_job_create_usm_audio_demux   one item per @SFA channel number, ascending: the channel's type-0 payloads concatenated,
+ *                         padding stripped (USM.reader, usm.py:263-277); with decrypt != 0 ADX payloads get the extractor's
+ *                         AudioMask (usm.py:313-322: bytes from 0x140 on, whole 8-byte words).  The codec of a channel is taken
+ *                         from its first payload (0x80 0x00 = ADX) instead of the @UTF header's audio_codec.  Input blob = the USM.
+ *  cri_job_create_sfa_pack          one item per audio stream (ADX or HCA file bytes): its list of @SFA chunks, concatenated --
+ *                         32-byte chunk headers, payloads padded to 0x20, "#CONTENTS END" last (USMBuilder.get_data,
+ *                         usm.py:578-716); encrypt_audio masks ADX payloads (AudioMask, usm.py:1290-1300).
+ *                         tags: cri_job_item_tags() = channel number | codec << 16 (demux), chunk count (pack). */
+typedef struct cri_usm_chunk {
+    char fourcc[4]; uint32_t chno, type, padding; uint64_t payload_offset; uint32_t payload_len, frame_time, frame_rate, pad;
+} cri_usm_chunk;
+#define CRI_USM_CODEC_ADX 2
+#define CRI_USM_CODEC_HCA 4
+int cri_usm_audio_mask(uint64_t key, uint8_t mask[32]);
+int cri_usm_index(const uint8_t* usm, size_t len, cri_usm_chunk* chunks, uint32_t cap, uint32_t* count);
+int cri_job_create_usm_audio_demux(const uint8_t* usm, size_t len, uint64_t key, uint32_t decrypt, cri_job** job);
+int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t codec, uint64_t key,
+                            uint32_t encrypt_audio, cri_job** job);
+const uint32_t* cri_job_item_tags(const cri_job* job);      /* n entries (jobs that define them), else NULL */
+const uint64_t* cri_job_item_sizes(const cri_job* job);     /* byte length of every output item (these two job kinds), else NULL */
 int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,
                              const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
 

@@ -21,7 +21,14 @@ SYMBOLS = [
     "cri_job_output_bytes", "cri_job_output_offsets", "cri_job_host_status", "cri_job_scratch_bytes", "cri_job_units",
     "cri_job_units2", "cri_job_algorithmic_bytes", "cri_job_run", "cri_job_dominant_kernel", "cri_job_destroy", "cri_job_run_host", "cri_job_enable_events",
     "cri_job_event_ms", "cri_awb_index", "cri_job_create_awb_decode", "cri_job_run_host_into",
+    "cri_usm_audio_mask", "cri_usm_index", "cri_job_create_usm_audio_demux", "cri_job_create_sfa_pack", "cri_job_item_tags", "cri_job_item_sizes",
 ]
+
+
+class UsmChunk(C.Structure):
+    _fields_ = [("fourcc", C.c_char * 4), ("chno", C.c_uint32), ("type", C.c_uint32), ("padding", C.c_uint32),
+                ("payload_offset", C.c_uint64), ("payload_len", C.c_uint32), ("frame_time", C.c_uint32),
+                ("frame_rate", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class AdxEncodeParams(C.Structure):
@@ -77,6 +84,14 @@ def lib():
     L.cri_awb_index.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), u64p, u8p, C.c_uint32]
     L.cri_job_create_awb_decode.argtypes = [vp, C.c_size_t, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.cri_job_destroy.restype = None
+    L.cri_usm_audio_mask.argtypes = [C.c_uint64, u8p]
+    L.cri_usm_index.argtypes = [vp, C.c_size_t, C.POINTER(UsmChunk), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.cri_job_create_usm_audio_demux.argtypes = [vp, C.c_size_t, C.c_uint64, C.c_uint32, C.POINTER(vp)]
+    L.cri_job_create_sfa_pack.argtypes = [vp, u64p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(vp)]
+    L.cri_job_item_tags.argtypes = [vp]
+    L.cri_job_item_tags.restype = C.POINTER(C.c_uint32)
+    L.cri_job_item_sizes.argtypes = [vp]
+    L.cri_job_item_sizes.restype = C.POINTER(C.c_uint64)
     _lib = L
     return L
 
@@ -97,7 +112,7 @@ def raise_for(code):
     (adx.cpp:32-38, pcm.cpp:35-38, hca.cpp:3252-3268)."""
     if code == 0:
         return
-    if code == -3:
+    if code == -3 or code in (-411, -412):                 # usm.py:130, 189 raise NotImplementedError too
         raise NotImplementedError(strerror(code))
     if -18 <= code <= -1 or -110 <= code <= -101 or -216 <= code <= -201:
         raise ValueError(strerror(code))

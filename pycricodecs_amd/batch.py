@@ -8,7 +8,7 @@ import numpy as np
 
 from . import _capi
 
-KIND_NAMES = {1: "adx_decode", 2: "adx_encode", 3: "hca_decode", 4: "hca_encode", 5: "hca_crypt"}
+KIND_NAMES = {1: "adx_decode", 2: "adx_encode", 3: "hca_decode", 4: "hca_encode", 5: "hca_crypt", 6: "usm_demux", 7: "sfa_pack"}
 
 
 def pack(items):
@@ -37,6 +37,10 @@ class Job:
         self.dominant_kernel = L.cri_job_dominant_kernel(handle).decode()
         self.output_offsets = np.ctypeslib.as_array(L.cri_job_output_offsets(handle), shape=(self.n + 1,)).copy()
         self.host_status = np.ctypeslib.as_array(L.cri_job_host_status(handle), shape=(max(self.n, 1),)).copy()[:self.n]
+        tags = L.cri_job_item_tags(handle)
+        self.item_tags = np.ctypeslib.as_array(tags, shape=(self.n,)).copy() if tags else None
+        sizes = L.cri_job_item_sizes(handle)
+        self.item_sizes = np.ctypeslib.as_array(sizes, shape=(self.n,)).copy() if sizes else None
 
     def __del__(self):
         try:
@@ -78,6 +82,27 @@ class Job:
         if rc:
             _capi.raise_for(rc)
         return cls(hh, awb, offs), cls(ha, awb, offs)
+
+    @classmethod
+    def usm_audio_demux(cls, usm, key=0, decrypt=False):
+        """One item per @SFA channel of a USM container (ascending channel number): its audio stream as the reference's
+        USM.demux() returns it.  item_tags = channel | codec << 16 (2 ADX, 4 HCA).  The input blob is the container."""
+        buf = usm if isinstance(usm, bytes) else bytes(usm)
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_usm_audio_demux(buf, len(buf), key & 0xFFFFFFFFFFFFFFFF, int(bool(decrypt)), C.byref(h))
+        if rc:
+            _capi.raise_for(rc)
+        return cls(h, buf, np.array([0, len(buf)], dtype=np.uint64))
+
+    @classmethod
+    def sfa_pack(cls, items, codec, key=0, encrypt_audio=False):
+        """ADX (codec 2) or HCA (codec 4) files -> their @SFA chunk streams (USMBuilder.get_data, usm.py:578-716).
+        item_tags = chunks per item."""
+        blob, offs, buf = cls._blob_args(items)
+        h = C.c_void_p()
+        rc = _capi.lib().cri_job_create_sfa_pack(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), codec,
+                                                 key & 0xFFFFFFFFFFFFFFFF, int(bool(encrypt_audio)), C.byref(h))
+        return cls._finish(rc, h, blob, offs)
 
     @classmethod
     def adx_decode(cls, items):
@@ -158,6 +183,8 @@ class Job:
             return int.from_bytes(blob[o + 4:o + 8], "little") + 8 if blob[o:o + 4] == b"RIFF" else 0
         if self.kind == "hca_crypt":
             return int(self.offsets[i + 1] - self.offsets[i])
+        if self.item_sizes is not None:
+            return int(self.item_sizes[i])
         return None
 
     def split(self, blob):

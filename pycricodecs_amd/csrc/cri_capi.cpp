@@ -66,6 +66,10 @@ struct cri_job {
     uint32_t adx_streams = 0;                    // number of valid ADX streams
     bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
     CryptArgs crypt{};
+    SegmentArgs seg{};                           // USM demux / SFA pack: segment copies (+ audio mask)
+    DevBuf d_segs;
+    std::vector<uint32_t> item_tags;
+    std::vector<uint64_t> item_sizes;             // true byte length of every output item (jobs whose items carry no length of their own)
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
     std::vector<HcaEncArgs> hca_enc;
     std::vector<uint32_t> hca_enc_crc_off;       // per launch: offset into d_crcmul
@@ -146,6 +150,8 @@ extern "C" const char* cri_strerror(int code) {
         case CRI_ERR_UNSUPPORTED: return "Input is valid for the reference but not yet supported by the device path.";
         case CRI_ERR_AWB_HEADER: return "Invalid AWB header.";                     // awb.py:38
         case CRI_ERR_AWB_INTSIZE: return "Unknown int size.";                      // awb.py:106
+        case CRI_ERR_USM_HEADER: return "Unsupported file type";                   // usm.py:130
+        case CRI_ERR_USM_CHUNK: return "Unsupported chunk type";                   // usm.py:189
         case CRI_ITEM_SKIPPED: return "Item is not handled by this job.";
     }
     if (code <= -211 && code >= -216) return "Decoding error, either an incorrect key or an unknown exception.";
@@ -444,6 +450,230 @@ extern "C" int cri_job_create_awb_decode(const uint8_t* awb, size_t len, uint64_
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------ USM audio chunks
+extern "C" int cri_usm_audio_mask(uint64_t key, uint8_t mask[32]) {
+    if (!mask) return CRI_ERR_INVALID_ARG;
+    // usm.py:60-117 (USM.init_key); key1 = low 32 bits, key2 = high 32 bits, both big-endian byte strings
+    const uint8_t k1[4] = {(uint8_t)(key >> 24), (uint8_t)(key >> 16), (uint8_t)(key >> 8), (uint8_t)key};
+    const uint8_t k2[4] = {(uint8_t)(key >> 56), (uint8_t)(key >> 48), (uint8_t)(key >> 40), (uint8_t)(key >> 32)};
+    uint8_t t[32];
+    t[0x00] = k1[3]; t[0x01] = k1[2]; t[0x02] = k1[1]; t[0x03] = (uint8_t)(k1[0] - 0x34);
+    t[0x04] = (uint8_t)(k2[3] + 0xF9); t[0x05] = (uint8_t)(k2[2] ^ 0x13); t[0x06] = (uint8_t)(k2[1] + 0x61);
+    t[0x07] = (uint8_t)(k1[3] ^ 0xFF); t[0x08] = (uint8_t)(k1[1] + k1[2]);
+    t[0x09] = (uint8_t)(t[0x01] - t[0x07]); t[0x0A] = (uint8_t)(t[0x02] ^ 0xFF); t[0x0B] = (uint8_t)(t[0x01] ^ 0xFF);
+    t[0x0C] = (uint8_t)(t[0x0B] + t[0x09]); t[0x0D] = (uint8_t)(t[0x08] - t[0x03]);
+    t[0x0E] = (uint8_t)(t[0x0D] ^ 0xFF); t[0x0F] = (uint8_t)(t[0x0A] - t[0x0B]);
+    t[0x10] = (uint8_t)(t[0x08] - t[0x0F]);
+    t[0x11] = (uint8_t)(t[0x10] ^ t[0x07]); t[0x12] = (uint8_t)(t[0x0F] ^ 0xFF); t[0x13] = (uint8_t)(t[0x03] ^ 0x10);
+    t[0x14] = (uint8_t)(t[0x04] - 0x32); t[0x15] = (uint8_t)(t[0x05] + 0xED); t[0x16] = (uint8_t)(t[0x06] ^ 0xF3);
+    t[0x17] = (uint8_t)(t[0x13] - t[0x0F]); t[0x18] = (uint8_t)(t[0x15] + t[0x07]); t[0x19] = (uint8_t)(0x21 - t[0x13]);
+    t[0x1A] = (uint8_t)(t[0x14] ^ t[0x17]); t[0x1B] = (uint8_t)(t[0x16] + t[0x16]);
+    t[0x1C] = (uint8_t)(t[0x17] + 0x44); t[0x1D] = (uint8_t)(t[0x03] + t[0x04]); t[0x1E] = (uint8_t)(t[0x05] - t[0x16]);
+    t[0x1F] = (uint8_t)(t[0x1D] ^ t[0x13]);
+    static const char urug[4] = {'U', 'R', 'U', 'C'};
+    for (int x = 0; x < 32; x++) mask[x] = (x & 1) ? (uint8_t)urug[(x >> 1) & 3] : (uint8_t)(t[x] ^ 0xFF);   // videomask2 = ~t
+    return 0;
+}
+
+static bool usm_known_fourcc(const uint8_t* p) {             // chunk.py:14-24
+    static const char* names[] = {"CRID", "SFSH", "@SFV", "@SFA", "@ALP", "@CUE", "@SBT", "@AHX", "@USR", "@PST"};
+    for (const char* n : names) if (memcmp(p, n, 4) == 0) return true;
+    return false;
+}
+
+extern "C" int cri_usm_index(const uint8_t* usm, size_t len, cri_usm_chunk* chunks, uint32_t cap, uint32_t* count) {
+    if (!usm || !count) return CRI_ERR_INVALID_ARG;
+    if (len < 4 || memcmp(usm, "CRID", 4) != 0) return CRI_ERR_USM_HEADER;
+    uint32_t n = 0;
+    uint64_t pos = 0;
+    while (pos < len) {                                      // usm.py:138-190: USMChunkHeader = ">4sIBBHBBBBIIII"
+        if (len - pos < 0x20) return CRI_ERR_USM_CHUNK;
+        const uint8_t* h = usm + pos;
+        if (!usm_known_fourcc(h)) return CRI_ERR_USM_CHUNK;
+        const uint32_t size = be32(h + 4), offset = h[9], padding = ((uint32_t)h[10] << 8) | h[11];
+        if (size < 0x18 || offset < 0x18) return CRI_ERR_USM_CHUNK;
+        const uint64_t data = pos + 0x20, data_len = std::min<uint64_t>(size - 0x18, len - data);
+        const uint64_t skip = std::min<uint64_t>(offset - 0x18, data_len);
+        if (chunks) {
+            if (n >= cap) return CRI_ERR_INVALID_ARG;
+            cri_usm_chunk& c = chunks[n];
+            memcpy(c.fourcc, h, 4); c.chno = h[12]; c.type = h[15]; c.padding = padding;
+            c.payload_offset = data + skip; c.payload_len = (uint32_t)(data_len - skip);
+            c.frame_time = be32(h + 16); c.frame_rate = be32(h + 20); c.pad = 0;
+        }
+        n++;
+        pos = data + (uint64_t)(size - 0x18);
+    }
+    *count = n;
+    return 0;
+}
+
+static int upload_segments(cri_job* j, const std::vector<Segment>& segs, const uint8_t mask[32]) {
+    j->seg.n = (uint32_t)segs.size();
+    memcpy(j->seg.mask, mask, 32);
+    j->dominant = "k_usm_segments";
+    if (segs.empty()) return 0;
+    return j->d_segs.upload(segs);
+}
+
+extern "C" int cri_job_create_usm_audio_demux(const uint8_t* usm, size_t len, uint64_t key, uint32_t decrypt, cri_job** out) {
+    if (!usm || !out) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    uint32_t nc = 0;
+    int rc = cri_usm_index(usm, len, nullptr, 0, &nc);
+    if (rc) return rc;
+    std::vector<cri_usm_chunk> chunks(nc ? nc : 1);
+    rc = cri_usm_index(usm, len, chunks.data(), nc, &nc);
+    if (rc) return rc;
+    // channels that carry @SFA data, ascending
+    std::vector<int> item_of(256, -1);
+    std::vector<uint32_t> chnos;
+    for (uint32_t k = 0; k < nc; k++) if (memcmp(chunks[k].fourcc, "@SFA", 4) == 0 && chunks[k].type == 0) item_of[chunks[k].chno & 255] = 0;
+    for (uint32_t c = 0; c < 256; c++) if (item_of[c] == 0) { item_of[c] = (int)chnos.size(); chnos.push_back(c); }
+    const uint32_t n = (uint32_t)chnos.size();
+    std::vector<uint64_t> in_off(n + 1, 0);
+    for (uint32_t i = 0; i <= n; i++) in_off[i] = i == n ? (uint64_t)len : 0;          // every item reads the one container
+    cri_job* j = new_job(CRI_JOB_USM_DEMUX, in_off.data(), n);
+    j->in_bytes = len;
+    std::vector<uint64_t> size(n, 0);
+    std::vector<uint32_t> codec(n, 0);
+    for (uint32_t k = 0; k < nc; k++) {
+        const cri_usm_chunk& c = chunks[k];
+        if (memcmp(c.fourcc, "@SFA", 4) != 0 || c.type != 0) continue;
+        const int i = item_of[c.chno & 255];
+        if (!codec[i]) codec[i] = (c.payload_len >= 2 && usm[c.payload_offset] == 0x80 && usm[c.payload_offset + 1] == 0x00) ? CRI_USM_CODEC_ADX : CRI_USM_CODEC_HCA;
+        size[i] += c.payload_len > c.padding ? c.payload_len - c.padding : 0;
+    }
+    uint64_t pos = 0;
+    std::vector<uint64_t> cur(n);
+    for (uint32_t i = 0; i < n; i++) { j->out_offsets[i] = cur[i] = pos; pos = align_up(pos + size[i], 64); }
+    j->out_offsets[n] = pos; j->out_bytes = pos;
+    std::vector<Segment> segs;
+    for (uint32_t k = 0; k < nc; k++) {
+        const cri_usm_chunk& c = chunks[k];
+        if (memcmp(c.fourcc, "@SFA", 4) != 0 || c.type != 0) continue;
+        const int i = item_of[c.chno & 255];
+        Segment g; memset(&g, 0, sizeof g);
+        g.src = c.payload_offset; g.dst = cur[i]; g.len = c.payload_len > c.padding ? c.payload_len - c.padding : 0;
+        g.mask_begin = g.mask_end = 0xFFFFFFFFu;
+        if (decrypt && codec[i] == CRI_USM_CODEC_ADX && c.payload_len > 0x140) {      // usm.py:313-322: whole 8-byte words after 0x140, padding included
+            g.mask_begin = 0x140; g.mask_end = 0x140 + ((c.payload_len - 0x140) / 8) * 8;
+        }
+        cur[i] += g.len;
+        j->alg_bytes += 2ull * g.len;
+        if (g.len) segs.push_back(g);
+    }
+    j->units = segs.size();
+    for (uint32_t i = 0; i < n; i++) { j->item_tags.push_back(chnos[i] | (codec[i] << 16)); j->item_sizes.push_back(size[i]); }
+    uint8_t mask[32];
+    cri_usm_audio_mask(key, mask);
+    rc = upload_segments(j, segs, mask);
+    if (rc) { delete j; return rc; }
+    *out = j;
+    return 0;
+}
+
+// USMChunkHeader.pack(...) of an @SFA chunk (chunk.py:5, usm.py:599-613)
+static void sfa_chunk_header(std::vector<uint8_t>& h, uint32_t size, uint32_t padding, uint32_t chno, uint32_t type, uint32_t frame_time, uint32_t frame_rate) {
+    h.assign(0x20, 0);
+    memcpy(h.data(), "@SFA", 4);
+    h[4] = (uint8_t)(size >> 24); h[5] = (uint8_t)(size >> 16); h[6] = (uint8_t)(size >> 8); h[7] = (uint8_t)size;
+    h[9] = 0x18; h[10] = (uint8_t)(padding >> 8); h[11] = (uint8_t)padding; h[12] = (uint8_t)chno; h[15] = (uint8_t)type;
+    h[16] = (uint8_t)(frame_time >> 24); h[17] = (uint8_t)(frame_time >> 16); h[18] = (uint8_t)(frame_time >> 8); h[19] = (uint8_t)frame_time;
+    h[20] = (uint8_t)(frame_rate >> 24); h[21] = (uint8_t)(frame_rate >> 16); h[22] = (uint8_t)(frame_rate >> 8); h[23] = (uint8_t)frame_rate;
+}
+
+extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t codec, uint64_t key,
+                                       uint32_t encrypt_audio, cri_job** out) {
+    if (!blob || !offsets || !out || (codec != CRI_USM_CODEC_ADX && codec != CRI_USM_CODEC_HCA)) return CRI_ERR_INVALID_ARG;
+    if (!cri_device_available()) return CRI_ERR_HIP;
+    cri_job* j = new_job(CRI_JOB_SFA_PACK, offsets, n);
+    std::vector<Segment> segs;
+    uint64_t out_pos = 0;
+    std::vector<uint8_t> hdr;
+    // one chunk: header image + payload segment (+ zero padding: the output is cleared by the header images' gaps -- see below)
+    auto emit = [&](uint32_t item, uint64_t src, uint32_t len, uint32_t frame_time, bool mask) {
+        const uint32_t padding = len % 0x20 ? 0x20 - len % 0x20 : 0;
+        sfa_chunk_header(hdr, len + 0x18 + padding, padding, item, 0, frame_time, 2997);
+        Image im; im.dst = out_pos; im.bytes = hdr;
+        im.bytes.resize(0x20);
+        j->images.push_back(im);
+        Segment g; memset(&g, 0, sizeof g);
+        g.src = src; g.dst = out_pos + 0x20; g.len = len; g.mask_begin = g.mask_end = 0xFFFFFFFFu;
+        if (mask && len > 0x140) { g.mask_begin = 0x140; g.mask_end = len; }             // usm.py:1290-1300: every byte from 0x140 on
+        if (len) segs.push_back(g);
+        if (padding) { Image z; z.dst = out_pos + 0x20 + len; z.bytes.assign(padding, 0); j->images.push_back(z); }
+        out_pos += 0x20 + len + padding;
+        j->alg_bytes += 2ull * len;
+    };
+    auto contents_end = [&](uint32_t item) {                     // usm.py:640-657: type 2, appended to the stream's last chunk
+        sfa_chunk_header(hdr, 0x38, 0, item, 2, 0, 30);
+        Image im; im.dst = out_pos; im.bytes = hdr;
+        static const char tail[] = "#CONTENTS END   ===============";
+        im.bytes.insert(im.bytes.end(), tail, tail + 32);        // 31 characters + NUL
+        j->images.push_back(im);
+        out_pos += 0x40;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        j->out_offsets[i] = out_pos;
+        const uint8_t* d = blob + offsets[i];
+        const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        uint32_t chunks = 0;
+        if (codec == CRI_USM_CODEC_HCA) {                        // usm.py:659-716
+            HcaHeader h;
+            const uint32_t hs = len >= 8 ? (((uint32_t)d[6] << 8) | d[7]) : 0;
+            int rc = hca_parse_header(d, len, hs, h);
+            if (rc) { j->host_status[i] = rc; j->item_tags.push_back(0); continue; }
+            emit(i, offsets[i], h.header_size, 0, false); chunks++;
+            uint32_t t = 0;
+            for (uint32_t f = 0; f < h.frame_count; f++) {       // hca.py:297-301 get_frames: FrameSize bytes each
+                const uint64_t fo = (uint64_t)h.header_size + (uint64_t)f * h.frame_size;
+                if (fo + h.frame_size > len) break;
+                emit(i, offsets[i] + fo, h.frame_size, t, false); chunks++;
+                t += 64;                                         // base_interval_per_SFA_chunk, usm.py:1177
+            }
+            contents_end(i);
+        } else {                                                 // usm.py:584-657 (for an ADX file: filetype "adx")
+            AdxHeader h;
+            int rc = adx_parse_header(d, len, h);
+            if (rc) { j->host_status[i] = rc; j->item_tags.push_back(0); continue; }
+            const uint32_t cs = (uint32_t)((double)(uint32_t)((double)h.rate / 29.97) / 32.0);   // int(rate // 29.97 // 32)
+            const uint32_t chunk = cs * (h.blocksize * h.channels);
+            const uint32_t first = h.data_offset + 4;
+            if (chunk == 0 || len < (size_t)h.blocksize + first) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->item_tags.push_back(0); continue; }
+            const uint64_t stream_size = len - h.blocksize;
+            uint64_t tell = 0; uint32_t count = 0, interval = 0;
+            while (tell < stream_size) {
+                uint32_t take;
+                if (tell == 0) take = first;
+                else take = tell + chunk > stream_size ? (uint32_t)((stream_size - first - chunk) % chunk) : chunk;
+                take = (uint32_t)std::min<uint64_t>(take, len - tell);
+                if (take == 0) break;
+                emit(i, offsets[i] + tell, take, interval, encrypt_audio != 0); chunks++;
+                tell += take;
+                interval = (uint32_t)(int64_t)((double)count * 99.9);                    // usm.py:619, 1168 (the builder is VP9 only)
+                count++;
+            }
+            emit(i, offsets[i] + tell, (uint32_t)std::min<uint64_t>(h.blocksize, len - tell), interval, false); chunks++;
+            contents_end(i);
+        }
+        j->item_tags.push_back(chunks);
+        j->units += chunks;
+    }
+    j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    for (uint32_t i = 0; i < n; i++) j->item_sizes.push_back(j->out_offsets[i + 1] - j->out_offsets[i]);
+    uint8_t mask[32];
+    cri_usm_audio_mask(key, mask);
+    int rc = j->upload_images();
+    if (!rc) rc = upload_segments(j, segs, mask);
+    if (rc) { delete j; return rc; }
+    *out = j;
+    return 0;
+}
+
+extern "C" const uint64_t* cri_job_item_sizes(const cri_job* j) { return j && j->item_sizes.size() == j->n && j->n ? j->item_sizes.data() : nullptr; }
+extern "C" const uint32_t* cri_job_item_tags(const cri_job* j) { return j && j->item_tags.size() == j->n && j->n ? j->item_tags.data() : nullptr; }
+
 // ------------------------------------------------------------------------------------------------ ADX encode
 extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const cri_adx_encode_params* p, cri_job** out) {
     if (!blob || !offsets || !out || !p) return CRI_ERR_INVALID_ARG;
@@ -713,6 +943,13 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
             a.frame_sizes = (const uint32_t*)j->d_frame_sizes.p; a.cipher_tables = (const uint8_t*)j->d_cipher.p;
             a.first_frame = (const uint32_t*)j->d_first_frame.p;
             j->mark(0, true, s); launch_hca_crypt(a, s); j->mark(0, false, s);
+            break;
+        }
+        case CRI_JOB_USM_DEMUX:
+        case CRI_JOB_SFA_PACK: {
+            SegmentArgs a = j->seg;
+            a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.segs = (const Segment*)j->d_segs.p;
+            j->mark(0, true, s); launch_segments(a, s); j->mark(0, false, s);
             break;
         }
         default: return CRI_ERR_UNSUPPORTED;

@@ -330,9 +330,6 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 
     const uint32_t g = tile * 64 + lane;
     const bool valid = g < a.frames;
-    uint32_t si = a.stream_begin, f = 0;
-    if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
-    const HcaStream st = a.streams[si];
     // the records of a format group are consecutive in frame order (cri_capi.cpp): frame g's starts at group base + g * record_bytes
     uint8_t* tile_rec = a.scratch + a.streams[a.stream_begin].scratch_offset + (uint64_t)tile * 64 * F.record_bytes;
     uint8_t* rec = tile_rec + (uint64_t)lane * F.record_bytes;

@@ -86,4 +86,10 @@ void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const ui
 // copies item bodies verbatim (crypt: headers are patched on the host image, frames by the kernel)
 void launch_fill_i32(int32_t* p, int32_t v, uint32_t n, hipStream_t s);
 
+// USM audio (@SFA) chunk streams, usm.py: byte segments copied between a container and contiguous streams, with the audio
+// mask (32 bytes, usm.py:112-117) XORed over bytes [mask_begin, mask_end) of a segment
+struct Segment { uint64_t src, dst; uint32_t len, mask_begin, mask_end, pad; };
+struct SegmentArgs { const uint8_t* in; uint8_t* out; const Segment* segs; uint32_t n; uint32_t mask[8]; };
+void launch_segments(const SegmentArgs& a, hipStream_t s);
+
 }  // namespace cri

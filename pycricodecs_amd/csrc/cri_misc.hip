@@ -29,6 +29,47 @@ void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const ui
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// @SFA chunk payloads <-> contiguous audio streams (usm.py:263-277 reader, 313-322 / 1290-1300 AudioMask, 584-716 chunking):
+// one wave per segment; bytes [mask_begin, mask_end) of a segment are XORed with mask[(j - mask_begin) % 32]
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_usm_segments(SegmentArgs a) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+        const Segment g = a.segs[i];
+        const uint8_t* src = a.in + g.src;
+        uint8_t* dst = a.out + g.dst;
+        if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0 && (g.mask_begin & 3) == 0) {
+            const uint32_t nd = g.len >> 2;
+            for (uint32_t d = lane; d < nd; d += 64) {
+                uint32_t w = ((const uint32_t*)src)[d];
+                const uint32_t j = d * 4;
+                if (j + 4 > g.mask_begin && j < g.mask_end) {
+                    uint32_t m = a.mask[((j - g.mask_begin) >> 2) & 7];
+                    if (j + 4 > g.mask_end) m &= 0xFFFFFFFFu >> (8 * (j + 4 - g.mask_end));   // the mask stops inside this word
+                    w ^= j >= g.mask_begin ? m : 0u;
+                }
+                ((uint32_t*)dst)[d] = w;
+            }
+            for (uint32_t j = (nd << 2) + lane; j < g.len; j += 64) {
+                uint8_t b = src[j];
+                if (j >= g.mask_begin && j < g.mask_end) b ^= (uint8_t)(a.mask[((j - g.mask_begin) >> 2) & 7] >> (8 * ((j - g.mask_begin) & 3)));
+                dst[j] = b;
+            }
+        } else {
+            for (uint32_t j = lane; j < g.len; j += 64) {
+                uint8_t b = src[j];
+                if (j >= g.mask_begin && j < g.mask_end) b ^= (uint8_t)(a.mask[((j - g.mask_begin) >> 2) & 7] >> (8 * ((j - g.mask_begin) & 3)));
+                dst[j] = b;
+            }
+        }
+    }
+}
+void launch_segments(const SegmentArgs& a, hipStream_t s) {
+    if (!a.n) return;
+    hipLaunchKernelGGL(k_usm_segments, dim3(a.n < (1u << 20) ? a.n : (1u << 20)), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // PCM::Get_PCM16 for WAV data that is not already 16-bit (pcm.cpp:455-545): one thread per sample, int16 into scratch
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_pcm_convert(ConvertArgs a) {

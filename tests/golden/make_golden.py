@@ -164,6 +164,97 @@ def main():
         put(name, data)
         py_info.append({"label": label, "file": name, "key": key, "info": {k: (v if isinstance(v, (int, str, float, bool, type(None))) else repr(v)) for k, v in info.items()}})
     man["py_info"] = py_info
+    # USM audio layer (usm.py): the audio mask of a key, the reference builder's @SFA chunks for an HCA stream, and the
+    # reference demuxer's output for well-formed containers.  The reference's USMBuilder writes a container its own USM
+    # class cannot read (a metadata chunk's size field is 16 bytes long), and its ADX branch needs an ADX object the package
+    # no longer has, so the demux fixtures are assembled here: CRID chunk from the reference builder, @SFA header chunk
+    # from the reference's UTFBuilder, data chunks packed with USMChunkHeader, payloads masked with the reference's own
+    # AudioMask.
+    import struct
+    from PyCriCodecs.usm import USM as RefUSM, USMBuilder as RefUSMBuilder
+    from PyCriCodecs.utf import UTFBuilder as RefUTFBuilder
+    from PyCriCodecs.chunk import UTFTypeValues, USMChunkHeader
+
+    class _Keyed(RefUSM):
+        def __init__(self, key):
+            self.init_key(key)
+    usm = {"masks": []}
+    for key in (0x0123456789ABCDEF, 0xCF222F1FE0748978, 1, 0xFFFFFFFFFFFFFFFF, "7F4551499DF55E68", "1234"):
+        usm["masks"].append({"key": key, "mask": bytes(_Keyed(key).audiomask).hex()})
+
+    def tiny_ivf(nframes=3):
+        body = b""
+        for i in range(nframes):
+            data = (b"\x82I\x83B" if i == 0 else b"\x86\x00") + bytes((i * 7 + k) & 0xFF for k in range(100 + 13 * i))
+            body += struct.pack("<IQ", len(data), i) + data
+        return struct.pack("<4sHH4sHHIIII", b"DKIF", 0, 32, b"VP90", 64, 64, 30, 1, nframes, 0) + body
+    hca_stream = R.hca_encode(synth.wav(5, 3000, 2, 48000), 1)
+    adx_stream = R.adx_encode(synth.wav(6, 9600, 2, 48000))
+    with tempfile.TemporaryDirectory() as td:
+        pi, ph = os.path.join(td, "t.ivf"), os.path.join(td, "t.hca")
+        open(pi, "wb").write(tiny_ivf()); open(ph, "wb").write(hca_stream)
+        bld = RefUSMBuilder(pi, audio=ph, audio_codec="hca")
+        bld.build()
+        built = bytes(bld.get_usm())
+    put("usm_ref_built_hca.usm", built)
+    put("usm_audio.hca", hca_stream)
+    put("usm_audio.adx", adx_stream)
+    try:
+        RefUSM(built).demux()
+        ref_reads_own = True
+    except NotImplementedError:
+        ref_reads_own = False
+    usm["ref_built"] = {"file": "usm_ref_built_hca.usm", "sha": sha(built), "audio": "usm_audio.hca", "reference_demux_ok": ref_reads_own}
+
+    def chunk(sig, payload, chno, typ, frame_time=0, frame_rate=2997):
+        pad = -len(payload) % 0x20
+        return USMChunkHeader.pack(sig, len(payload) + 0x18 + pad, 0, 0x18, pad, chno, 0, 0, typ, frame_time, frame_rate, 0, 0) + payload + b"\0" * pad
+
+    def audio_header(codec):
+        info = [{"audio_codec": (UTFTypeValues.uchar, codec), "ixsize": (UTFTypeValues.uint, 27860),
+                 "metadata_count": (UTFTypeValues.uint, 0), "metadat_size": (UTFTypeValues.uint, 0),
+                 "num_channels": (UTFTypeValues.uchar, 2), "sampling_rate": (UTFTypeValues.uint, 48000),
+                 "total_samples": (UTFTypeValues.uint, 9600)}]
+        b = RefUTFBuilder(info, table_name="AUDIO_HDRINFO")
+        b.strings = b"<NULL>\x00" + b.strings
+        return chunk(b"@SFA", b.parse(), 0, 1, 0, 30)
+    crid = built[:0x800]                                   # (the reference builder's video header chunk follows it, 0x800-0xa00)
+    assert built[0x800:0x804] == b"@SFV" and built[0xa00:0xa04] == b"@SFA"
+    usm["demux"] = []
+    for name, stream, codec, key, sizes in [("usm_hca_plain.usm", hca_stream, 4, False, None), ("usm_adx_plain.usm", adx_stream, 2, False, [292, 1800, 1800, 250, 1800]),
+                                           ("usm_adx_keyed.usm", adx_stream, 2, 0x0123456789ABCDEF, [292, 1800, 1800, 250, 1800]),
+                                           ("usm_hca_keyed.usm", hca_stream, 4, "7F4551499DF55E68", None)]:
+        masker = _Keyed(key) if key else None
+        parts = [crid, built[0x800:0xa00], audio_header(codec), chunk(b"@SFV", b"#HEADER END     ===============\x00", 0, 2, 0, 30),
+                 chunk(b"@SFA", b"#HEADER END     ===============\x00", 0, 2, 0, 30)]
+        pos, k = 0, 0
+        if codec == 4:
+            hs = int.from_bytes(stream[6:8], "big"); fs = int.from_bytes(stream[28:30], "big")
+            cuts = [hs] + [fs] * ((len(stream) - hs) // fs)
+        else:
+            cuts = list(sizes)
+            while sum(cuts) < len(stream):
+                cuts.append(min(1800, len(stream) - sum(cuts)))
+        for n in cuts:
+            pay = stream[pos:pos + n]; pos += n
+            pad = -len(pay) % 0x20
+            body = bytearray(pay + b"\0" * pad)
+            if masker is not None and codec == 2:
+                body = masker.AudioMask(body)              # XOR: masking = unmasking (extractor variant, whole 8-byte words)
+            parts.append(USMChunkHeader.pack(b"@SFA", len(body) + 0x18, 0, 0x18, pad, 0, 0, 0, 0, k * 100, 2997, 0, 0) + bytes(body))
+            if k % 2 == 0:
+                parts.append(chunk(b"@SFV", bytes((7 * k + j) & 0xFF for j in range(0x260 + 8 * k)), 0, 0, k * 100, 3000))
+            k += 1
+        parts.append(chunk(b"@SFV", b"#CONTENTS END   ===============\x00", 0, 2, 0, 30))
+        parts.append(chunk(b"@SFA", b"#CONTENTS END   ===============\x00", 0, 2, 0, 30))
+        data = b"".join(parts)
+        put(name, data)
+        ru = RefUSM(data, key=key)
+        ru.demux()
+        out = bytes(ru.output["@SFA_0"])
+        assert out == stream, name
+        usm["demux"].append({"file": name, "key": key, "codec": codec, "sfa_0_sha": sha(out), "sfa_0_len": len(out), "stream": "usm_audio.hca" if codec == 4 else "usm_audio.adx"})
+    man["usm"] = usm
     # generator-independent known answers
     man["known"] = {"crc16_123456789": 0xFEE8,
                     "adx_coefs": {"500,48000": [7400, -3342], "500,44100": [7334, -3283], "500,22050": [6569, -2634], "0,48000": [8192, -4096]},

@@ -111,3 +111,34 @@ def test_info_dictionaries_match_the_reference_class():
         got = HCA(G.load(ent["file"]), key=ent["key"]).info()
         got = {k: (v if isinstance(v, (int, str, float, bool, type(None))) else repr(v)) for k, v in got.items()}
         assert got == ent["info"], ent["label"]
+
+
+def test_usm_audio_mask_and_index_match_reference(capi):
+    """cri_usm_audio_mask against the masks the reference's USM.init_key derives, and cri_usm_index (host only) on the
+    golden containers: the chunk walk, the payload ranges (their concatenation minus padding is the reference demuxer's
+    stream), and the reference's failures (no CRID, unknown chunk, its own builder's malformed container)."""
+    import golden_util as G
+    from pycricodecs_amd import usm
+    u = G.manifest()["usm"]
+    for m in u["masks"]:
+        assert usm.audio_mask(m["key"]).hex() == m["mask"], m["key"]
+    with pytest.raises(ValueError):
+        usm.audio_mask("0" * 17)
+    for d in u["demux"]:
+        data = G.load(d["file"])
+        chunks = usm.usm_index(data)
+        assert chunks[0]["fourcc"] == b"CRID" and chunks[-1]["fourcc"] == b"@SFA" and chunks[-1]["type"] == 2
+        sfa = [c for c in chunks if c["fourcc"] == b"@SFA" and c["type"] == 0]
+        if d["key"] is False or d["codec"] == 4:               # unmasked payloads: the gather alone reproduces the stream
+            got = b"".join(data[c["payload_offset"]:c["payload_offset"] + c["payload_len"] - c["padding"]] for c in sfa)
+            assert G.sha(got) == d["sfa_0_sha"] and len(got) == d["sfa_0_len"]
+        assert sum(c["payload_len"] - c["padding"] for c in sfa) == d["sfa_0_len"]
+    assert not u["ref_built"]["reference_demux_ok"]            # the reference cannot read what its builder writes ...
+    with pytest.raises(NotImplementedError, match="Unsupported chunk type"):
+        usm.usm_index(G.load(u["ref_built"]["file"]))          # ... and neither do we, the same way
+    with pytest.raises(NotImplementedError, match="Unsupported file type"):
+        usm.usm_index(b"RIFF" + bytes(60))
+    good = G.load(u["demux"][0]["file"])
+    with pytest.raises(NotImplementedError):
+        usm.usm_index(good[:-0x30])                            # a chunk header cut short (the reference dies in struct.unpack)
+    assert len(usm.usm_index(good[:-7])) == len(usm.usm_index(good))   # a short last payload is read as far as it goes
