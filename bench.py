@@ -133,6 +133,27 @@ def secondary_measurements(args, dev, rank):
     assert wav0[:len(ref)] == ref, "GPU ADX decode differs from the oracle"
     r.update(workload="ADX decode of the same files", unit="frames/s (units2 = blocks/s)", chains=2 * n, blocks=job.units2)
     res["adx_decode"] = r
+    del bufs
+    torch.cuda.empty_cache()
+    # USM audio layer: the ADX files as masked @SFA chunk streams, then the demux of a container made of them (HBM-bound copies)
+    from pycricodecs_amd import usm
+    adx_items = [adx_u[i % len(adx_u)] for i in range(n)]
+    # (a container carries at most 256 audio channels: the chunk header's channel number is one byte)
+    key = 0x0123456789ABCDEF
+    job = Job.sfa_pack(adx_items[:250], usm.CODEC_ADX, key, True)
+    bufs, r = measure(job, dev)
+    packed = bufs[1].cpu().numpy().tobytes()
+    r.update(workload="ADX files -> masked @SFA chunk streams (usm.py:584-657), %d x %.0f s" % (len(adx_items[:250]), args.seconds), unit="chunks/s", chunks=job.units)
+    res["sfa_pack"] = r
+    del bufs
+    torch.cuda.empty_cache()
+    crid = b"CRID" + (0x18).to_bytes(4, "big") + bytes([0, 0x18]) + bytes(22)      # an empty CRID chunk: only the signature is read here
+    job = Job.usm_audio_demux(crid + packed, key, True)
+    bufs, r = measure(job, dev)
+    first = bytes(bufs[1][:len(adx_items[0])].cpu().numpy())
+    assert first == adx_items[0], "USM demux does not give the ADX stream back"
+    r.update(workload="demux + AudioMask of that container (%d channels, %d chunks)" % (job.n, job.units), unit="chunks/s", chunks=job.units)
+    res["usm_demux"] = r
     return res
 
 
