@@ -130,8 +130,9 @@ int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint
  *                         the count.  payload_offset/payload_len describe chunk data from its data offset on, padding included.
  *  cri_job_create_usm_audio_demux   one item per @SFA channel number, ascending: the channel's type-0 payloads concatenated,
  *                         padding stripped (USM.reader, usm.py:263-277); with decrypt != 0 ADX payloads get the extractor's
- *                         AudioMask (usm.py:313-322: bytes from 0x140 on, whole 8-byte words).  The codec of a channel is taken
- *                         from its first payload (0x80 0x00 = ADX) instead of the @UTF header's audio_codec.  Input blob = the USM.
+ *                         AudioMask (usm.py:313-322: bytes from 0x140 on, whole 8-byte words).  As in the reference the codec is
+ *                         audio_codec of the most recent @SFA header chunk's @UTF table (usm.py:165-168); a container without
+ *                         header chunks is judged by each channel's first payload (0x80 0x00 = ADX).  Input blob = the USM.
  *  cri_job_create_sfa_pack          one item per audio stream (ADX or HCA file bytes): its list of @SFA chunks, concatenated --
  *                         32-byte chunk headers, payloads padded to 0x20, "#CONTENTS END" last (USMBuilder.get_data,
  *                         usm.py:578-716); encrypt_audio masks ADX payloads (AudioMask, usm.py:1290-1300).

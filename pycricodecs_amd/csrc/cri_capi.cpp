@@ -508,6 +508,36 @@ extern "C" int cri_usm_index(const uint8_t* usm, size_t len, cri_usm_chunk* chun
     return 0;
 }
 
+// One unsigned field of row 0 of an @UTF table, by column name (the reference's UTF class, utf.py:30-34, 53-75: 32-byte
+// header, then per column a flag byte (storage << 4 | type) and a name offset; storage 3 carries the value inline, 5 in
+// the row, 1 is the type's zero).  Enough to read AUDIO_HDRINFO.audio_codec (usm.py:165-168); encrypted tables are not read.
+static bool utf_field_u32(const uint8_t* t, size_t len, const char* name, uint32_t* value) {
+    static const uint8_t size_of[16] = {1, 1, 2, 2, 4, 4, 8, 8, 4, 8, 4, 8, 0, 0, 0, 0};   // "BbHhIiQqfdI" + bytes (offset, size)
+    if (len < 32 || memcmp(t, "@UTF", 4) != 0) return false;
+    const uint64_t rows = (uint64_t)be32(t + 8) + 8, strings = (uint64_t)be32(t + 12) + 8;
+    const uint32_t ncol = be16(t + 24);
+    uint64_t pos = 32, rowpos = rows;
+    const size_t nlen = strlen(name);
+    for (uint32_t c = 0; c < ncol; c++) {
+        if (pos + 5 > len) return false;
+        const uint32_t flag = t[pos], st = flag >> 4, sz = size_of[flag & 15];
+        const uint64_t noff = strings + be32(t + pos + 1);
+        pos += 5;
+        const uint8_t* v = nullptr;
+        if (st == 3) { v = t + pos; if (pos + sz > len) return false; pos += sz; }
+        else if (st == 5) { v = t + rowpos; if (rowpos + sz > len) return false; rowpos += sz; }
+        else if (st != 1) return false;
+        if (sz == 0) return false;
+        if (noff + nlen + 1 <= len && memcmp(t + noff, name, nlen + 1) == 0) {
+            uint64_t x = 0;
+            if (v) for (uint32_t k = 0; k < sz; k++) x = (x << 8) | v[k];
+            *value = (uint32_t)x;
+            return true;
+        }
+    }
+    return false;
+}
+
 static int upload_segments(cri_job* j, const std::vector<Segment>& segs, const uint8_t mask[32]) {
     j->seg.n = (uint32_t)segs.size();
     memcpy(j->seg.mask, mask, 32);
@@ -537,11 +567,23 @@ extern "C" int cri_job_create_usm_audio_demux(const uint8_t* usm, size_t len, ui
     j->in_bytes = len;
     std::vector<uint64_t> size(n, 0);
     std::vector<uint32_t> codec(n, 0);
+    // The reference keeps ONE codec for the whole container: audio_codec of the most recent @SFA header chunk (type 1,
+    // usm.py:165-168), and masks a payload when that is 2.  Without any header chunk the first payload decides (80 00 = ADX).
+    std::vector<uint32_t> codec_at(nc, 0);
+    uint32_t cur_codec = 0;
     for (uint32_t k = 0; k < nc; k++) {
         const cri_usm_chunk& c = chunks[k];
-        if (memcmp(c.fourcc, "@SFA", 4) != 0 || c.type != 0) continue;
+        if (memcmp(c.fourcc, "@SFA", 4) != 0) continue;
+        if (c.type == 1) {
+            uint32_t v = 0;
+            if (utf_field_u32(usm + c.payload_offset, c.payload_len, "audio_codec", &v)) cur_codec = v;
+            continue;
+        }
+        if (c.type != 0) continue;
         const int i = item_of[c.chno & 255];
-        if (!codec[i]) codec[i] = (c.payload_len >= 2 && usm[c.payload_offset] == 0x80 && usm[c.payload_offset + 1] == 0x00) ? CRI_USM_CODEC_ADX : CRI_USM_CODEC_HCA;
+        const uint32_t sniff = (c.payload_len >= 2 && usm[c.payload_offset] == 0x80 && usm[c.payload_offset + 1] == 0x00) ? CRI_USM_CODEC_ADX : CRI_USM_CODEC_HCA;
+        codec_at[k] = cur_codec ? cur_codec : (codec[i] ? codec[i] : sniff);
+        if (!codec[i]) codec[i] = cur_codec ? cur_codec : sniff;
         size[i] += c.payload_len > c.padding ? c.payload_len - c.padding : 0;
     }
     uint64_t pos = 0;
@@ -556,7 +598,7 @@ extern "C" int cri_job_create_usm_audio_demux(const uint8_t* usm, size_t len, ui
         Segment g; memset(&g, 0, sizeof g);
         g.src = c.payload_offset; g.dst = cur[i]; g.len = c.payload_len > c.padding ? c.payload_len - c.padding : 0;
         g.mask_begin = g.mask_end = 0xFFFFFFFFu;
-        if (decrypt && codec[i] == CRI_USM_CODEC_ADX && c.payload_len > 0x140) {      // usm.py:313-322: whole 8-byte words after 0x140, padding included
+        if (decrypt && codec_at[k] == CRI_USM_CODEC_ADX && c.payload_len > 0x140) {      // usm.py:313-322: whole 8-byte words after 0x140, padding included
             g.mask_begin = 0x140; g.mask_end = 0x140 + ((c.payload_len - 0x140) / 8) * 8;
         }
         cur[i] += g.len;

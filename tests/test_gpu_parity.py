@@ -562,6 +562,27 @@ def test_usm_audio_demux_golden(cc):
         assert bytes(out["@SFA_0"]) == stream
         wav = u.decode_audio()["@SFA_0"]
         assert diff(wav, O.hca_decode(stream) if d["codec"] == 4 else O.adx_decode(stream)) is None
+    # mutated chunk headers (padding, channel, type, signature, data offset): the device job against the numpy statement of
+    # the rule, which tests/test_oracle_vs_reference.py pins against the reference's USM.demux()
+    import usm_model
+    rng = np.random.default_rng(12)
+    checked = 0
+    for d in MAN["usm"]["demux"]:
+        base = G.load(d["file"])
+        key = int(d["key"], 16) if isinstance(d["key"], str) else int(d["key"])
+        heads = [c["payload_offset"] - 0x20 for c in usm.usm_index(base)][3:]
+        for _ in range(25):
+            data = usm_model.mutate(base, heads, rng)
+            try:
+                want = usm_model.demux(data, key)
+            except NotImplementedError:
+                with pytest.raises(NotImplementedError):
+                    usm.USM(data, key=d["key"]).demux()
+                continue
+            got = usm.USM(data, key=d["key"]).demux()
+            assert {int(k[5:]): bytes(v) for k, v in got.items()} == {k: bytes(v) for k, v in want.items() if len(v)}, d["file"]
+            checked += 1
+    assert checked > 50
     # a keyed ADX container read without the key stays masked (and differs)
     d = [x for x in MAN["usm"]["demux"] if x["codec"] == 2 and x["key"]][0]
     assert G.sha(bytes(usm.USM(G.load(d["file"])).demux()["@SFA_0"])) != d["sfa_0_sha"]
