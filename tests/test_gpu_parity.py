@@ -194,7 +194,7 @@ def test_hca_v3_noise_fill(cc, q, ch, n):
     assert accepted > 0
 
 
-@pytest.mark.parametrize("ch", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("ch", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_hca_multichannel_layouts(cc, ch):
     """Streams longer than one run of 8 frames (the run's halo steps) for every channel count, then forged comp chunks:
     joint-stereo bands, HFR groups, several tracks (stereo pairs starting on odd channels: 2 tracks x 3 channels) and
