@@ -68,14 +68,16 @@ struct EncTab {
     const uint16_t* crcmul;                                                 // [6][16] per launch (HcaEncArgs::crc_mul)
     const uint8_t* sfbase;                                                  // [32] entries of deq[0..62] that are <= 2^(j - 25)
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
+    const uint32_t* bnd;                                                    // [16] per resolution: fewest | most << 16 bits one spectrum can take
 };
-#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32)
+#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32 + 64)
 __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads, const uint16_t* crc_mul) {
     float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 72;
     float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
     uint8_t* curve = (uint8_t*)(ib + 16); uint8_t* clen = curve + 64; uint8_t* code = clen + 128; uint8_t* shuf = code + 128;
     uint16_t* cm = (uint16_t*)(shuf + 128);
     uint8_t* sfb = (uint8_t*)(cm + 96);
+    uint32_t* bnd = (uint32_t*)(sfb + 32);
     for (uint32_t i = tid; i < 96; i += nthreads) cm[i] = crc_mul[i];
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
@@ -87,9 +89,15 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
         for (uint32_t k = 0; k < 63; k++) n += HCA_DEQ_SCALE[k] <= thr ? 1u : 0u;
         sfb[j] = (uint8_t)n;
     }
-    for (uint32_t i = tid; i < 16; i += nthreads) { dead[i] = HCA_ENC_DEAD_ZONE[i]; inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f; }
+    for (uint32_t i = tid; i < 16; i += nthreads) {
+        dead[i] = HCA_ENC_DEAD_ZONE[i]; inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f;
+        uint32_t lo, hi;                                   // code lengths of resolution i (hca.cpp:2771-2786)
+        if (i >= 8) { hi = i - 3; lo = hi - 1; }           // sign-magnitude: max bits, one less for a zero
+        else { lo = i ? 15 : 0; hi = 0; for (uint32_t q = 8 - i; q <= 8 + i; q++) { const uint32_t l = HCA_ENC_CODE_LEN[i][q]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; } }
+        bnd[i] = lo | (hi << 16);                          // per spectrum; a band has 8
+    }
     EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
-    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb;
+    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb; T.bnd = bnd;
     return T;
 }
 
@@ -144,18 +152,27 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const EncLds&
     for (uint32_t c = 0; c < F.C; c++) {
         const int coded = (int)F.coded(c);
         const uint8_t* sf = L.sfac + c * 128;
-        int any = 0;
-        for (int b = (int)lane; b < coded; b += 64) any |= sf[b] != 0;
-        any = wave_sum(any);
+        // a delta width db codes |delta| <= 2^(db-1) - 1 in db bits and the rest in db + 6: the length is
+        // db * (coded - 1) + 6 * (deltas above the limit), so one pass counts the deltas above 0, 1, 3, 7, 15 (a byte each)
+        uint32_t w0 = 0, w1 = 0;
+        for (int b = (int)lane; b < coded; b += 64) {
+            const int cur = sf[b];
+            w1 |= cur != 0 ? 0x100u : 0u;                  // any scalefactor at all
+            if (b >= 1) {
+                int d = cur - (int)sf[b - 1]; d = d < 0 ? -d : d;
+                w0 += (d > 0 ? 1u : 0u) | (d > 1 ? 0x100u : 0u) | (d > 3 ? 0x10000u : 0u) | (d > 7 ? 0x1000000u : 0u);
+                w1 += d > 15 ? 1u : 0u;
+            }
+        }
+        w0 = (uint32_t)wave_sum((int)w0);                  // every count is at most 127
+        w1 = (uint32_t)wave_sum((int)w1);
+        const int any = (int)(w1 >> 8);
         int min_len = 3, min_db = 0;
         if (any) {
             min_db = 6; min_len = 3 + 6 * coded;
+            const int above[5] = {(int)(w0 & 0xFF), (int)((w0 >> 8) & 0xFF), (int)((w0 >> 16) & 0xFF), (int)(w0 >> 24), (int)(w1 & 0xFF)};
             for (int db = 1; db < 6; db++) {
-                const int maxd = (1 << (db - 1)) - 1;
-                int part = 0;
-                for (int b = (int)lane; b < coded; b += 64)
-                    if (b >= 1) { int d = (int)sf[b] - (int)sf[b - 1]; d = d < 0 ? -d : d; part += d > maxd ? db + 6 : db; }
-                const int length = 3 + 6 + wave_sum(part);
+                const int length = 3 + 6 + db * (coded > 0 ? coded - 1 : 0) + 6 * above[db - 1];
                 if (length < min_len) { min_len = length; min_db = db; }
             }
         }
@@ -545,19 +562,33 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
         } else return enc_used_bits(F, L, T, lane, noise, eb);
     };
     enc_header_length(F, L, lane);
+    ENC_MARK(14);
     load_bands();
+    ENC_MARK(15);
     const int avail = (int)F.frame_size * 8;
     int noise_level = -1, eval_boundary = 0, status = 0;
     {
         int highest = (int)(F.base + F.stereo) - 1;
         for (;;) {
-            int low = 0, high = 255, mid_value = 0;
+            int low = 0, high = 255;
+            bool over = false;                             // "mid_value > available bits" of the last step (hca.cpp:2806-2815)
             while (low != high) {
                 const int mid = (low + high) / 2;
-                mid_value = used_bits(mid, 0);
-                if (mid_value > avail) low = mid + 1; else high = mid;
+                if constexpr (CT > 0) {
+                    // the same decision from per-resolution bounds when they settle it (far from the answer they do): the
+                    // fewest / most bits a band of that resolution can take, summed -- no quantisation of the spectra
+                    uint32_t part = 0;
+#pragma unroll
+                    for (int b = 0; b < NB; b++) part += inr[b] ? T.bnd[enc_resolution(T, sfr[b], mid)] : 0u;
+                    const uint32_t tot = (uint32_t)wave_sum((int)part);                      // at most 2 * CT * 64 * 12 per half: no carry
+                    const int hb = header_bits(), least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
+                    if (least > avail) over = true;
+                    else if (most <= avail) over = false;
+                    else over = used_bits(mid, 0) > avail;
+                } else over = used_bits(mid, 0) > avail;
+                if (over) low = mid + 1; else high = mid;
             }
-            noise_level = (low == 255 && mid_value > avail) ? -1 : low;
+            noise_level = (low == 255 && over) ? -1 : low;
             if (noise_level >= 0) break;
             highest -= 2;
             if (highest < 0) { status = CRI_ERR_HCA_ENCODE; break; }

@@ -19,6 +19,7 @@ torch.cuda.synchronize()
 lib.cri_debug_enc_profile(out, 0)
 names = ["mdct", "intensity", "hfr+scalefactors+scale", "header+noise search", "boundary search", "resolutions+header pack", "spectra pack", "crc+store"]
 names += ["  mdct: lane constants", "  mdct: first fetch issue", "  mdct: window/fold (waits for samples)", "  mdct: next fetch issue", "  mdct: butterflies", "  mdct: spectrum store"]
-tot = sum(out[:8])
-for n, v in zip(names, list(out[:8]) + list(out[8:14])):
+tot = sum(out[:8]) + out[14] + out[15]
+names += ["  rate: header length", "  rate: band registers"]
+for n, v in zip(names, list(out[:8]) + list(out[8:16])):
     print("%-28s %5.1f %%  %8.0f cycles/frame" % (n, 100.0 * v / tot, v / (3.0 * job.units)))
