@@ -345,8 +345,9 @@ void launch_adx_encode(const AdxArgs& a, hipStream_t s) {
 // Wave-per-file variants for batches with few chains (BASELINE configs[1]: 1 000 files = 2 000 chains would keep 32 of
 // 1 024 SIMDs busy in the lane-per-chain mapping).  Standard layout only: blocksize 18, bitdepth 4, 1 or 2 channels, so
 // that one ADX frame is one wavefront: lanes 0-31 = the 32 samples of channel 0's block, lanes 32-63 = channel 1's.
-// The per-sample parts (nibble unpack, code*scale; encoder pass A residuals + min/max) run across the lanes; the
-// recurrence itself is walked sample by sample with v_readlane broadcasts, identically in every lane of a half.
+// The per-sample parts (nibble unpack, code*scale; encoder pass A residuals + min/max) run across the lanes; the encoder
+// walks its recurrence sample by sample with v_readlane broadcasts, identically in every lane of a half, the decoder hands
+// a frame's products through LDS to registers (see k_adx_decode_wpf).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t half_min(int32_t v) {
 #pragma unroll
@@ -359,71 +360,143 @@ __device__ __forceinline__ int32_t half_max(int32_t v) {
     return v;
 }
 
+// Decode.  A wave per file runs alone on its SIMD, so every dependent instruction and every memory round trip is paid in
+// full; the kernel is organised around that:
+//  * input: coalesced dwords of a chunk of K frames, requested two chunks ahead and landed in LDS one chunk ahead.  vmcnt
+//    counts loads and stores together, in order, so the wait for a chunk also waits for the stores issued just before it
+//    (microseconds for a lone wave): large chunks make that rare;
+//  * a round of R frames: code * scale across the lanes into LDS, then the first lane of each half walks its channel's
+//    recurrence on registers -- d + (c0*h1 >> 12) + (c1*h2 >> 12) = (c0*h1 + ((d + (c1*h2 >> 12)) << 12)) >> 12, whose
+//    second term does not depend on the newest sample: 6 VALU instructions per sample, the dependent chain is
+//    multiply-add, shift, clamp -- and the samples go back through LDS for one coalesced store per frame.
 __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
+    constexpr int R = 4;                                                // frames per round
+    constexpr uint32_t K = 64, KW = K * 36 / 4 / 64;                    // frames per input chunk; dwords per lane of a chunk (9)
+    __shared__ __attribute__((aligned(16))) int32_t dl[R][2][32];      // [frame][half][sample] code * scale
+    __shared__ __attribute__((aligned(16))) int32_t ol[R][2][32];      // [frame][half][sample] decoded samples
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2][K * 36];
     const AdxStream S = a.streams[blockIdx.x];
     const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
     const bool act = half < C;
     const uint32_t chain = S.first_chain + (act ? half : 0);
     int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
-    int32_t c0 = S.coef0, c1 = S.coef1;
     const uint8_t* src = a.in + S.src_offset;
     const uint8_t* end = a.in + S.src_end;
     uint8_t* out = a.out + S.dst_offset;
     const uint32_t rowb = 18 * C;
-    constexpr int R = 4;
-    uint32_t nb[R], nsc[R];
-    auto fetch = [&](uint32_t fr, uint32_t& b, uint32_t& sc) {
+    const uint32_t chunk_bytes = K * rowb, chunk_dwords = (chunk_bytes + 3) / 4;
+    uint32_t w[KW], wsh[KW];                               // dwords in flight; right shift that drops the bytes before a dword re-based at the stream end (32: nothing to keep)
+    auto request = [&](uint32_t chunk) {                   // branch-free: the loads only leave, nothing here waits for them
+        const uint8_t* base = src + (uint64_t)chunk * chunk_bytes;
+#pragma unroll
+        for (uint32_t i = 0; i < KW; i++) {
+            const uint32_t d = i * 64 + lane;
+            const uint8_t* p = base + 4 * d;
+            const bool some = d < chunk_dwords && p < end, whole = some && p + 4 <= end;
+            wsh[i] = whole ? 0u : (some ? 8u * (4u - (uint32_t)(end - p)) : 32u);
+            w[i] = ld_u32_unaligned(whole ? p : end - 4);  // (the stream's last dword when the wanted one crosses its end; block data follows a header, so end - 4 is inside the blob)
+        }
+    };
+    auto land = [&](uint32_t chunk) {
+#pragma unroll
+        for (uint32_t i = 0; i < KW; i++) { const uint32_t d = i * 64 + lane; if (d < chunk_dwords) ((uint32_t*)stage[chunk & 1])[d] = wsh[i] < 32 ? w[i] >> wsh[i] : 0u; }
+    };
+    auto fetch = [&](uint32_t fr, uint32_t& b, uint32_t& sc) {           // this lane's code byte and its block's scale word of frame fr
         b = 0; sc = 0;
         const uint8_t* row = src + (uint64_t)fr * rowb;
         if (fr < S.frames && row + rowb <= end && act) {
-            const uint8_t* blk = row + half * 18;
+            const uint8_t* blk = stage[(fr / K) & 1] + (fr % K) * rowb + half * 18;
             b = blk[2 + (s >> 1)];
             sc = ((uint32_t)blk[0] << 8) | blk[1];
         }
     };
-#pragma unroll
-    for (int t = 0; t < R; t++) fetch((uint32_t)t, nb[t], nsc[t]);
+    request(0); land(0); request(1);
+    wave_lds_sync();
     uint32_t done = 0;
     bool stopped = false;
     for (uint32_t f0 = 0; f0 < S.frames && !stopped; f0 += R) {
+        if (f0 % K == 0) {                                 // entering chunk f0 / K: the next one lands, the one after is requested
+            land(f0 / K + 1); request(f0 / K + 2);
+            wave_lds_sync();
+        }
         uint32_t b[R], sc[R];
 #pragma unroll
-        for (int t = 0; t < R; t++) { b[t] = nb[t]; sc[t] = nsc[t]; }
-#pragma unroll
-        for (int t = 0; t < R; t++) fetch(f0 + R + t, nb[t], nsc[t]);           // next round in flight during this one
+        for (int t = 0; t < R; t++) fetch(f0 + t, b[t], sc[t]);
+        // per-sample part of the round's frames: code * scale into LDS; the round ends at an EOF marker / truncated row
+        int32_t c0t[R], c1t[R];
+        bool fastt[R];
+        uint32_t nv = 0;
 #pragma unroll
         for (int t = 0; t < R; t++) {
+            c0t[t] = S.coef0; c1t[t] = S.coef1; fastt[t] = false;
             const uint32_t fr = f0 + t;
-            if (fr >= S.frames || stopped) break;
+            if (fr >= S.frames || stopped) continue;
             const uint8_t* row = src + (uint64_t)fr * rowb;
             const uint32_t sc0 = __builtin_amdgcn_readlane(sc[t], 0);            // channel 0's scale word: EOF marker check (adx.cpp:405-406)
-            if (row + rowb > end || sc0 == 0x8001) { stopped = true; break; }
+            if (row + rowb > end || sc0 == 0x8001) { stopped = true; continue; }
             int32_t scale = (int32_t)sc[t];
             if (S.mode == 4) scale = (int32_t)(1u << ((12 - scale) & 31));
             else if (S.mode == 2) {
                 const uint32_t pred = ((uint32_t)scale >> 13) & 7;
                 scale = (scale & 0x1FFF) + 1;
-                c0 = pred < 4 ? ADX_STATIC_COEFS[pred * 2] : 0;
-                c1 = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
+                c0t[t] = pred < 4 ? ADX_STATIC_COEFS[pred * 2] : 0;
+                c1t[t] = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
             } else scale += 1;
             const int32_t code = (int32_t)((s & 1 ? b[t] << 28 : b[t] << 24) & 0xF0000000u) >> 28;
-            const int32_t ds = code * scale;
-            int32_t mine = 0;
-#pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const int32_t d0 = __builtin_amdgcn_readlane(ds, k), d1 = __builtin_amdgcn_readlane(ds, 32 + k);
-                int32_t v = (half ? d1 : d0) + (__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12);
-                v = clamp_sym(v, 0x7FFF);
-                h2 = h1; h1 = v;
-                mine = (int)s == k ? v : mine;
-            }
-            const uint64_t idx = (uint64_t)fr * 32 + s;
-            if (C == 2) {
-                const int32_t other = __shfl_down(mine, 32);
-                if (half == 0 && idx < S.samples) ((uint32_t*)out)[idx] = ((uint32_t)mine & 0xFFFF) | ((uint32_t)other << 16);
-            } else if (half == 0 && idx < S.samples) ((int16_t*)out)[idx] = (int16_t)mine;
-            done = fr + 1;
+            dl[t][half][s] = code * scale;
+            fastt[t] = __all(scale >= 0 && scale <= 0x9000);
+            nv = t + 1;
         }
+        wave_lds_sync();
+        // the recurrence (adx.cpp:198-214) on registers: every lane of a half walks the same values, lanes 0 and 32 keep them
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            if ((uint32_t)t >= nv) break;
+            const int32_t c0 = c0t[t], c1 = c1t[t];
+            int32_t d[32];
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) { const int4 q = *(const int4*)&dl[t][half][k]; d[k] = q.x; d[k + 1] = q.y; d[k + 2] = q.z; d[k + 3] = q.w; }
+            if (fastt[t]) {                                // |d| <= 8 * 0x9000 keeps the multiply-add form inside 32 bits
+                int32_t v1 = h1, v2 = h2;
+                int32_t pre = (d[0] + (__mul24(c1, v2) >> 12)) << 12;
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    const int32_t v = clamp_sym((__mul24(c0, v1) + pre) >> 12, 0x7FFF);
+                    if (k < 31) pre = (d[k + 1] + (__mul24(c1, v1) >> 12)) << 12;
+                    d[k] = v;
+                    v2 = v1; v1 = v;
+                }
+            } else {
+                // prediction terms: p1 = c0*h1 >> 12 and p2 = c1*h2 >> 12 of the next sample; r1 = c1*h1 >> 12 becomes p2 one step later
+                int32_t p1 = __mul24(c0, h1) >> 12, p2 = __mul24(c1, h2) >> 12, r1 = __mul24(c1, h1) >> 12;
+#pragma unroll
+                for (int k = 0; k < 32; k++) {
+                    const int32_t v = clamp_sym(d[k] + p1 + p2, 0x7FFF);
+                    p2 = r1;
+                    p1 = __mul24(c0, v) >> 12;
+                    r1 = __mul24(c1, v) >> 12;
+                    d[k] = v;
+                }
+            }
+            h1 = d[31]; h2 = d[30];
+            if (s == 0) {
+#pragma unroll
+                for (int k = 0; k < 32; k += 4) *(int4*)&ol[t][half][k] = make_int4(d[k], d[k + 1], d[k + 2], d[k + 3]);
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            if ((uint32_t)t >= nv) break;
+            const uint64_t idx = (uint64_t)(f0 + t) * 32 + s;
+            if (half == 0 && idx < S.samples) {
+                const int32_t mine = ol[t][0][s];
+                if (C == 2) ((uint32_t*)out)[idx] = ((uint32_t)mine & 0xFFFF) | ((uint32_t)ol[t][1][s] << 16);
+                else ((int16_t*)out)[idx] = (int16_t)mine;
+            }
+        }
+        done = f0 + nv;
+        wave_lds_sync();
     }
     // rows never reached (EOF marker / truncated input) decode to silence
     for (uint64_t i = (uint64_t)done * 32 * C + lane; i < (uint64_t)S.samples * C; i += 64) ((int16_t*)out)[i] = 0;
