@@ -402,13 +402,13 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
         for (uint32_t i = 0; i < KW; i++) { const uint32_t d = i * 64 + lane; if (d < chunk_dwords) ((uint32_t*)stage[chunk & 1])[d] = wsh[i] < 32 ? w[i] >> wsh[i] : 0u; }
     };
     auto fetch = [&](uint32_t fr, uint32_t& b, uint32_t& sc) {           // this lane's code byte and its block's scale word of frame fr
-        b = 0; sc = 0;
+        // (unconditional LDS reads, selected afterwards: the four frames of a round then wait for them once)
         const uint8_t* row = src + (uint64_t)fr * rowb;
-        if (fr < S.frames && row + rowb <= end && act) {
-            const uint8_t* blk = stage[(fr / K) & 1] + (fr % K) * rowb + half * 18;
-            b = blk[2 + (s >> 1)];
-            sc = ((uint32_t)blk[0] << 8) | blk[1];
-        }
+        const bool ok = fr < S.frames && row + rowb <= end && act;
+        const uint8_t* blk = stage[(fr / K) & 1] + (fr % K) * rowb + (act ? half : 0) * 18;
+        const uint32_t bb = blk[2 + (s >> 1)], s0 = blk[0], s1 = blk[1];
+        b = ok ? bb : 0u;
+        sc = ok ? ((s0 << 8) | s1) : 0u;
     };
     request(0); land(0); request(1);
     wave_lds_sync();
@@ -422,6 +422,58 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
         uint32_t b[R], sc[R];
 #pragma unroll
         for (int t = 0; t < R; t++) fetch(f0 + t, b[t], sc[t]);
+        // The usual round -- four whole frames inside the stream and the sample count, constant coefficients, scale = word + 1
+        // small, no EOF marker -- runs as straight-line code: a lone wave pays for every branch and every separate LDS wait.
+        {
+            bool full = S.mode == 3 && f0 + R <= S.frames && src + (uint64_t)(f0 + R) * rowb <= end && (uint64_t)(f0 + R) * 32 <= S.samples;
+#pragma unroll
+            for (int t = 0; t < R; t++) full = full && __builtin_amdgcn_readlane(sc[t], 0) != 0x8001 && __all(sc[t] < 0x9000);
+            if (full) {
+#pragma unroll
+                for (int t = 0; t < R; t++) {
+                    const int32_t code = (int32_t)((s & 1 ? b[t] << 28 : b[t] << 24) & 0xF0000000u) >> 28;
+                    dl[t][half][s] = code * ((int32_t)sc[t] + 1);
+                }
+                wave_lds_sync();
+                const int32_t c0 = S.coef0, c1 = S.coef1;
+#pragma unroll
+                for (int t = 0; t < R; t++) {
+                    int32_t d[32];
+#pragma unroll
+                    for (int k = 0; k < 32; k += 4) { const int4 q = *(const int4*)&dl[t][half][k]; d[k] = q.x; d[k + 1] = q.y; d[k + 2] = q.z; d[k + 3] = q.w; }
+                    int32_t v1 = h1, v2 = h2;
+                    int32_t pre = (d[0] + (__mul24(c1, v2) >> 12)) << 12;
+#pragma unroll
+                    for (int k = 0; k < 32; k++) {
+                        const int32_t v = clamp_sym((__mul24(c0, v1) + pre) >> 12, 0x7FFF);
+                        if (k < 31) pre = (d[k + 1] + (__mul24(c1, v1) >> 12)) << 12;
+                        d[k] = v;
+                        v2 = v1; v1 = v;
+                    }
+                    h1 = d[31]; h2 = d[30];
+                    if (s == 0) {
+#pragma unroll
+                        for (int k = 0; k < 32; k += 4) *(int4*)&ol[t][half][k] = make_int4(d[k], d[k + 1], d[k + 2], d[k + 3]);
+                    }
+                }
+                wave_lds_sync();
+                int32_t m0[R], m1[R];
+#pragma unroll
+                for (int t = 0; t < R; t++) { m0[t] = ol[t][0][s]; m1[t] = ol[t][1][s]; }
+                if (half == 0) {
+                    if (C == 2) {
+#pragma unroll
+                        for (int t = 0; t < R; t++) ((uint32_t*)out)[(uint64_t)(f0 + t) * 32 + s] = ((uint32_t)m0[t] & 0xFFFF) | ((uint32_t)m1[t] << 16);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < R; t++) ((int16_t*)out)[(uint64_t)(f0 + t) * 32 + s] = (int16_t)m0[t];
+                    }
+                }
+                done = f0 + R;
+                wave_lds_sync();
+                continue;
+            }
+        }
         // per-sample part of the round's frames: code * scale into LDS; the round ends at an EOF marker / truncated row
         int32_t c0t[R], c1t[R];
         bool fastt[R];
@@ -485,14 +537,17 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
             }
         }
         wave_lds_sync();
+        // (all of the round's samples are read back before the first store: one LDS latency per round, not two per frame)
+        int32_t m0[R], m1[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) { m0[t] = ol[t][0][s]; m1[t] = ol[t][1][s]; }
 #pragma unroll
         for (int t = 0; t < R; t++) {
             if ((uint32_t)t >= nv) break;
             const uint64_t idx = (uint64_t)(f0 + t) * 32 + s;
             if (half == 0 && idx < S.samples) {
-                const int32_t mine = ol[t][0][s];
-                if (C == 2) ((uint32_t*)out)[idx] = ((uint32_t)mine & 0xFFFF) | ((uint32_t)ol[t][1][s] << 16);
-                else ((int16_t*)out)[idx] = (int16_t)mine;
+                if (C == 2) ((uint32_t*)out)[idx] = ((uint32_t)m0[t] & 0xFFFF) | ((uint32_t)m1[t] << 16);
+                else ((int16_t*)out)[idx] = (int16_t)m0[t];
             }
         }
         done = f0 + nv;
