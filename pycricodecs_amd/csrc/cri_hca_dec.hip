@@ -486,7 +486,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     //      in blocks of 16 symbols; bands past `coded` carry resolution 0 = no bits
     //      The code descriptions of a block are loaded one block ahead, before the pending stores: every vector memory
     //      operation a block waits for (feed_land) is then a whole block old.
-    uint4 mv_next = metag[0];
+    //      (channels without coded bands -- a secondary channel of a format with base_band_count 0 -- have no blocks)
+    uint32_t first_c = 0;
+    while (first_c + 1 < C && F.coded(first_c) == 0) first_c++;
+    uint4 mv_next = metag[first_c * 8 * 64];
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): nothing is pending when the loop is entered, so the
                                                                   // waits the compiler places inside it stay exact counts
     for (uint32_t sf = 0; sf < 8; sf++) {
@@ -497,7 +500,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 const uint4 mv = mv_next;
                 {
                     uint32_t nb = blk + 1, nc = c;
-                    if (nb >= nblk) { nb = 0; nc = c + 1 == C ? 0 : c + 1; }
+                    if (nb >= nblk) {                          // the next channel that has blocks (this one again, if it is the only one)
+                        nb = 0;
+                        do { nc = nc + 1 == C ? 0 : nc + 1; } while (F.coded(nc) == 0 && nc != c);
+                    }
                     mv_next = metag[(nc * 8 + nb) * 64];
                 }
                 feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);

@@ -235,6 +235,29 @@ def test_hca_multichannel_layouts(cc, ch):
     assert accepted >= tried // 2, (accepted, tried)
 
 
+def test_hca_secondary_channel_without_coded_bands(cc):
+    """Found by the long header fuzz (CRI_FUZZ_ITERS=3000): base_band_count 0 with joint-stereo bands leaves the secondary
+    channel without any coded band, i.e. without spectra blocks in the parse -- the block walk must skip it."""
+    for q in (2, 3):
+        base = O.hca_encode(synth.wav(77, 9000, 2, 48000), q)
+        hs = int.from_bytes(base[6:8], "big")
+        total, bb, sb = base[0x22], base[0x23], base[0x24]
+        for (nb, ns) in ((0, bb + sb), (0, 16), (16, bb + sb - 16)):
+            f0 = hca_forge.forge_comp(base, base=nb, stereo=ns)
+            checked = 0
+            for seed in range(6):
+                f = f0 if seed == 0 else hca_forge.random_frames(f0, 900 + seed, density=0.3)
+                try:
+                    ref = O.hca_decode(f)
+                except O.OracleError:
+                    with pytest.raises(ValueError):
+                        cc.HcaDecode(f, hs, 0, 0)
+                    continue
+                checked += 1
+                assert diff(cc.HcaDecode(f, hs, 0, 0), ref) is None, (q, nb, ns, seed)
+            assert checked >= 1, (q, nb, ns)
+
+
 def test_v3_delta_intensity_keeps_stale_entries(cc):
     """Found by tools/debug/frame_fuzz.py: a v3.0 delta-coded intensity list that runs out of range leaves the remaining
     entries at the previous frame's values (the reference returns early and ignores the error, hca.cpp:1185, 1405-1408)."""
@@ -518,7 +541,7 @@ def test_header_mutation_fuzz(cc, kind):
     region = {"hca": 96, "adx": 40, "wav_adx": 44, "wav_hca": 44}[kind]
     agree_ok = 0
     import os
-    for it in range(int(os.environ.get("CRI_FUZZ_ITERS", "160"))):
+    for it in range(int(os.environ.get("CRI_FUZZ_ITERS", "600"))):
         b = bytearray(base)
         if it % 8 == 7:
             b = b[:int(rng.integers(0, len(b)))]                        # truncation
