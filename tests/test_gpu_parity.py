@@ -235,6 +235,22 @@ def test_hca_multichannel_layouts(cc, ch):
     assert accepted >= tried // 2, (accepted, tried)
 
 
+@pytest.mark.parametrize("ch", [1, 2, 4, 6])
+def test_hca_batch_random_lengths(cc, ch):
+    """One batch of streams of every length from a fraction of a frame to a few runs of 8 frames (the transform splits a run
+    between its transform slots by frame count), plain and HFR qualities mixed, against the oracle item by item."""
+    from pycricodecs_amd.batch import Job
+    rng = np.random.default_rng(40 + ch)
+    items = []
+    for i in range(36):
+        n = int(rng.integers(1, 26000)) if i % 3 else int(rng.integers(1, 1400))
+        items.append(O.hca_encode(synth.wav(200 + i, n, ch, [48000, 44100, 32000][i % 3]), quality=1 if i % 4 else 3))
+    outs, st = Job.hca_decode(items).run_host()
+    for i, (o, h, code) in enumerate(zip(outs, items, st)):
+        assert code == 0, i
+        assert diff(bytes(o), O.hca_decode(h)) is None, (i, len(h))
+
+
 def test_hca_secondary_channel_without_coded_bands(cc):
     """Found by the long header fuzz (CRI_FUZZ_ITERS=3000): base_band_count 0 with joint-stereo bands leaves the secondary
     channel without any coded band, i.e. without spectra blocks in the parse -- the block walk must skip it."""
