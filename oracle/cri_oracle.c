@@ -278,6 +278,7 @@ int ora_adx_decode(const uint8_t* d, size_t len, uint8_t** out, size_t* out_len)
     if (mode != 2 && mode != 3 && mode != 4) return E_ADX(4);
     if (ver != 3 && ver != 4 && ver != 5) return E_ADX(5);
     if (((int)(bs - 2) * 8) % (int)bd != 0 || bd >= 16) return E_ADX(6);
+    if (bs <= 2) return E_ADX(6);        /* no samples per block: the reference divides by zero (2) or sizes its buffers negative (1) */
     if (ch == 0) return E_ADX(7);
     hist = (int16_t(*)[2])calloc(ch, sizeof *hist);
     if (!hist) return E_NOMEM;

@@ -156,6 +156,7 @@ int adx_parse_header(const uint8_t* d, size_t len, AdxHeader& h) {
     if (h.mode != 2 && h.mode != 3 && h.mode != 4) return CRI_ERR_ADX(4);
     if (h.version != 3 && h.version != 4 && h.version != 5) return CRI_ERR_ADX(5);
     if (((int)(h.blocksize - 2) * 8) % (int)h.bitdepth != 0 || h.bitdepth >= 16) return CRI_ERR_ADX(6);
+    if (h.blocksize <= 2) return CRI_ERR_ADX(6);              // no samples per block: the reference divides by zero (2) or sizes its buffers negative (1)
     if (h.channels == 0) return CRI_ERR_ADX(7);
     h.history.assign((size_t)h.channels * 2, 0);
     uint32_t base = 20;

@@ -147,6 +147,13 @@ def test_hca_decode_errors(cc):
         cc.AdxDecode(bytes([0x80, 0, 0, 0x2C, 3, 18, 4, 2, 0, 0, 0xBB, 0x80, 0, 0, 0, 64, 1, 0xF4, 4, 0]) + bytes(200))
     with pytest.raises(ValueError, match="Bitdepth"):
         cc.AdxEncode(synth.wav(0, 320, 2), 1, 18, 3, 500, 0, 4, False)
+    adx = bytearray(O.adx_encode(synth.wav(0, 320, 2)))
+    for bs in (1, 2):                                          # no samples per block (found by the long header fuzz: the oracle crashed on it)
+        adx[5] = bs
+        with pytest.raises(ValueError):
+            cc.AdxDecode(bytes(adx))
+        with pytest.raises(O.OracleError):
+            O.adx_decode(bytes(adx))
 
 
 @pytest.mark.parametrize("f", MAN["forged"], ids=lambda f: f["file"])
