@@ -632,6 +632,7 @@ static int hca_parse_header(const uint8_t* d, size_t len, uint32_t size_arg, hca
         uint32_t a = h->total_bands - h->base_bands - h->stereo_bands, b = h->bands_per_hfr_group;
         h->hfr_group_count = b < 1 ? 0 : (a / b + ((a % b) ? 1 : 0));
     }
+    if (h->hfr_group_count > 128) return E_HCA_HEADER;   /* total < base + stereo wraps the count: the reference then indexes scalefactors[128 - count] out of bounds */
     if (h->ath_type == 0) memset(h->ath, 0, 128);                                 /* hca.cpp:451-485 */
     else if (h->ath_type == 1) {
         uint32_t acc = 0;

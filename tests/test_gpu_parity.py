@@ -258,6 +258,18 @@ def test_hca_batch_random_lengths(cc, ch):
         assert diff(bytes(o), O.hca_decode(h)) is None, (i, len(h))
 
 
+def test_hca_header_with_wrapped_hfr_group_count(cc):
+    """Found by tools/debug/header_fuzz_multi.py: total_band_count below base + stereo with HFR groups wraps the unsigned
+    group count; the reference (and the oracle, before) segfault on it -- both sides reject the header."""
+    base = O.hca_encode(synth.wav(74, 9500, 4, 48000), quality=3)
+    assert base[0x25] > 0                                       # bands per HFR group
+    bad = hca_forge.forge_comp(base, total=base[0x23] + base[0x24] - 1)
+    with pytest.raises(O.OracleError):
+        O.hca_decode(bad)
+    with pytest.raises(ValueError, match="not a valid HCA header"):
+        cc.HcaDecode(bad, int.from_bytes(bad[6:8], "big"), 0, 0)
+
+
 def test_hca_secondary_channel_without_coded_bands(cc):
     """Found by the long header fuzz (CRI_FUZZ_ITERS=3000): base_band_count 0 with joint-stereo bands leaves the secondary
     channel without any coded band, i.e. without spectra blocks in the parse -- the block walk must skip it."""
@@ -558,7 +570,8 @@ def _both(gpu_call, ora_call):
 def test_header_mutation_fuzz(cc, kind):
     """Random byte edits and truncations in the header region: the host planners must take the oracle's accept/reject
     decision and produce its bytes (and, above all, must not read or write out of bounds doing so)."""
-    rng = np.random.default_rng({"hca": 1, "adx": 2, "wav_adx": 3, "wav_hca": 4}[kind])
+    import os
+    rng = np.random.default_rng({"hca": 1, "adx": 2, "wav_adx": 3, "wav_hca": 4}[kind] + 10 * int(os.environ.get("CRI_FUZZ_SEED", "0")))
     w = synth.wav(77, 3008, 2, 48000)
     base = {"hca": O.hca_encode(w, quality=2), "adx": O.adx_encode(w), "wav_adx": w, "wav_hca": w}[kind]
     region = {"hca": 96, "adx": 40, "wav_adx": 44, "wav_hca": 44}[kind]
