@@ -271,13 +271,16 @@ __device__ __forceinline__ int parse_symbol(BitBuf& bb, uint32_t meta) {
     if (CHECKED) bb.pos += (int)len;
     return (int)((sym >> 1) ^ (uint32_t)__builtin_amdgcn_sbfe(sym, 0, 1));       // = -(value): 0, -1, 1, -2, 2, ...
 }
-// two symbols' negated values -> their int16 pair
-__device__ __forceinline__ uint32_t pack_negated(int n0, int n1) {
+// two symbols' negated values as an int16 pair (still negated), and the two record forms made of such pairs:
+//  int16 lines: the pair negated back (v_pk_sub_i16);  int8 lines (HCA_REC_NARROW frames): the low bytes of two pairs,
+//  left negated -- the transform negates that frame's gains instead, which is exact
+__device__ __forceinline__ uint32_t pair_negated(int n0, int n1) { return __builtin_amdgcn_perm((uint32_t)n1, (uint32_t)n0, 0x05040100u); }   // n1.lo16 : n0.lo16
+__device__ __forceinline__ uint32_t pair_to_i16(uint32_t p) {
     typedef short s2 __attribute__((ext_vector_type(2)));
-    const uint32_t p = __builtin_amdgcn_perm((uint32_t)n1, (uint32_t)n0, 0x05040100u);   // n1.lo16 : n0.lo16
     const s2 z = {0, 0};
-    return __builtin_bit_cast(uint32_t, z - __builtin_bit_cast(s2, p));                  // v_pk_sub_i16
+    return __builtin_bit_cast(uint32_t, z - __builtin_bit_cast(s2, p));
 }
+__device__ __forceinline__ uint32_t pairs_to_i8(uint32_t p01, uint32_t p23) { return __builtin_amdgcn_perm(p23, p01, 0x06040200u); }
 // refill for up to two symbols (24 bits)
 __device__ __forceinline__ void pair_refill(BitBuf& b, const uint32_t* ring) { bb_refill(b, ring); }
 // code description of a band of resolution res (see parse_symbol)
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     feed_checkpoint(fd, bb); feed_checkpoint(fd, bb); feed_checkpoint(fd, bb);   // prime: 12 words landed, 4 in flight
     bb.hi = ring[0]; bb.lo = ring[64]; bb.nw = ring[128]; bb.rd = 2;
     bb_skip(bb, 16);                                             // sync word, checked by k_hca_prepare
-    uint32_t packed = 0, flags = 0, draws = 0;
+    uint32_t packed = 0, flags = 0, draws = 0, wide_bits = 0;
     {
         const uint32_t nl = bb_read(bb, ring, 9), eb = bb_read(bb, ring, 7);   // hca.cpp:1175-1178
         packed = (nl << 8) - eb;
@@ -415,6 +418,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                     const bool coded_res = ((mw[k >> 2] >> (8 * (k & 3))) & 0xFF) != 0;      // band_meta(0) == 0
                     n_noise += live && !coded_res ? 1u : 0u; n_valid += live && coded_res ? 1u : 0u;
                 }
+            }
+            if (a.narrow) {                                       // a band whose symbols can take more than 8 bits (resolution >= 12) needs int16 lines
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) wide_bits |= ((mw[q] & 0x0F0F0F0Fu) + 0x07070707u) & 0x10101010u;
             }
             metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 #pragma unroll
@@ -486,6 +493,9 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     //      in blocks of 16 symbols; bands past `coded` carry resolution 0 = no bits
     //      The code descriptions of a block are loaded one block ahead, before the pending stores: every vector memory
     //      operation a block waits for (feed_land) is then a whole block old.
+    //      Formats the in-lane transform handles (a.narrow) store the lines as int8 -- half the record bytes, and this kernel is
+    //      partly bound by the CU's store path -- when no band of the tile's 64 frames can exceed 8 bits (the usual case by far).
+    const bool narrow = a.narrow != 0 && !__any(wide_bits != 0);
     //      (channels without coded bands -- a secondary channel of a format with base_band_count 0 -- have no blocks)
     uint32_t first_c = 0;
     while (first_c + 1 < C && F.coded(first_c) == 0) first_c++;
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                         pair_refill(bb, ring);
                         const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
                         const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
-                        words[k] = pack_negated(v0, v1);
+                        words[k] = pair_negated(v0, v1);
                     }
                     bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
                 } else {
@@ -526,20 +536,27 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                         pair_refill(bb, ring);
                         const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
                         const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
-                        words[k] = pack_negated(v0, v1);
+                        words[k] = pair_negated(v0, v1);
                     }
                 }
+                if (narrow) {                                  // (tile-uniform) int8 lines: 16 bytes per block, 64 B of a frame per four blocks
 #pragma unroll
-                for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * OST + lane] = words[k];
-                if ((blk & 1) || blk + 1 == nblk)
-                    pend.set(HCA_REC_QC(C, sf, c) + (blk >> 1) * 64, (blk & 1) ? 16 : 8);
+                    for (uint32_t k = 0; k < 4; k++) ostage[((blk & 3) * 4 + k) * OST + lane] = pairs_to_i8(words[2 * k], words[2 * k + 1]);
+                    if ((blk & 3) == 3 || blk + 1 == nblk)
+                        pend.set(HCA_REC_QC(C, sf, c) + (blk >> 2) * 64, 4 * ((blk & 3) + 1));
+                } else {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * OST + lane] = pair_to_i16(words[k]);
+                    if ((blk & 1) || blk + 1 == nblk)
+                        pend.set(HCA_REC_QC(C, sf, c) + (blk >> 1) * 64, (blk & 1) ? 16 : 8);
+                }
             }
         }
     }
     pend.run(ostage, recq, rb16, nvalid, lane);
     if (valid) {
         uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
-        tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags; tail[3] = draws;      // k_hca_noise_scan turns tail[3] into a prefix
+        tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags | (narrow ? HCA_REC_NARROW : 0u); tail[3] = draws;      // k_hca_noise_scan turns tail[3] into a prefix
     }
 }
 
@@ -1302,7 +1319,7 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
 // eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of HCA_RUN
 // frames, but its 4 slots ("units") are 4/C groups x C channels: each group takes a contiguous part of the run and walks
 // it frame by frame, subframe by subframe, after one halo pass (the subframe before its first one).
-struct PlainPre { uint2 ps; uint32_t sf2[4]; };       // setup inputs of the four units' frames: lane v < 4 holds unit v's {packed, status}
+struct PlainPre { uint2 ps; uint32_t fl; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
 #ifndef CRI_PLAIN_WAVES
 #define CRI_PLAIN_WAVES 4
@@ -1311,6 +1328,8 @@ template <int C>
 __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
+    constexpr bool NW = C == 2;                            // int8 lines (HCA_REC_NARROW) are read by the stereo instance only: the mono and
+                                                           // four-channel ones are at their register limit without that and spill with it
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
     float* G = (float*)smem;                               // [4][128] gains of each unit's frame
@@ -1361,7 +1380,8 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
         PlainPre p;
         {
             bool live; const uint32_t f = unit_frame(lane & 3, s, live);
-            p.ps = *(const uint2*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_TAIL(C));
+            const uint32_t* tail = (const uint32_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_TAIL(C));
+            p.ps = *(const uint2*)tail; p.fl = NW ? tail[2] : 0u;
             p.ps.y = live ? p.ps.y : 0u;
         }
 #pragma unroll
@@ -1370,6 +1390,16 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
             p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(C, v % C)))[lane];
         }
         return p;
+    };
+    // HCA_REC_NARROW of this lane's unit's frame / of all four (the frame's lines are int8, negated: see k_hca_parse)
+    auto my_narrow = [&](const PlainPre& p) {
+        if (!NW) return false;
+        const uint32_t z0 = __builtin_amdgcn_readlane(p.fl, 0), z1 = __builtin_amdgcn_readlane(p.fl, 1), z2 = __builtin_amdgcn_readlane(p.fl, 2), z3 = __builtin_amdgcn_readlane(p.fl, 3);
+        return (((u & 2) ? ((u & 1) ? z3 : z2) : ((u & 1) ? z1 : z0)) & HCA_REC_NARROW) != 0;
+    };
+    auto all_narrow = [&](const PlainPre& p) {
+        if (!NW) return false;
+        return (__builtin_amdgcn_readlane(p.fl, 0) & __builtin_amdgcn_readlane(p.fl, 1) & __builtin_amdgcn_readlane(p.fl, 2) & __builtin_amdgcn_readlane(p.fl, 3) & HCA_REC_NARROW) != 0;
     };
     // gains of the four units' frames (hca.cpp:1444-1507), two bands per lane; false if one of the frames is bad
     auto setup = [&](const PlainPre& p) {
@@ -1381,6 +1411,7 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
             const uint32_t packed = __builtin_amdgcn_readlane(p.ps.x, v), sf2 = p.sf2[v], coded = F.coded(v % C);
+            const bool neg = NW && (__builtin_amdgcn_readlane(p.fl, v) & HCA_REC_NARROW) != 0;      // negated lines: negated gains (exact)
             float gn[2];
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
@@ -1393,49 +1424,69 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
                 res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
                 res = sv > 0 ? res : 0u;
                 const float gain = scale[sv & 63] * range[res & 15];
-                gn[hh] = i < coded ? gain : 0.0f;
+                gn[hh] = i < coded ? (neg ? -gain : gain) : 0.0f;
             }
             *(float2*)(G + v * 128 + 2 * lane) = make_float2(gn[0], gn[1]);
         }
         wave_lds_sync();
         return true;
     };
-    // row 0 of this lane's unit's quantised lines in the frame of step s: bands l16*8 .. +7; subframe sf is sf*C*256 bytes on
+    // row 0 of this lane's unit's quantised lines in the frame of step s (subframe sf is sf*C*256 bytes on), and where this
+    // lane's bands l16*8 .. +7 sit in a row: 16 bytes of int16 or 8 bytes of int8
+    // (as a 32-bit offset from the record before the run's first one: the run's records and its halo's are within 9 records of it)
+    const uint8_t* rec_run = rec0 + ((uint64_t)f0 - (f0 > 0 ? 1 : 0)) * F.record_bytes;
     auto row0 = [&](int s) {
         bool live; const uint32_t f = unit_frame(u, s, live);
-        return rec0 + (uint64_t)f * F.record_bytes + (HCA_REC_QC(C, 0, c) + l16 * 16);
+        return (f - (f0 - (f0 > 0 ? 1 : 0))) * F.record_bytes + HCA_REC_QC(C, 0, c);
     };
-    auto dct_pass = [&](const uint4& q, f2 x[4]) {
+    auto lane_off = [&](bool narrow) { return narrow ? l16 * 8 : l16 * 16; };
+    // (step_narrow: all four units' frames are int8 -- wave-uniform; mine: this lane's is)
+    auto dct_pass = [&](const uint4& q, bool step_narrow, bool mine, f2 x[4]) {
         const float4 g0 = *(const float4*)(G + u * 128 + l16 * 8), g1 = *(const float4*)(G + u * 128 + l16 * 8 + 4);
         const f2 gg[4] = {f2{g0.x, g0.y}, f2{g0.z, g0.w}, f2{g1.x, g1.y}, f2{g1.z, g1.w}};
         const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+        if (NW && __builtin_expect(step_narrow, 1)) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = gg[k] * f2{(float)(int)(int16_t)(qw[k] & 0xFFFF), (float)((int)qw[k] >> 16)};   // gains are 0 past the coded bands
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = qw[k >> 1] >> (16 * (k & 1));
+                x[k] = gg[k] * f2{(float)(int)(int8_t)(w & 0xFF), (float)(int)(int8_t)((w >> 8) & 0xFF)};   // gains are 0 past the coded bands
+            }
+        } else {                                           // a frame with wide lines among the four (rare): either form per lane
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = qw[k >> 1] >> (16 * (k & 1));
+                const int a0 = NW && mine ? (int)(int8_t)(w & 0xFF) : (int)(int16_t)(qw[k] & 0xFFFF), a1 = NW && mine ? (int)(int8_t)((w >> 8) & 0xFF) : ((int)qw[k] >> 16);
+                x[k] = gg[k] * f2{(float)a0, (float)a1};
+            }
+        }
         dct4_inplace(x, L);
     };
 
     float prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // hca.cpp:962: the overlap tail starts as zeros
     PlainPre pre = load_pre(-1);
-    const uint8_t* rows = row0(-1);                        // rows of the current step's frame
-    uint4 q = *(const uint4*)(rows + 7 * C * 256);
+    uint32_t rows = row0(-1);                              // rows of the current step's frame
+    uint4 q = *(const uint4*)(rec_run + (rows + 7 * C * 256 + lane_off(my_narrow(pre))));        // (the one load of a run that waits for a flag first)
     const uint32_t last_count = unit_count(3);             // frames of the last group: steps below it have every group at work
     const uint32_t group_dwords = h * 512 * C;             // output dwords between the frames of consecutive groups
     // step -1 is the halo: the subframe before each group's first one (its frame's subframe 7) only feeds the overlap state
 #pragma unroll 1
     for (int s = -1; s < (int)h; s++) {
-        const uint8_t* next_rows = s + 1 < (int)h ? row0(s + 1) : rows;
+        const uint32_t next_rows = s + 1 < (int)h ? row0(s + 1) : rows;
+        bool step_narrow, mine;
         {
             const PlainPre cur = pre;
+            step_narrow = all_narrow(cur); mine = my_narrow(cur);
             if (s + 1 < (int)h) pre = load_pre(s + 1);
             wave_lds_sync();                               // (the previous pass has read G)
             if (!setup(cur)) return;                       // (a group's halo frame is one of the run's own, except the first group's)
         }
 #pragma unroll 1
         for (uint32_t sf = s < 0 ? 7 : 0; sf < 8; sf++) {
-            const uint4 qc = q;
-            q = *(const uint4*)(sf < 7 ? rows + (sf + 1) * (C * 256) : next_rows);
             f2 x[4];
-            dct_pass(qc, x);
+            dct_pass(q, step_narrow, mine, x);
+            // the next pass's lines, requested as soon as this pass's are in registers as floats (the next step's first row is laid
+            // out by that frame's own flag, which came with `pre` seven passes ago)
+            q = *(const uint4*)(rec_run + (sf < 7 ? rows + (sf + 1) * (C * 256) + lane_off(mine) : next_rows + lane_off(s + 1 < (int)h ? my_narrow(pre) : mine)));
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
 #pragma unroll

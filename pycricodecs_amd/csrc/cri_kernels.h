@@ -26,6 +26,8 @@ struct HcaDecArgs {
     uint32_t plain;                // 1: no HFR and no joint stereo in this format (spectra need dequantisation only)
     uint32_t noise_fill;           // 1: min_resolution == 0 (v3.0): k_hca_noise_scan + noise reconstruction in the transform
     uint32_t pairs_even;           // 1: every stereo pair starts on an even channel (a pair then shares a transform pass)
+    uint32_t narrow;               // 1: k_hca_transform_plain reads this format's records: int8 lines where the values allow it
+    uint32_t pad1;
     uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][R+1][64] uint32 (big-endian words)
     uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
     uint64_t resg_offset;          // scratch byte offset of this group's band code descriptions: [tile][C][8 blocks][64 lanes] uint4 (16 bands x 1 byte)

@@ -52,6 +52,8 @@ static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels
 #define HCA_REC_SF(C, c) ((C) * 2048u + (c) * 128u)
 #define HCA_REC_INT(C, c) ((C) * 2176u + (c) * 8u)
 #define HCA_REC_TAIL(C) ((C) * 2184u)
+#define HCA_REC_NARROW 0x40000000u   // tail flags: the frame's quantised lines are int8 and NEGATED, 128 B per (subframe, channel) row at the row's int16 place
+                                     // (formats with HcaDecArgs::narrow only: k_hca_parse -> k_hca_transform_plain)
 
 // ---- ADX ---------------------------------------------------------------------------------------------------
 struct AdxStream {
