@@ -1465,7 +1465,11 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
     float prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // hca.cpp:962: the overlap tail starts as zeros
     PlainPre pre = load_pre(-1);
     uint32_t rows = row0(-1);                              // rows of the current step's frame
-    uint4 q = *(const uint4*)(rec_run + (rows + 7 * C * 256 + lane_off(my_narrow(pre))));        // (the one load of a run that waits for a flag first)
+    uint4 q = make_uint4(0, 0, 0, 0);
+    {   // (the one load of a run that waits for a flag first)
+        const uint8_t* p = rec_run + (rows + 7 * C * 256 + lane_off(my_narrow(pre)));
+        if (NW && all_narrow(pre)) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
+    }
     const uint32_t last_count = unit_count(3);             // frames of the last group: steps below it have every group at work
     const uint32_t group_dwords = h * 512 * C;             // output dwords between the frames of consecutive groups
     // step -1 is the halo: the subframe before each group's first one (its frame's subframe 7) only feeds the overlap state
@@ -1486,7 +1490,13 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
             dct_pass(q, step_narrow, mine, x);
             // the next pass's lines, requested as soon as this pass's are in registers as floats (the next step's first row is laid
             // out by that frame's own flag, which came with `pre` seven passes ago)
-            q = *(const uint4*)(rec_run + (sf < 7 ? rows + (sf + 1) * (C * 256) + lane_off(mine) : next_rows + lane_off(s + 1 < (int)h ? my_narrow(pre) : mine)));
+            {
+                const bool more = s + 1 < (int)h;
+                const uint8_t* p = rec_run + (sf < 7 ? rows + (sf + 1) * (C * 256) + lane_off(mine) : next_rows + lane_off(more ? my_narrow(pre) : mine));
+                // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
+                if (NW && (sf < 7 ? step_narrow : (more ? all_narrow(pre) : step_narrow))) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; }
+                else q = *(const uint4*)p;
+            }
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
 #pragma unroll
