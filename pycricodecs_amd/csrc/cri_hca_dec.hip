@@ -1476,10 +1476,10 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
 #pragma unroll 1
     for (int s = -1; s < (int)h; s++) {
         const uint32_t next_rows = s + 1 < (int)h ? row0(s + 1) : rows;
-        bool step_narrow, mine;
+        bool step_narrow, mine; uint32_t loff;
         {
             const PlainPre cur = pre;
-            step_narrow = all_narrow(cur); mine = my_narrow(cur);
+            step_narrow = all_narrow(cur); mine = my_narrow(cur); loff = lane_off(mine);
             if (s + 1 < (int)h) pre = load_pre(s + 1);
             wave_lds_sync();                               // (the previous pass has read G)
             if (!setup(cur)) return;                       // (a group's halo frame is one of the run's own, except the first group's)
@@ -1490,12 +1490,14 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
             dct_pass(q, step_narrow, mine, x);
             // the next pass's lines, requested as soon as this pass's are in registers as floats (the next step's first row is laid
             // out by that frame's own flag, which came with `pre` seven passes ago)
-            {
-                const bool more = s + 1 < (int)h;
-                const uint8_t* p = rec_run + (sf < 7 ? rows + (sf + 1) * (C * 256) + lane_off(mine) : next_rows + lane_off(more ? my_narrow(pre) : mine));
-                // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
-                if (NW && (sf < 7 ? step_narrow : (more ? all_narrow(pre) : step_narrow))) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; }
-                else q = *(const uint4*)p;
+            {   // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
+                const uint8_t* p; bool ld8;
+                if (sf < 7) { p = rec_run + (rows + (sf + 1) * (C * 256) + loff); ld8 = NW && step_narrow; }
+                else {                                     // the next step's first row, laid out by that frame's own flag (it came with `pre` seven passes ago)
+                    const bool more = s + 1 < (int)h;
+                    p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);
+                }
+                if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
             }
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
