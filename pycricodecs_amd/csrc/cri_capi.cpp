@@ -277,7 +277,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.noise_fill = F.min_res == 0 ? 1 : 0;
         if (a.noise_fill) a.plain = 0;                                 // noise reconstruction lives in the general variant of the transform
-        a.narrow = (a.plain && a.channels == 2) ? 1 : 0;          // (k_hca_transform_plain<2> is the instance that reads int8 lines)
+        a.narrow = (a.plain && a.channels <= 2) ? 1 : 0;          // (k_hca_transform_plain<1>, <2> are the instances that read int8 lines)
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
         a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave

@@ -1328,8 +1328,8 @@ template <int C>
 __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
-    constexpr bool NW = C == 2;                            // int8 lines (HCA_REC_NARROW) are read by the stereo instance only: the mono and
-                                                           // four-channel ones are at their register limit without that and spill with it
+    constexpr bool NW = C <= 2;                            // int8 lines (HCA_REC_NARROW) are read by the mono and stereo instances: the
+                                                           // four-channel one is at its register limit without that and spills with it
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
     float* G = (float*)smem;                               // [4][128] gains of each unit's frame
