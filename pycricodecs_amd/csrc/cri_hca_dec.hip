@@ -15,6 +15,8 @@
 //                    8 frames, four transforms at a time in registers (1, 2, 4, 6 or 8 channels).
 //   k_hca_transform_plain      formats without HFR / joint stereo / noise fill, 1, 2 or 4 channels (the usual case): each 16-lane
 //                    slot follows one channel through consecutive subframes, so window + overlap-add stay in the DCT's lanes.
+//                    Between k_hca_parse and it (mono, stereo) a frame's quantised lines travel as int8 when its tile allows
+//                    it (HCA_REC_NARROW, cri_types.h), as int16 otherwise.
 //   k_hca_transform_generic    the same for any other channel layout, one wave per frame, spectra assembled in LDS
 //                    (the DCT is the same register network); k_hca_noise_scan gives it the generator state each frame starts from.
 // All float work is single IEEE binary32 operations in the reference's order (compiled with -ffp-contract=off).
