@@ -79,8 +79,17 @@ void cri_free(void* p);
  * (adx.cpp:11-30, pcm.cpp:22-33, hca.cpp:3255-3264). */
 const char* cri_strerror(int code);
 
-/* 1 when a gfx950 device is usable, 0 otherwise. */
+/* 1 when a gfx950 device is usable, 0 otherwise (thread-safe). */
 int cri_device_available(void);
+
+/* Device selection for hosts that drive more than one GPU from one process.  The current device is per THREAD (HIP's rule):
+ * cri_set_device selects the GPU that jobs created by, and single-file calls made from, the calling thread use.  A job
+ * stays bound to the device it was created on: cri_job_run / cri_job_run_host* / cri_job_destroy may be called from any
+ * thread and switch to that device for the duration of the call (buffers and stream passed to cri_job_run must belong to
+ * it).  One process per GPU (the multi-GPU layout of this path) needs none of these. */
+int cri_device_count(void);
+int cri_set_device(int device);   /* 0, CRI_ERR_INVALID_ARG (no such device) or CRI_ERR_HIP */
+int cri_get_device(void);         /* the calling thread's current device, -1 without a device */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Batch jobs, device resident.  A job is built on the host from the items' headers only, then run any number
@@ -152,6 +161,7 @@ const uint64_t* cri_job_item_sizes(const cri_job* job);     /* byte length of ev
 int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,
                              const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
 
+int cri_job_device(const cri_job* job);                     /* device the job is bound to (see cri_set_device) */
 uint32_t cri_job_kind(const cri_job* job);
 uint32_t cri_job_items(const cri_job* job);
 uint64_t cri_job_input_bytes(const cri_job* job);
@@ -171,6 +181,15 @@ uint64_t cri_job_algorithmic_bytes(const cri_job* job);
  * receives 0 or the first failing frame's code per item (may be NULL).  d_scratch: cri_job_scratch_bytes()
  * bytes (may be NULL when 0). */
 int cri_job_run(cri_job* job, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, void* hip_stream);
+
+/* Validation run of an HCA decode job (north_star states the HCA tolerance on the floats BEFORE the int16 clamp:
+ * hca.cpp:1987-1992 wave[subframe][sample], read by clHCA_ReadSamples16 at 339-360).  Same as cri_job_run, and additionally
+ * stores every decoded frame's pre-clamp samples: item i at d_floats + cri_job_float_offsets()[i], as
+ * [frame][1024 samples][channels] floats, for the frames the decode visits (all of them unless the padding spans whole
+ * frames).  d_floats holds cri_job_float_count() floats.  Not a product path: the instances that store floats are slower. */
+uint64_t cri_job_float_count(const cri_job* job);
+const uint64_t* cri_job_float_offsets(const cri_job* job);  /* n+1 entries, in floats; NULL for other job kinds */
+int cri_job_run_floats(cri_job* job, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, float* d_floats, void* hip_stream);
 
 /* Name of the job's dominant kernel (for profiling cross-checks). */
 const char* cri_job_dominant_kernel(const cri_job* job);

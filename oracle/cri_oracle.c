@@ -120,7 +120,8 @@ static int wav_parse(const uint8_t* w, size_t len, wavin* o) {
         if (cur + 8 > len) return E_PCM(7);
         sig = le32(w + cur);
         size = le32(w + cur + 4) + 8;
-        size += ((size & 1) && size + sum + (size & 1) <= fullsize);
+        if (size < 8) return E_PCM(7);                       /* wrapped 32-bit add: the reference stops advancing here */
+        size += ((size & 1) && (uint64_t)size + sum + (size & 1) <= fullsize);
         if (sig == 0x20746D66u) {                                                     /* "fmt " pcm.cpp:177-201 */
             uint32_t fsz = le32(w + cur + 4);
             if (fsz < 16) return E_PCM(2);
@@ -155,8 +156,8 @@ static int wav_parse(const uint8_t* w, size_t len, wavin* o) {
             have_data = 1;
         }
         cur += size;
+        if ((uint64_t)sum + size > fullsize) return E_PCM(7);
         sum += size;
-        if (sum > fullsize) return E_PCM(7);
     }
     if (!have_fmt) return E_PCM(2);
     if (!have_data) return E_PCM(6);
@@ -560,64 +561,73 @@ static void channel_types(uint32_t channels, uint32_t track_count, uint32_t ster
     }
 }
 
+/* the reference's bit reader at byte granularity (hca.cpp:225-232): a read crossing the bound returns 0 */
+static uint32_t rd_be(const uint8_t* d, size_t bound, uint32_t at, uint32_t n) {
+    uint32_t v = 0, k;
+    if ((size_t)at + n > bound) return 0;
+    for (k = 0; k < n; k++) v = (v << 8) | d[at + k];
+    return v;
+}
+
 static int hca_parse_header(const uint8_t* d, size_t len, uint32_t size_arg, hca_info* h) {
     uint32_t size = size_arg, pos = 0, i;
-#define MAGIC(at) (be32(d + (at)) & 0x7F7F7F7Fu)
-#define HAVE(n) ((size_t)pos + (n) <= len)
+    const size_t bound = len < (size_t)size_arg ? len : (size_t)size_arg;   /* bitreader_init(&br, data, size), hca.cpp:639 */
+#define RD(at, n) rd_be(d, bound, (at), (n))
+#define MAGIC(at) (RD((at), 4) & 0x7F7F7F7Fu)
     memset(h, 0, sizeof *h);
     if (size < 8 || len < 8) return E_HCA_HEADER;
     if (MAGIC(0) != 0x48434100u) return E_HCA_HEADER;
-    h->version = be16(d + 4); h->header_size = be16(d + 6);
+    h->version = RD(4, 2); h->header_size = RD(6, 2);
     if (h->version != 0x0101 && h->version != 0x0102 && h->version != 0x0103 && h->version != 0x0200 && h->version != 0x0300) return E_HCA_HEADER;
     if (size < h->header_size || len < h->header_size) return E_HCA_HEADER;
     if (ora_crc16(d, h->header_size)) return E_HCA_HEADER;
     size -= 8; pos = 8;
-    if (size >= 0x10 && HAVE(16) && MAGIC(pos) == 0x666D7400u) {
-        h->channels = d[pos + 4]; h->rate = be32(d + pos + 4) & 0xFFFFFF; h->frame_count = be32(d + pos + 8);
-        h->delay = be16(d + pos + 12); h->padding = be16(d + pos + 14);
+    if (size >= 0x10 && MAGIC(pos) == 0x666D7400u) {                                /* fmt, hca.cpp:667-688 */
+        h->channels = RD(pos + 4, 1); h->rate = RD(pos + 5, 3); h->frame_count = RD(pos + 8, 4);
+        h->delay = RD(pos + 12, 2); h->padding = RD(pos + 14, 2);
         if (!(h->channels >= 1 && h->channels <= 16)) return E_HCA_HEADER;
         if (h->frame_count == 0) return E_HCA_HEADER;
         if (!(h->rate >= 1 && h->rate <= 0x7FFFFF)) return E_HCA_HEADER;
         size -= 0x10; pos += 0x10;
     } else return E_HCA_HEADER;
-    if (size >= 0x10 && HAVE(16) && MAGIC(pos) == 0x636F6D70u) {                 /* comp */
-        h->frame_size = be16(d + pos + 4); h->min_res = d[pos + 6]; h->max_res = d[pos + 7];
-        h->track_count = d[pos + 8]; h->channel_config = d[pos + 9]; h->total_bands = d[pos + 10];
-        h->base_bands = d[pos + 11]; h->stereo_bands = d[pos + 12]; h->bands_per_hfr_group = d[pos + 13];
-        h->ms_stereo = d[pos + 14];
+    if (size >= 0x10 && MAGIC(pos) == 0x636F6D70u) {                                /* comp, hca.cpp:691-709 */
+        h->frame_size = RD(pos + 4, 2); h->min_res = RD(pos + 6, 1); h->max_res = RD(pos + 7, 1);
+        h->track_count = RD(pos + 8, 1); h->channel_config = RD(pos + 9, 1); h->total_bands = RD(pos + 10, 1);
+        h->base_bands = RD(pos + 11, 1); h->stereo_bands = RD(pos + 12, 1); h->bands_per_hfr_group = RD(pos + 13, 1);
+        h->ms_stereo = RD(pos + 14, 1);
         size -= 0x10; pos += 0x10;
-    } else if (size >= 0x0c && HAVE(12) && MAGIC(pos) == 0x64656300u) {          /* dec */
-        h->frame_size = be16(d + pos + 4); h->min_res = d[pos + 6]; h->max_res = d[pos + 7];
-        h->total_bands = d[pos + 8] + 1u; h->base_bands = d[pos + 9] + 1u;
-        h->track_count = d[pos + 10] >> 4; h->channel_config = d[pos + 10] & 0xF; h->stereo_type = d[pos + 11];
+    } else if (size >= 0x0c && MAGIC(pos) == 0x64656300u) {                         /* dec, hca.cpp:710-727 */
+        h->frame_size = RD(pos + 4, 2); h->min_res = RD(pos + 6, 1); h->max_res = RD(pos + 7, 1);
+        h->total_bands = RD(pos + 8, 1) + 1u; h->base_bands = RD(pos + 9, 1) + 1u;
+        h->track_count = RD(pos + 10, 1) >> 4; h->channel_config = RD(pos + 10, 1) & 0xF; h->stereo_type = RD(pos + 11, 1);
         if (h->stereo_type == 0) h->base_bands = h->total_bands;
         h->stereo_bands = h->total_bands - h->base_bands;
         h->bands_per_hfr_group = 0;
         size -= 0x0c; pos += 0x0c;
     } else return E_HCA_HEADER;
-    if (size >= 8 && HAVE(8) && MAGIC(pos) == 0x76627200u) {                      /* vbr */
-        uint32_t mx = be16(d + pos + 4);
+    if (size >= 8 && MAGIC(pos) == 0x76627200u) {                                   /* vbr, hca.cpp:733-748 */
+        uint32_t mx = RD(pos + 4, 2);
         if (!(h->frame_size == 0 && mx > 8 && mx <= 0x1FF)) return E_HCA_HEADER;
         size -= 8; pos += 8;
     }
-    if (size >= 6 && HAVE(6) && MAGIC(pos) == 0x61746800u) { h->ath_type = be16(d + pos + 4); pos += 6; } /* size not reduced (hca.cpp:749-752) */
+    if (size >= 6 && MAGIC(pos) == 0x61746800u) { h->ath_type = RD(pos + 4, 2); pos += 6; } /* ath: size not reduced (hca.cpp:750-753) */
     else h->ath_type = h->version < 0x0200 ? 1 : 0;
-    if (size >= 0x10 && HAVE(16) && MAGIC(pos) == 0x6C6F6F70u) {                 /* loop */
-        h->loop_start_frame = be32(d + pos + 4); h->loop_end_frame = be32(d + pos + 8);
-        h->loop_start_delay = be16(d + pos + 12); h->loop_end_padding = be16(d + pos + 14);
+    if (size >= 0x10 && MAGIC(pos) == 0x6C6F6F70u) {                                /* loop, hca.cpp:760-774 */
+        h->loop_start_frame = RD(pos + 4, 4); h->loop_end_frame = RD(pos + 8, 4);
+        h->loop_start_delay = RD(pos + 12, 2); h->loop_end_padding = RD(pos + 14, 2);
         h->loop_flag = 1;
         if (!(h->loop_start_frame <= h->loop_end_frame && h->loop_end_frame < h->frame_count)) return E_HCA_HEADER;
         size -= 0x10; pos += 0x10;
     }
-    if (size >= 6 && HAVE(6) && MAGIC(pos) == 0x63697068u) {                      /* ciph */
+    if (size >= 6 && MAGIC(pos) == 0x63697068u) {                                   /* ciph, hca.cpp:786-794 */
         h->ciph_pos = pos;
-        h->ciph_type = be16(d + pos + 4);
+        h->ciph_type = RD(pos + 4, 2);
         if (!(h->ciph_type == 0 || h->ciph_type == 1 || h->ciph_type == 56)) return E_HCA_HEADER;
         size -= 6; pos += 6;
     }
-    if (size >= 8 && HAVE(8) && MAGIC(pos) == 0x72766100u) { size -= 8; pos += 8; } /* rva: volume unused */
-    if (size >= 5 && HAVE(5) && MAGIC(pos) == 0x636F6D6Du) {                      /* comm */
-        h->comment_len = d[pos + 4];
+    if (size >= 8 && MAGIC(pos) == 0x72766100u) { size -= 8; pos += 8; }            /* rva, hca.cpp:799-812: volume unused */
+    if (size >= 5 && MAGIC(pos) == 0x636F6D6Du) {                                   /* comm, hca.cpp:814-830 */
+        h->comment_len = RD(pos + 4, 1);
         if (h->comment_len > size) return E_HCA_HEADER;
         size -= 5 + h->comment_len; pos += 5 + h->comment_len;
     }
@@ -649,7 +659,7 @@ static int hca_parse_header(const uint8_t* d, size_t len, uint32_t size_arg, hca
     if (h->ms_stereo) return E_HCA_HEADER;
     return 0;
 #undef MAGIC
-#undef HAVE
+#undef RD
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -963,9 +973,9 @@ int ora_hca_crypt(uint8_t* d, size_t len, uint32_t encrypt, uint32_t type, uint6
         for (i = 0; i < h.frame_size; i++) fr[i] = t[fr[i]];
         put_be16(fr + h.frame_size - 2, ora_crc16(fr, h.frame_size - 2));
     }
-    /* chunk magic masks, hca.cpp:3166-3250 */
+    /* chunk magic masks, hca.cpp:3166-3250; bounded reader over the header (hca.cpp:3171), `ath` keeps `size` (3203-3206) */
     size = hs; pos = 0;
-#define MAGIC(at) (be32(d + (at)) & 0x7F7F7F7Fu)
+#define MAGIC(at) (rd_be(d, hs, (at), 4) & 0x7F7F7F7Fu)
 #define FLIP3(at) do { d[(at)] ^= 0x80; d[(at) + 1] ^= 0x80; d[(at) + 2] ^= 0x80; } while (0)
 #define FLIP4(at) do { FLIP3(at); d[(at) + 3] ^= 0x80; } while (0)
     if (MAGIC(pos) == 0x48434100u) { FLIP3(pos); pos += 8; size -= 8; }
@@ -975,10 +985,14 @@ int ora_hca_crypt(uint8_t* d, size_t len, uint32_t encrypt, uint32_t type, uint6
     if (size >= 8 && MAGIC(pos) == 0x76627200u) { FLIP3(pos); pos += 8; size -= 8; }
     if (size >= 6 && MAGIC(pos) == 0x61746800u) { FLIP3(pos); pos += 6; }
     if (size >= 0x10 && MAGIC(pos) == 0x6C6F6F70u) { FLIP4(pos); pos += 16; size -= 16; }
-    if (size >= 6 && MAGIC(pos) == 0x63697068u) { FLIP4(pos); put_be16(d + pos + 4, encrypt == 1 ? (type & 0xFFFF) : 0); pos += 6; size -= 6; }
+    if (size >= 6 && MAGIC(pos) == 0x63697068u) {
+        FLIP4(pos);
+        if ((size_t)pos + 6 <= hs) put_be16(d + pos + 4, encrypt == 1 ? (type & 0xFFFF) : 0);   /* (the reference writes it out of bounds otherwise) */
+        pos += 6; size -= 6;
+    }
     if (size >= 8 && MAGIC(pos) == 0x72766100u) { FLIP3(pos); pos += 8; size -= 8; }
-    if (size >= 5 && MAGIC(pos) == 0x636F6D6Du) { uint32_t cl = d[pos + 4]; FLIP4(pos); pos += 5 + cl; size -= 5 + cl; }
-    if (size >= 4 && pos + 4 <= hs && MAGIC(pos) == 0x70616400u) { FLIP3(pos); }
+    if (size >= 5 && MAGIC(pos) == 0x636F6D6Du) { uint32_t cl = rd_be(d, hs, pos + 4, 1); FLIP4(pos); pos += 5 + cl; size -= 5 + cl; }
+    if (size >= 4 && MAGIC(pos) == 0x70616400u) { FLIP3(pos); }
     put_be16(d + hs - 2, ora_crc16(d, hs - 2));
 #undef MAGIC
 #undef FLIP3

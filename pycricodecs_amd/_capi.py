@@ -21,6 +21,7 @@ SYMBOLS = [
     "cri_job_output_bytes", "cri_job_output_offsets", "cri_job_host_status", "cri_job_scratch_bytes", "cri_job_units",
     "cri_job_units2", "cri_job_algorithmic_bytes", "cri_job_run", "cri_job_dominant_kernel", "cri_job_destroy", "cri_job_run_host", "cri_job_enable_events",
     "cri_job_event_ms", "cri_awb_index", "cri_job_create_awb_decode", "cri_job_run_host_into",
+    "cri_device_count", "cri_set_device", "cri_get_device", "cri_job_device", "cri_job_run_floats", "cri_job_float_count", "cri_job_float_offsets",
     "cri_usm_audio_mask", "cri_usm_index", "cri_job_create_usm_audio_demux", "cri_job_create_sfa_pack", "cri_job_item_tags", "cri_job_item_sizes",
 ]
 
@@ -76,6 +77,13 @@ def lib():
     L.cri_job_dominant_kernel.argtypes = [vp]
     L.cri_job_dominant_kernel.restype = C.c_char_p
     L.cri_job_run.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.cri_set_device.argtypes = [C.c_int]
+    L.cri_job_device.argtypes = [vp]
+    L.cri_job_run_floats.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.cri_job_float_count.argtypes = [vp]
+    L.cri_job_float_count.restype = C.c_uint64
+    L.cri_job_float_offsets.argtypes = [vp]
+    L.cri_job_float_offsets.restype = u64p
     L.cri_job_run_host.argtypes = [vp, vp, C.POINTER(u8p), i32p]
     L.cri_job_run_host_into.argtypes = [vp, vp, vp, i32p]
     L.cri_job_enable_events.argtypes = [vp, C.c_int]

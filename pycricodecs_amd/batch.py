@@ -154,6 +154,21 @@ class Job:
         if rc:
             _capi.raise_for(rc)
 
+    def run_floats(self, d_in, d_out, d_scratch, d_status, stream=None):
+        """Validation run of an HCA decode job: run() plus the samples before the int16 conversion.  Returns
+        (float32 tensor, offsets uint64[n+1] in floats): item i = [frame][1024][channels] at offsets[i]."""
+        import torch
+        L = _capi.lib()
+        n = int(L.cri_job_float_count(self._h))
+        offs = np.ctypeslib.as_array(L.cri_job_float_offsets(self._h), shape=(self.n + 1,)).copy()
+        d_f = torch.zeros(max(n, 1), dtype=torch.float32, device=d_in.device)
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        rc = L.cri_job_run_floats(self._h, d_in.data_ptr(), d_out.data_ptr(), d_scratch.data_ptr(),
+                                  d_status.data_ptr() if d_status is not None else None, d_f.data_ptr(), st)
+        if rc:
+            _capi.raise_for(rc)
+        return d_f, offs
+
     def enable_events(self, on=True):
         _capi.lib().cri_job_enable_events(self._h, 1 if on else 0)
 

@@ -214,7 +214,10 @@ __global__ __launch_bounds__(64) void k_adx_decode(AdxArgs a) {
 }
 
 void launch_adx_decode(const AdxArgs& a, hipStream_t s) {
-    if (a.chains) hipLaunchKernelGGL(k_adx_decode, dim3((a.chains + 63) / 64), dim3(64), a.lds_in_bytes + a.lds_out_bytes, s, a);
+    if (!a.chains) return;
+    const uint32_t lds = a.lds_in_bytes + a.lds_out_bytes;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_adx_decode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_adx_decode, dim3((a.chains + 63) / 64), dim3(64), lds, s, a);
 }
 
 __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
@@ -337,7 +340,10 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
 }
 
 void launch_adx_encode(const AdxArgs& a, hipStream_t s) {
-    if (a.chains) hipLaunchKernelGGL(k_adx_encode, dim3((a.chains + 63) / 64), dim3(64), a.lds_in_bytes + a.lds_out_bytes, s, a);
+    if (!a.chains) return;
+    const uint32_t lds = a.lds_in_bytes + a.lds_out_bytes;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_adx_encode, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_adx_encode, dim3((a.chains + 63) / 64), dim3(64), lds, s, a);
 }
 
 

@@ -8,7 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -41,6 +43,7 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 struct cri_job {
     uint32_t kind = 0, n = 0;
+    int device = -1;                             // HIP device the job's metadata lives on (current device of the creating thread)
     std::vector<uint64_t> in_offsets, out_offsets;
     std::vector<int32_t> host_status;
     uint64_t in_bytes = 0, out_bytes = 0, scratch_bytes = 0, units = 0, units2 = 0, alg_bytes = 0;
@@ -70,6 +73,7 @@ struct cri_job {
     DevBuf d_segs;
     std::vector<uint32_t> item_tags;
     std::vector<uint64_t> item_sizes;             // true byte length of every output item (jobs whose items carry no length of their own)
+    std::vector<uint64_t> float_offsets;          // HCA decode: n + 1 offsets (in floats) of the items in the validation output
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
     std::vector<HcaEncArgs> hca_enc;
     std::vector<uint32_t> hca_enc_crc_off;       // per launch: offset into d_crcmul
@@ -108,15 +112,35 @@ struct cri_job {
     int upload_convert() { return convert.empty() ? 0 : d_convert.upload(convert); }
 };
 
-static bool g_dev_checked = false, g_dev_ok = false;
-extern "C" int cri_device_available(void) {
-    if (!g_dev_checked) {
-        int n = 0;
-        g_dev_ok = hipGetDeviceCount(&n) == hipSuccess && n > 0;
-        g_dev_checked = true;
-    }
-    return g_dev_ok ? 1 : 0;
+// Device selection.  HIP's current device is a per-thread setting; a job is bound to the device that was current in the
+// thread that created it (its metadata lives there), and every later call on the job -- from any thread -- switches to that
+// device for its duration (DeviceGuard).  One process per GPU never notices; a threaded host may drive several GPUs.
+static std::once_flag g_dev_once;
+static std::atomic<int> g_dev_count{0};
+static int device_count() {
+    std::call_once(g_dev_once, [] { int n = 0; g_dev_count.store(hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0); });
+    return g_dev_count.load();
 }
+extern "C" int cri_device_available(void) { return device_count() > 0 ? 1 : 0; }
+extern "C" int cri_device_count(void) { return device_count(); }
+extern "C" int cri_set_device(int device) {
+    if (device < 0 || device >= device_count()) return device_count() ? CRI_ERR_INVALID_ARG : CRI_ERR_HIP;
+    return hipSetDevice(device) == hipSuccess ? 0 : CRI_ERR_HIP;
+}
+extern "C" int cri_get_device(void) {
+    int d = -1;
+    if (!device_count() || hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
+namespace {
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+}  // namespace
 
 extern "C" void cri_free(void* p) { free(p); }
 
@@ -170,11 +194,13 @@ extern "C" uint64_t cri_job_units(const cri_job* j) { return j ? j->units : 0; }
 extern "C" uint64_t cri_job_units2(const cri_job* j) { return j ? j->units2 : 0; }
 extern "C" uint64_t cri_job_algorithmic_bytes(const cri_job* j) { return j ? j->alg_bytes : 0; }
 extern "C" const char* cri_job_dominant_kernel(const cri_job* j) { return j ? j->dominant.c_str() : ""; }
-extern "C" void cri_job_destroy(cri_job* j) { delete j; }
+extern "C" void cri_job_destroy(cri_job* j) { if (!j) return; DeviceGuard g(j->device); delete j; }
+extern "C" int cri_job_device(const cri_job* j) { return j ? j->device : -1; }
 
 static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
     cri_job* j = new cri_job();
     j->kind = kind; j->n = n;
+    if (hipGetDevice(&j->device) != hipSuccess) j->device = -1;
     j->in_offsets.assign(offsets, offsets + n + 1);
     j->in_bytes = offsets[n];
     j->host_status.assign(n, 0);
@@ -195,9 +221,11 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
     std::map<std::pair<uint32_t, uint64_t>, uint32_t> cipher_index;
     std::map<std::vector<uint8_t>, uint32_t> ath_index;
     ath_index[std::vector<uint8_t>(128, 0)] = 0;
-    uint64_t out_pos = 0;
+    uint64_t out_pos = 0, float_pos = 0;
+    j->float_offsets.assign((size_t)n + 1, 0);
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
+        j->float_offsets[i] = float_pos;
         if (take && take[i] != take_kind) { j->host_status[i] = CRI_ITEM_SKIPPED; continue; }
         const uint8_t* d = blob + offsets[i];
         size_t len = (size_t)(offsets[i + 1] - offsets[i]);
@@ -249,13 +277,15 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         j->images.push_back(std::move(im));
         HcaStream S; memset(&S, 0, sizeof S);
         S.src_offset = offsets[i] + hs_arg; S.dst_offset = out_pos + wh; S.format = fidx; S.cipher = cidx; S.frames = frames;
-        S.delay = h.delay; S.samples = spc; S.item = i;
+        S.delay = h.delay; S.samples = spc; S.item = i; S.float_offset = float_pos;
+        float_pos += (uint64_t)frames * 1024 * h.channels;
         streams.push_back(S);
         out_pos = align_up(out_pos + wh + (uint64_t)spc * h.channels * 2, 64);
         j->units += frames;
         j->alg_bytes += (uint64_t)frames * (h.frame_size + 2048ull * h.channels);
     }
     j->out_offsets[n] = out_pos;
+    j->float_offsets[n] = float_pos;
     // true (unaligned) end of each item for consumers: offsets[i+1] is the aligned start of the next item, so the
     // item length is carried by the WAV header itself (RIFF size + 8).
     j->out_bytes = out_pos;
@@ -322,16 +352,44 @@ static bool adx_pick_wave_per_file(bool all_std, size_t n_streams) {
     return n_streams <= 8192;
 }
 
-// rows per round and LDS bytes of the ADX kernels: 64 chains x T rows of (blocksize) + (2 * samples_per_block) bytes, +4 per file
-static void adx_lds_plan(AdxArgs& a, uint32_t max_bs, uint32_t max_spb, bool encode) {
-    const uint32_t per_row = 64 * (max_bs + 2 * max_spb);
-    uint32_t T = (56 * 1024) / per_row;
-    T = T < 1 ? 1 : (T > 16 ? 16 : T);
-    const uint32_t blk = ((T * 64 * max_bs + 3) & ~3u) + 64 * 8, pcm = ((T * 64 * 2 * max_spb + 3) & ~3u) + 64 * 8;
-    a.rows_per_round = T;
-    a.lds_in_bytes = encode ? pcm : blk;
-    a.lds_out_bytes = encode ? blk : pcm;
-}
+// LDS plan of the lane-per-chain ADX kernels.  A wave stages, for each of its files, T rows of blocks and of PCM in LDS
+// (regions padded to 4 bytes + 4), so what a wave needs is the sum over ITS files, not 64 x the largest item of the batch:
+// one ADX item with bitdepth 1 and blocksize 255 (8 * 253 samples per block, 4.3 KB per chain and row) must not size -- or
+// fail -- the launch of everybody else.  place() keeps a file inside one wave (as before) and also starts a new wave when
+// the wave's rows would pass ADX_LDS_ROW_LIMIT; an item that does not fit a wave on its own is left to the caller
+// (CRI_ERR_UNSUPPORTED for that item alone).  finish() picks T for ~56 KB per wave (occupancy) and the exact maxima.
+static const uint32_t ADX_LDS_ROW_LIMIT = 150 * 1024;
+struct AdxWavePlan {
+    std::vector<uint32_t> in_row, out_row, files;        // per wave: sum of the files' row bytes (in / out), file count
+    bool place(std::vector<uint32_t>& chain_stream, std::vector<int16_t>& history, uint32_t channels, uint32_t in_row_bytes, uint32_t out_row_bytes) {
+        const uint32_t need = ((in_row_bytes + 3) & ~3u) + ((out_row_bytes + 3) & ~3u) + 8;
+        if (channels > 64 || need > ADX_LDS_ROW_LIMIT) return false;
+        size_t w = chain_stream.size() / 64;
+        if (in_row.size() <= w) { in_row.resize(w + 1, 0); out_row.resize(w + 1, 0); files.resize(w + 1, 0); }
+        const uint32_t used = ((in_row[w] + 3) & ~3u) + ((out_row[w] + 3) & ~3u) + 8 * files[w] + 8 * 64;
+        if ((chain_stream.size() % 64) + channels > 64 || (files[w] && used + need > ADX_LDS_ROW_LIMIT)) {
+            while (chain_stream.size() % 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
+            w = chain_stream.size() / 64;
+            in_row.resize(w + 1, 0); out_row.resize(w + 1, 0); files.resize(w + 1, 0);
+        }
+        in_row[w] += (in_row_bytes + 3) & ~3u; out_row[w] += (out_row_bytes + 3) & ~3u; files[w]++;
+        return true;
+    }
+    void finish(AdxArgs& a) const {
+        uint32_t worst = 1;
+        for (size_t w = 0; w < in_row.size(); w++) worst = std::max(worst, in_row[w] + out_row[w]);
+        uint32_t T = (56 * 1024) / worst;
+        T = T < 1 ? 1 : (T > 16 ? 16 : T);
+        uint32_t in_max = 0, out_max = 0;
+        for (size_t w = 0; w < in_row.size(); w++) {      // region = T * row bytes rounded up to 4, + 4 (each row sum is already a multiple of 4 per file)
+            in_max = std::max(in_max, T * in_row[w] + 8 * files[w]);
+            out_max = std::max(out_max, T * out_row[w] + 8 * files[w]);
+        }
+        a.rows_per_round = T;
+        a.lds_in_bytes = ((in_max + 15) & ~15u) + 64;
+        a.lds_out_bytes = ((out_max + 15) & ~15u) + 64;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ ADX decode
 static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out, const uint8_t* take = nullptr, uint8_t take_kind = 0) {
@@ -340,7 +398,7 @@ static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint3
     cri_job* j = new_job(CRI_JOB_ADX_DECODE, offsets, n);
     j->dominant = "k_adx_decode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history;
-    uint32_t max_bs = 3, max_spb = 1;
+    AdxWavePlan plan;
     bool all_std = true;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -360,10 +418,11 @@ static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         if (S.src_offset > S.src_end) S.src_offset = S.src_end;
         S.frames = h.blocks; S.channels = h.channels; S.blocksize = h.blocksize; S.bitdepth = h.bitdepth; S.mode = h.mode;
         S.samples_per_block = h.samples_per_block; S.coef0 = h.coef[0]; S.coef1 = h.coef[1]; S.samples = h.sample_count;
-        if (h.channels > 64) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); continue; }
-        while ((chain_stream.size() % 64) + h.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
+        // (more than 64 channels, or one block row that does not fit a wave's LDS: bitdepth 1 with tens of channels)
+        if (!plan.place(chain_stream, history, h.channels, h.channels * h.blocksize, h.channels * h.samples_per_block * 2)) {
+            j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); continue;
+        }
         S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
-        max_bs = std::max(max_bs, h.blocksize); max_spb = std::max(max_spb, h.samples_per_block);
         if (!(h.blocksize == 18 && h.bitdepth == 4 && h.channels <= 2)) all_std = false;
         for (uint32_t c = 0; c < h.channels; c++) {
             chain_stream.push_back((uint32_t)streams.size());
@@ -376,7 +435,7 @@ static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint3
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->adx.chains = (uint32_t)chain_stream.size();
-    adx_lds_plan(j->adx, max_bs, max_spb, false);
+    plan.finish(j->adx);
     j->adx_streams = (uint32_t)streams.size();
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size());
     if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
@@ -689,7 +748,10 @@ extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offs
             while (tell < stream_size) {
                 uint32_t take;
                 if (tell == 0) take = first;
-                else take = tell + chunk > stream_size ? (uint32_t)((stream_size - first - chunk) % chunk) : chunk;
+                else if (tell + chunk > stream_size) {           // Python's floor modulo (usm.py:598): the operand is negative for a stream shorter than one chunk
+                    const int64_t m = ((int64_t)stream_size - (int64_t)first - (int64_t)chunk) % (int64_t)chunk;
+                    take = (uint32_t)(m < 0 ? m + (int64_t)chunk : m);
+                } else take = chunk;
                 take = (uint32_t)std::min<uint64_t>(take, len - tell);
                 if (take == 0) break;
                 emit(i, offsets[i] + tell, take, interval, encrypt_audio != 0); chunks++;
@@ -724,7 +786,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     cri_job* j = new_job(CRI_JOB_ADX_ENCODE, offsets, n);
     j->dominant = "k_adx_encode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history; std::vector<uint8_t> stale;
-    uint32_t max_bs = 3, max_spb = 1;
+    AdxWavePlan plan;
     bool all_std = true;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -750,10 +812,10 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
         S.src_offset = offsets[i] + w.data_offset; S.src_end = offsets[i + 1]; S.dst_offset = out_pos + hs;
         S.frames = pl.frames; S.channels = pl.channels; S.blocksize = bs; S.bitdepth = p->bitdepth; S.mode = p->encoding_mode;
         S.samples_per_block = pl.samples_per_block; S.coef0 = pl.coef[0]; S.coef1 = pl.coef[1]; S.samples = pl.samples_per_channel;
-        if (pl.channels > 64) { j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); j->images.pop_back(); continue; }
+        if (!plan.place(chain_stream, history, pl.channels, pl.channels * pl.samples_per_block * 2, pl.channels * bs)) {
+            j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); j->images.pop_back(); continue;
+        }
         if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(offsets[i] + w.data_offset, w); S.src_end = S.src_offset + 2ull * w.column_size; S.src_in_scratch = 1; }
-        while ((chain_stream.size() % 64) + pl.channels > 64) { chain_stream.push_back(0xFFFFFFFFu); history.push_back(0); history.push_back(0); }
-        max_bs = std::max(max_bs, bs); max_spb = std::max(max_spb, pl.samples_per_block);
         if (!(bs == 18 && p->bitdepth == 4 && pl.channels <= 2 && pl.image.size() <= hs + 1)) all_std = false;
         S.filter_bits = p->filter << 13; S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
         if (pl.image.size() > hs) { S.stale_offset = (uint32_t)stale.size(); S.stale_len = (uint32_t)(pl.image.size() - hs);
@@ -769,7 +831,7 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     j->adx.chains = (uint32_t)chain_stream.size();
-    adx_lds_plan(j->adx, max_bs, max_spb, true);
+    plan.finish(j->adx);
     j->adx_streams = (uint32_t)streams.size();
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size());
     if (j->adx_wave_per_file) j->dominant = "k_adx_encode_wpf";
@@ -935,9 +997,10 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
 }
 
 // ------------------------------------------------------------------------------------------------ run
-extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, void* hip_stream) {
+static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, float* d_floats, void* hip_stream) {
     if (!j || !d_in || (!d_out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
     if (j->scratch_bytes && !d_scratch) return CRI_ERR_INVALID_ARG;
+    DeviceGuard guard(j->device);                // the caller's buffers and stream must belong to the job's device
     hipStream_t s = (hipStream_t)hip_stream;
     if (j->events_on) j->begin_run();
     if (d_status) launch_fill_i32(d_status, 0, j->n, s);
@@ -954,6 +1017,7 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
                 a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.scratch = (uint8_t*)d_scratch; a.status = d_status;
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p;
+                a.float_out = d_floats;
                 j->mark(0, true, s); launch_hca_prepare(a, s); j->mark(0, false, s);
                 j->mark(1, true, s); launch_hca_parse(a, s); j->mark(1, false, s);
                 j->mark(2, true, s); launch_hca_transform(a, s); j->mark(2, false, s);
@@ -1000,6 +1064,19 @@ extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_sc
     return hipGetLastError() == hipSuccess ? 0 : CRI_ERR_HIP;
 }
 
+extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, void* hip_stream) {
+    return job_run(j, d_in, d_out, d_scratch, d_status, nullptr, hip_stream);
+}
+
+// Validation run of an HCA decode job: the same kernels, in instances that also store wave[][] (the floats before the int16
+// conversion, hca.cpp:1987-1992 -> 339-360) so that a test can hold the device to north_star's float tolerance.
+extern "C" int cri_job_run_floats(cri_job* j, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, float* d_floats, void* hip_stream) {
+    if (!j || j->kind != CRI_JOB_HCA_DECODE || !d_floats) return CRI_ERR_INVALID_ARG;
+    return job_run(j, d_in, d_out, d_scratch, d_status, d_floats, hip_stream);
+}
+extern "C" uint64_t cri_job_float_count(const cri_job* j) { return j && !j->float_offsets.empty() ? j->float_offsets.back() : 0; }
+extern "C" const uint64_t* cri_job_float_offsets(const cri_job* j) { return j && !j->float_offsets.empty() ? j->float_offsets.data() : nullptr; }
+
 extern "C" int cri_job_enable_events(cri_job* j, int on) {
     if (!j) return CRI_ERR_INVALID_ARG;
     if (j->class_names.empty()) {
@@ -1014,6 +1091,7 @@ extern "C" int cri_job_enable_events(cri_job* j, int on) {
 
 extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int max_classes) {
     if (!j || !ms) return CRI_ERR_INVALID_ARG;
+    DeviceGuard guard(j->device);
     int n = (int)j->class_names.size();
     for (int c = 0; c < n && c < max_classes; c++) {
         float total = 0.f;
@@ -1031,6 +1109,7 @@ extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int m
 // Host buffers in, host buffers out: device allocations, H2D, the job, D2H.  `out` must hold cri_job_output_bytes(job).
 extern "C" int cri_job_run_host_into(cri_job* j, const uint8_t* blob, uint8_t* out, int32_t* status) {
     if (!j || !blob || (!out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
+    DeviceGuard guard(j->device);
     void *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr; int32_t* d_st = nullptr;
     int rc = 0;
     auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = CRI_ERR_HIP; return e == hipSuccess; };

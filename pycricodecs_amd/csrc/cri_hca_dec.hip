@@ -91,6 +91,9 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
     if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
     const HcaStream st = a.streams[si];
     const uint8_t* src = a.in + st.src_offset + (uint64_t)f * (uint32_t)fs;
+    // padding lanes of the last tile load (and discard) the tile's first frame: lane 0 is always a real frame, whereas a
+    // stream without frames at the start of the group may sit at the very end of the input blob
+    if (!valid) src = (const uint8_t*)readlane64((uint64_t)src, 0);
     const uint8_t* ct = cipher_in_lds ? cipher_lds + st.cipher * 256 : a.cipher_tables + st.cipher * 256;
     uint32_t* tb = (uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64;
     uint32_t crc = 0;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
                 for (uint32_t k = 0; k < 16; k++) {
                     const bool fv = __builtin_amdgcn_readlane((int)valid, fb + k) != 0;
                     const uint8_t* p = (const uint8_t*)readlane64((uint64_t)src, fb + k);
-                    const uint32_t w = ld_u32_unaligned(p + 4 * (whole ? rr : 0u));     // always a readable address (frame 0 of the group for padding lanes)
+                    const uint32_t w = ld_u32_unaligned(p + 4 * (whole ? rr : 0u));     // always a readable address (the tile's first frame for padding lanes)
                     v[k] = fv && whole ? w : 0u;
                 }
                 if (__any(part)) {                                          // the last, partial word of a frame (frame_size % 4 != 0)
@@ -857,12 +860,17 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
                 const int i = (int)l16 + 16 * m;
                 const float t0 = w_rhi[m] * dp[63 - i], t1 = w_rlo[m] * dp[i];
                 const float p0 = have_prev ? t0 : 0.0f, p1 = have_prev ? t1 : 0.0f;
-                const float o0 = (w_lo[m] * d[i + 64] + p0) * 32768.0f;
-                const float o1 = (w_hi[m] * d[127 - i] - p1) * 32768.0f;
+                const float v0 = w_lo[m] * d[i + 64] + p0, v1 = w_hi[m] * d[127 - i] - p1;     // wave[sf][i], wave[sf][i + 64]
+                const float o0 = v0 * 32768.0f;
+                const float o1 = v1 * 32768.0f;
                 int32_t q0 = cvt_trunc_x86(o0), q1 = cvt_trunc_x86(o1);
                 q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
                 q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
                 if (c < C) { pcms[i * C + c] = (uint16_t)(int16_t)q0; pcms[(i + 64) * C + c] = (uint16_t)(int16_t)q1; }
+                if (a.float_out && c < C) {                    // validation hook: the samples before the int16 conversion
+                    float* fo = a.float_out + st.float_offset + ((uint64_t)f * 1024 + sf * 128) * C + c;
+                    fo[(uint64_t)i * C] = v0; fo[(uint64_t)(i + 64) * C] = v1;
+                }
             }
         }
         wave_lds_sync();
@@ -1141,7 +1149,8 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
 // One loop over "steps": step -1 (only when the run does not start the stream) is the halo -- the DCT of the previous
 // frame's last subframe, which only feeds the overlap ring -- and steps 0 .. nf*2C-1 are the passes of the run's frames.
 // (the !PLAIN variants carry ~11 KB of LDS per wave, which already limits them to 3.5 waves per SIMD: give them the registers)
-template <bool PLAIN, int C>
+// FLT: validation instance that also stores the samples before the int16 conversion (HcaDecArgs::float_out)
+template <bool PLAIN, int C, bool FLT>
 __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transform(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
@@ -1257,8 +1266,13 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
             const int i = (int)l16 + 16 * m;
             const float t0 = T.win[127 - i] * dp[63 - i], t1 = T.win[63 - i] * dp[i];
             const float p0 = have_prev ? t0 : 0.0f, p1 = have_prev ? t1 : 0.0f;
-            o0[m] = (T.win[i] * d[i + 64] + p0) * 32768.0f;
-            o1[m] = (T.win[i + 64] * d[127 - i] - p1) * 32768.0f;
+            const float v0 = T.win[i] * d[i + 64] + p0, v1 = T.win[i + 64] * d[127 - i] - p1;        // wave[sf][i], wave[sf][i + 64]
+            o0[m] = v0 * 32768.0f;
+            o1[m] = v1 * 32768.0f;
+            if (FLT) {
+                float* fo = a.float_out + st.float_offset + ((uint64_t)f * 1024 + sf * 128) * C + c;
+                fo[(uint64_t)i * C] = v0; fo[(uint64_t)(i + 64) * C] = v1;
+            }
             const uint32_t u0 = __float_as_uint(o0[m]) & 0x7FFFFFFFu, u1 = __float_as_uint(o1[m]) & 0x7FFFFFFFu;
             big = max(big, max(u0, u1));
         }
@@ -1326,7 +1340,7 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t sf2[4]; };   // setup inputs o
 #ifndef CRI_PLAIN_WAVES
 #define CRI_PLAIN_WAVES 4
 #endif
-template <int C>
+template <int C, bool FLT>
 __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
@@ -1519,7 +1533,16 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
                 const float dy = x[j].y, pv = prev[j];
                 const f2 t = f2{wa[j], wb[j]} * f2{dy, dy};          // w[63-k]*d[127-k], w[64+k]*d[127-k]
                 const f2 r = f2{wb[j], wa[j]} * f2{pv, pv};          // w[64+k]*prev[k],  w[63-k]*prev[k]
-                o[j] = (t + f2{r.x, -r.y}) * f2{32768.0f, 32768.0f};
+                const f2 wv = t + f2{r.x, -r.y};                   // wave[sf][63 - k], wave[sf][64 + k]
+                o[j] = wv * f2{32768.0f, 32768.0f};
+                if (FLT) {
+                    bool live; const uint32_t ff = unit_frame(u, s, live);
+                    if (live) {
+                        const uint32_t k = ((j < 2 ? dlogp.x : dlogp.y) >> (16 * (j & 1))) & 0xFF;
+                        float* fo = a.float_out + st.float_offset + ((uint64_t)ff * 1024 + sf * 128) * C + c;
+                        fo[(uint64_t)(63 - k) * C] = wv.x; fo[(uint64_t)(64 + k) * C] = wv.y;
+                    }
+                }
                 prev[j] = x[j].x;
                 big = __builtin_fmaxf(big, __builtin_fmaxf(__builtin_fabsf(o[j].x), __builtin_fabsf(o[j].y)));
             }
@@ -1589,17 +1612,22 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     const bool in_regs = a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
     if (in_regs) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
-#define CRI_LAUNCH_TR(P, CH) hipLaunchKernelGGL((k_hca_transform<P, CH>), dim3(a.runs), dim3(64), lds, s, a)
+        const bool flt = a.float_out != nullptr;
+#define CRI_LAUNCH_TR(P, CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform<P, CH, true>), dim3(a.runs), dim3(64), lds, s, a); \
+                                  else hipLaunchKernelGGL((k_hca_transform<P, CH, false>), dim3(a.runs), dim3(64), lds, s, a); } while (0)
+#define CRI_LAUNCH_PL(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); \
+                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
         if (a.plain) switch (a.channels) {
-            case 1: hipLaunchKernelGGL(k_hca_transform_plain<1>, dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); break;
-            case 2: hipLaunchKernelGGL(k_hca_transform_plain<2>, dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); break;
-            case 4: hipLaunchKernelGGL(k_hca_transform_plain<4>, dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); break;
+            case 1: CRI_LAUNCH_PL(1); break;
+            case 2: CRI_LAUNCH_PL(2); break;
+            case 4: CRI_LAUNCH_PL(4); break;
             case 6: CRI_LAUNCH_TR(true, 6); break; default: CRI_LAUNCH_TR(true, 8); break;
         } else switch (a.channels) {
             case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;
             case 6: CRI_LAUNCH_TR(false, 6); break; default: CRI_LAUNCH_TR(false, 8); break;
         }
 #undef CRI_LAUNCH_TR
+#undef CRI_LAUNCH_PL
     } else {
         size_t lds = (size_t)a.channels * (2 * 128 + 2 * TR_DSTRIDE) * 4 + a.channels * 256 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);

@@ -24,7 +24,8 @@ uint16_t crc16(const uint8_t* p, size_t n) {           // hca.cpp:205-211
 
 // ------------------------------------------------------------------------------------------------ WAV
 // RIFF chunk walk: pcm.cpp:335-342 (riff), 291-327 (chunks), 177-201 (fmt), 243-261 (smpl), 276-283 (data),
-// 419-444 (sample layout).  Every access is bounds-checked against `len` (the reference trusts the RIFF size).
+// 419-444 (sample layout).  Every access is bounds-checked against `len` (the reference trusts the RIFF size) and every
+// iteration advances by at least 8 bytes (a chunk length of 0xFFFFFFF8..0xFFFFFFFF wraps the reference's 32-bit size).
 int wav_parse(const uint8_t* w, size_t len, WavInfo& o) {
     o = WavInfo();
     if (len < 12) return CRI_ERR_PCM(1);
@@ -35,7 +36,8 @@ int wav_parse(const uint8_t* w, size_t len, WavInfo& o) {
     while (sum < fullsize) {
         if (cur + 8 > len) return CRI_ERR_PCM(7);
         uint32_t sig = le32(w + cur), size = le32(w + cur + 4) + 8;
-        size += ((size & 1) && size + sum + (size & 1) <= fullsize);
+        if (size < 8) return CRI_ERR_PCM(7);                  // the 32-bit add wrapped (the reference then stops advancing: size 0 loops forever)
+        size += ((size & 1) && (uint64_t)size + sum + (size & 1) <= fullsize);
         if (sig == 0x20746D66u) {
             uint32_t fsz = le32(w + cur + 4);
             if (fsz < 16) return CRI_ERR_PCM(2);
@@ -73,8 +75,8 @@ int wav_parse(const uint8_t* w, size_t len, WavInfo& o) {
             have_data = true;
         }
         cur += size;
+        if ((uint64_t)sum + size > fullsize) return CRI_ERR_PCM(7);
         sum += size;
-        if (sum > fullsize) return CRI_ERR_PCM(7);
     }
     if (!have_fmt) return CRI_ERR_PCM(2);
     if (!have_data) return CRI_ERR_PCM(6);
@@ -284,60 +286,70 @@ void hca_channel_types(uint32_t channels, uint32_t track_count, uint32_t stereo_
 }
 
 // hca.cpp:628-984 (clHCA_DecodeHeader).  Returns 0 or CRI_ERR_HCA_HEADER.
+// The reference reads the chunks through its bit reader, initialised with the header size the caller passed (hca.cpp:639):
+// a read that would cross that bound returns 0 (hca.cpp:231-232), so a chunk magic is only ever matched inside it and
+// fields cut off by it read as zero.  `rd` is that rule (and never reads past `len` either).  The `ath` chunk does not
+// reduce `size` (hca.cpp:750-753) -- kept, it changes which later chunks a short header still accepts.
 int hca_parse_header(const uint8_t* d, size_t len, uint32_t size_arg, HcaHeader& h) {
     memset(&h, 0, sizeof h);
     uint32_t size = size_arg, pos = 0;
-    auto magic = [&](uint32_t at) { return be32(d + at) & 0x7F7F7F7Fu; };
-    auto have = [&](uint32_t n) { return (size_t)pos + n <= len; };
+    const size_t bound = len < (size_t)size_arg ? len : (size_t)size_arg;
+    auto rd = [&](uint32_t at, uint32_t n) -> uint32_t {
+        if ((size_t)at + n > bound) return 0;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < n; k++) v = (v << 8) | d[at + k];
+        return v;
+    };
+    auto magic = [&](uint32_t at) { return rd(at, 4) & 0x7F7F7F7Fu; };
     if (!d || size < 8 || len < 8) return CRI_ERR_HCA_HEADER;
     if (magic(0) != 0x48434100u) return CRI_ERR_HCA_HEADER;
-    h.version = be16(d + 4); h.header_size = be16(d + 6);
+    h.version = rd(4, 2); h.header_size = rd(6, 2);
     if (h.version != 0x0101 && h.version != 0x0102 && h.version != 0x0103 && h.version != 0x0200 && h.version != 0x0300) return CRI_ERR_HCA_HEADER;
     if (size < h.header_size || len < h.header_size) return CRI_ERR_HCA_HEADER;
     if (crc16(d, h.header_size)) return CRI_ERR_HCA_HEADER;
     size -= 8; pos = 8;
-    if (size >= 0x10 && have(16) && magic(pos) == 0x666D7400u) {
-        h.channels = d[pos + 4]; h.rate = be32(d + pos + 4) & 0xFFFFFF; h.frame_count = be32(d + pos + 8);
-        h.delay = be16(d + pos + 12); h.padding = be16(d + pos + 14);
+    if (size >= 0x10 && magic(pos) == 0x666D7400u) {                                   // fmt, hca.cpp:667-688
+        h.channels = rd(pos + 4, 1); h.rate = rd(pos + 5, 3); h.frame_count = rd(pos + 8, 4);
+        h.delay = rd(pos + 12, 2); h.padding = rd(pos + 14, 2);
         if (!(h.channels >= 1 && h.channels <= 16) || h.frame_count == 0 || !(h.rate >= 1 && h.rate <= 0x7FFFFF)) return CRI_ERR_HCA_HEADER;
         size -= 0x10; pos += 0x10;
     } else return CRI_ERR_HCA_HEADER;
-    if (size >= 0x10 && have(16) && magic(pos) == 0x636F6D70u) {
-        h.frame_size = be16(d + pos + 4); h.min_res = d[pos + 6]; h.max_res = d[pos + 7]; h.track_count = d[pos + 8];
-        h.channel_config = d[pos + 9]; h.total_bands = d[pos + 10]; h.base_bands = d[pos + 11]; h.stereo_bands = d[pos + 12];
-        h.bands_per_hfr_group = d[pos + 13]; h.ms_stereo = d[pos + 14];
+    if (size >= 0x10 && magic(pos) == 0x636F6D70u) {                                   // comp, hca.cpp:691-709
+        h.frame_size = rd(pos + 4, 2); h.min_res = rd(pos + 6, 1); h.max_res = rd(pos + 7, 1); h.track_count = rd(pos + 8, 1);
+        h.channel_config = rd(pos + 9, 1); h.total_bands = rd(pos + 10, 1); h.base_bands = rd(pos + 11, 1); h.stereo_bands = rd(pos + 12, 1);
+        h.bands_per_hfr_group = rd(pos + 13, 1); h.ms_stereo = rd(pos + 14, 1);
         size -= 0x10; pos += 0x10;
-    } else if (size >= 0x0c && have(12) && magic(pos) == 0x64656300u) {
-        h.frame_size = be16(d + pos + 4); h.min_res = d[pos + 6]; h.max_res = d[pos + 7];
-        h.total_bands = d[pos + 8] + 1u; h.base_bands = d[pos + 9] + 1u;
-        h.track_count = d[pos + 10] >> 4; h.channel_config = d[pos + 10] & 0xF; h.stereo_type = d[pos + 11];
+    } else if (size >= 0x0c && magic(pos) == 0x64656300u) {                            // dec (v1.x), hca.cpp:710-727
+        h.frame_size = rd(pos + 4, 2); h.min_res = rd(pos + 6, 1); h.max_res = rd(pos + 7, 1);
+        h.total_bands = rd(pos + 8, 1) + 1u; h.base_bands = rd(pos + 9, 1) + 1u;
+        h.track_count = rd(pos + 10, 1) >> 4; h.channel_config = rd(pos + 10, 1) & 0xF; h.stereo_type = rd(pos + 11, 1);
         if (h.stereo_type == 0) h.base_bands = h.total_bands;
         h.stereo_bands = h.total_bands - h.base_bands;
         h.bands_per_hfr_group = 0;
         size -= 0x0c; pos += 0x0c;
     } else return CRI_ERR_HCA_HEADER;
-    if (size >= 8 && have(8) && magic(pos) == 0x76627200u) {
-        uint32_t mx = be16(d + pos + 4);
+    if (size >= 8 && magic(pos) == 0x76627200u) {                                      // vbr, hca.cpp:733-748
+        uint32_t mx = rd(pos + 4, 2);
         if (!(h.frame_size == 0 && mx > 8 && mx <= 0x1FF)) return CRI_ERR_HCA_HEADER;
         size -= 8; pos += 8;
     }
-    if (size >= 6 && have(6) && magic(pos) == 0x61746800u) { h.ath_type = be16(d + pos + 4); pos += 6; }
+    if (size >= 6 && magic(pos) == 0x61746800u) { h.ath_type = rd(pos + 4, 2); pos += 6; } // ath, hca.cpp:750-753: `size` is NOT reduced
     else h.ath_type = h.version < 0x0200 ? 1 : 0;
-    if (size >= 0x10 && have(16) && magic(pos) == 0x6C6F6F70u) {
-        h.loop_start_frame = be32(d + pos + 4); h.loop_end_frame = be32(d + pos + 8);
-        h.loop_start_delay = be16(d + pos + 12); h.loop_end_padding = be16(d + pos + 14);
+    if (size >= 0x10 && magic(pos) == 0x6C6F6F70u) {                                   // loop, hca.cpp:760-774
+        h.loop_start_frame = rd(pos + 4, 4); h.loop_end_frame = rd(pos + 8, 4);
+        h.loop_start_delay = rd(pos + 12, 2); h.loop_end_padding = rd(pos + 14, 2);
         h.loop_flag = 1;
         if (!(h.loop_start_frame <= h.loop_end_frame && h.loop_end_frame < h.frame_count)) return CRI_ERR_HCA_HEADER;
         size -= 0x10; pos += 0x10;
     }
-    if (size >= 6 && have(6) && magic(pos) == 0x63697068u) {
-        h.ciph_type = be16(d + pos + 4);
+    if (size >= 6 && magic(pos) == 0x63697068u) {                                      // ciph, hca.cpp:786-794
+        h.ciph_type = rd(pos + 4, 2);
         if (!(h.ciph_type == 0 || h.ciph_type == 1 || h.ciph_type == 56)) return CRI_ERR_HCA_HEADER;
         size -= 6; pos += 6;
     }
-    if (size >= 8 && have(8) && magic(pos) == 0x72766100u) { size -= 8; pos += 8; }
-    if (size >= 5 && have(5) && magic(pos) == 0x636F6D6Du) {
-        h.comment_len = d[pos + 4];
+    if (size >= 8 && magic(pos) == 0x72766100u) { size -= 8; pos += 8; }               // rva, hca.cpp:799-812 (volume unused by the decoder)
+    if (size >= 5 && magic(pos) == 0x636F6D6Du) {                                      // comm, hca.cpp:814-830
+        h.comment_len = rd(pos + 4, 1);
         if (h.comment_len > size) return CRI_ERR_HCA_HEADER;
         size -= 5 + h.comment_len; pos += 5 + h.comment_len;
     }
@@ -415,11 +427,22 @@ uint64_t hca_mix_key(uint64_t key, uint16_t subkey) {        // hca.cpp:3381-338
     return key;
 }
 
-// hca.cpp:3166-3250: toggle bit 7 of the chunk magics, rewrite the ciph type, refresh the header CRC.
+// hca.cpp:3166-3250 (CryptHeader): toggle bit 7 of the chunk magics, rewrite the ciph type, refresh the header CRC.
+// Same walk as hca_parse_header, including the `ath` chunk that leaves `size` alone (hca.cpp:3203-3206): every magic is
+// matched through the reference's bounded reader (bound = the header size, hca.cpp:3171), so nothing past the header is
+// read; the reference's one unguarded write -- the cipher type of a `ciph` chunk whose last bytes lie past the header --
+// is dropped instead of written out of bounds.
 void hca_crypt_header(uint8_t* d, uint32_t hs, uint32_t encrypt, uint32_t type) {
     uint32_t size = hs, pos = 0;
-    auto magic = [&](uint32_t at) { return be32(d + at) & 0x7F7F7F7Fu; };
-    auto flip = [&](uint32_t at, int n) { for (int i = 0; i < n; i++) d[at + i] ^= 0x80; };
+    auto rd = [&](uint32_t at, uint32_t n) -> uint32_t {
+        if ((uint64_t)at + n > hs) return 0;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < n; k++) v = (v << 8) | d[at + k];
+        return v;
+    };
+    auto magic = [&](uint32_t at) { return rd(at, 4) & 0x7F7F7F7Fu; };
+    auto flip = [&](uint32_t at, int n) { for (int i = 0; i < n; i++) d[at + i] ^= 0x80; };   // only after magic(at) matched: at + 4 <= hs
+    if (hs < 2) return;
     if (magic(pos) == 0x48434100u) { flip(pos, 3); pos += 8; size -= 8; }
     if (size >= 0x10 && magic(pos) == 0x666D7400u) { flip(pos, 3); pos += 16; size -= 16; }
     if (size >= 0x10 && magic(pos) == 0x636F6D70u) { flip(pos, 4); pos += 16; size -= 16; }
@@ -427,10 +450,14 @@ void hca_crypt_header(uint8_t* d, uint32_t hs, uint32_t encrypt, uint32_t type) 
     if (size >= 8 && magic(pos) == 0x76627200u) { flip(pos, 3); pos += 8; size -= 8; }
     if (size >= 6 && magic(pos) == 0x61746800u) { flip(pos, 3); pos += 6; }
     if (size >= 0x10 && magic(pos) == 0x6C6F6F70u) { flip(pos, 4); pos += 16; size -= 16; }
-    if (size >= 6 && magic(pos) == 0x63697068u) { flip(pos, 4); put_be16(d + pos + 4, encrypt == 1 ? (type & 0xFFFF) : 0); pos += 6; size -= 6; }
+    if (size >= 6 && magic(pos) == 0x63697068u) {
+        flip(pos, 4);
+        if ((uint64_t)pos + 6 <= hs) put_be16(d + pos + 4, encrypt == 1 ? (type & 0xFFFF) : 0);
+        pos += 6; size -= 6;
+    }
     if (size >= 8 && magic(pos) == 0x72766100u) { flip(pos, 3); pos += 8; size -= 8; }
-    if (size >= 5 && magic(pos) == 0x636F6D6Du) { uint32_t cl = d[pos + 4]; flip(pos, 4); pos += 5 + cl; size -= 5 + cl; }
-    if (size >= 4 && pos + 4 <= hs && magic(pos) == 0x70616400u) flip(pos, 3);
+    if (size >= 5 && magic(pos) == 0x636F6D6Du) { uint32_t cl = rd(pos + 4, 1); flip(pos, 4); pos += 5 + cl; size -= 5 + cl; }
+    if (size >= 4 && magic(pos) == 0x70616400u) flip(pos, 3);
     put_be16(d + hs - 2, crc16(d, hs - 2));
 }
 

@@ -31,6 +31,8 @@ struct HcaDecArgs {
     uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][R+1][64] uint32 (big-endian words)
     uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
     uint64_t resg_offset;          // scratch byte offset of this group's band code descriptions: [tile][C][8 blocks][64 lanes] uint4 (16 bands x 1 byte)
+    float* float_out;              // validation runs only (cri_job_run_floats), else null: every frame's samples before the int16
+                                   // conversion (hca.cpp:1987-1992 wave[][]), [frame][1024][C] floats from HcaStream::float_offset on
 };
 size_t hca_prepare_lds_bytes(uint32_t chunk_rows, uint32_t n_cipher);
 size_t hca_parse_lds_bytes(uint32_t channels);

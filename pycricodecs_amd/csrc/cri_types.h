@@ -39,7 +39,8 @@ struct HcaStream {
     uint32_t enc_loop_src;         // first source sample of the post audio (the loop start)
     uint32_t enc_loop_src_end;     // source samples at or past this index read as zero in the post audio
     uint32_t enc_have;             // samples per channel actually present in the WAV data
-    uint32_t pad1, pad2, pad3;
+    uint64_t float_offset;         // decode: first float of this stream in the validation output (HcaDecArgs::float_out), in floats
+    uint32_t pad3;
 };
 
 // Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):

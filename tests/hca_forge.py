@@ -83,3 +83,89 @@ def accepted_random_stream(hca: bytes, seed: int, density: float, accept):
         if not ok[f]:
             frames[f] = good[f % len(good)]
     return bytes(b[:hs]) + b"".join(frames)
+
+
+def forge_header(hca: bytes, version=0x0200, dec=None, vbr=None, ath=None, loop=None, ciph=0, rva=None, comm=None, pad=True,
+                 frame_size=None) -> bytes:
+    """Rebuild the header of a v2.0 stream in any of the chunk forms clHCA_DecodeHeader accepts (hca.cpp:628-845), frames
+    untouched.  Chunk order is the reference's: HCA, fmt, comp | dec, vbr, ath, loop, ciph, rva, comm, pad.
+      dec  = None keeps the comp chunk; dict(stereo_type=.., base=..) writes the v1.x "dec" chunk (hca.cpp:710-727) with
+             the comp chunk's frame size / band count (base = base band count when stereo_type != 0)
+      vbr  = (max_frame_size, noise_level); ath = type or None; loop = (start_frame, end_frame, start_delay, end_padding)
+      ciph = type or None (no chunk); rva = float volume; comm = comment bytes; pad = pad the header to a multiple of 0x20
+    """
+    b = bytearray(hca)
+    hs = struct.unpack(">H", b[6:8])[0]
+    assert bytes(x & 0x7F for x in b[0x18:0x1C]) == b"comp"
+    fmt = bytes(b[8:0x18])
+    comp = bytes(b[0x18:0x28])
+    fs = struct.unpack(">H", comp[4:6])[0] if frame_size is None else frame_size
+    out = bytearray()
+    out += b"fmt\0" + fmt[4:]
+    if dec is None:
+        out += b"comp" + struct.pack(">H", fs) + comp[6:]
+    else:
+        total = comp[10]
+        base = dec.get("base", total)
+        out += b"dec\0" + struct.pack(">HBBBBBB", fs, comp[6], comp[7], total - 1, base - 1, (comp[8] << 4) | (comp[9] & 0xF),
+                                      dec.get("stereo_type", 0))
+    if vbr is not None:
+        out += b"vbr\0" + struct.pack(">HH", vbr[0], vbr[1])
+    if ath is not None:
+        out += b"ath\0" + struct.pack(">H", ath)
+    if loop is not None:
+        out += b"loop" + struct.pack(">IIHH", *loop)
+    if ciph is not None:
+        out += b"ciph" + struct.pack(">H", ciph)
+    if rva is not None:
+        out += b"rva\0" + struct.pack(">f", rva)
+    if comm is not None:
+        out += b"comm" + bytes([len(comm)]) + comm
+    n = 8 + len(out) + 2
+    if pad:
+        tgt = (n + 4 + 0x1F) // 0x20 * 0x20
+        out += b"pad\0" + bytes(tgt - n - 4)
+        n = tgt
+    head = bytearray(b"HCA\0" + struct.pack(">HH", version, n) + bytes(out) + b"\0\0")
+    head[n - 2:n] = struct.pack(">H", crc16(bytes(head[:n - 2])))
+    return bytes(head) + bytes(b[hs:])
+
+
+def one_frame_stream(hca: bytes) -> bytes:
+    """The same header with frame_count 1 and no delay/padding accounting beyond what one frame holds; first frame kept."""
+    b = bytearray(hca)
+    hs = struct.unpack(">H", b[6:8])[0]
+    fs = 0
+    for off in range(8, hs - 4):
+        if bytes(x & 0x7F for x in b[off:off + 4]) in (b"comp", b"dec\0"):
+            fs = struct.unpack(">H", b[off + 4:off + 6])[0]
+            break
+    b[0x10:0x14] = struct.pack(">I", 1)
+    b[0x14:0x18] = b"\0\0\0\0"
+    fix_header_crc(b)
+    return bytes(b[:hs + fs])
+
+
+def header_form_streams(hca_encode, wav):
+    """Streams in every header form clHCA_DecodeHeader takes besides the encoder's own (hca.cpp:710-830): the v1.x `dec`
+    chunk (stereo_type 0 and != 0), explicit `ath` 0 / 1, `vbr` (never acceptable: it needs frame_size 0), `rva`, `comm`.
+    q2 (Middle) streams carry stereo bands and no HFR, so a `dec` chunk can describe them exactly.
+    hca_encode(wav_bytes, quality) and wav(seed, n, ch, sr) are passed in (oracle or reference encoder, synth.wav)."""
+    q1 = hca_encode(wav(21, 5000, 2, 48000), 1)
+    q2 = hca_encode(wav(22, 7000, 2, 48000), 2)
+    m1 = hca_encode(wav(23, 4000, 1, 44100), 1)
+    base2 = q2[0x23]
+    return {
+        "v101_dec_mono_default_ath": forge_header(m1, version=0x0101, dec=dict(stereo_type=0), ath=None),
+        "v101_dec_st0": forge_header(q1, version=0x0101, dec=dict(stereo_type=0), ath=None),
+        "v102_dec_st1_ath0_rva_comm": forge_header(q2, version=0x0102, dec=dict(stereo_type=1, base=base2), ath=0, rva=0.75, comm=b"made by forge"),
+        "v103_dec_st1_ath1_loop": forge_header(q2, version=0x0103, dec=dict(stereo_type=2, base=base2), ath=1, loop=(1, 5, 10, 20)),
+        "v102_dec_st0_on_joint_frames": forge_header(q2, version=0x0102, dec=dict(stereo_type=0), ath=0),
+        "v200_comp_ath1_rva": forge_header(q1, version=0x0200, ath=1, rva=2.0),
+        "v300_comp_ath0_comm_nopad": forge_header(q1, version=0x0300, ath=0, comm=b"x" * 40, pad=False),
+        "v200_vbr_with_frame_size": forge_header(q1, version=0x0200, vbr=(0x100, 2)),
+        "v200_vbr_frame_size_0": forge_header(q1, version=0x0200, vbr=(0x100, 2), frame_size=0),
+        "v101_dec_vbr_bad_max": forge_header(q1, version=0x0101, dec=dict(stereo_type=0), vbr=(8, 0), frame_size=0),
+        "v200_ath2": forge_header(q1, version=0x0200, ath=2),
+        "v101_dec_ath_only_44_bytes": forge_header(m1, version=0x0101, dec=dict(stereo_type=0), ath=1, ciph=None, pad=False),
+    }

@@ -1,0 +1,154 @@
+"""Host-side header logic of the product (pycricodecs_amd/csrc/cri_host.cpp) driven on the CPU through a test-only shim
+(tests/shim/host_shim.cpp, plain g++): the planner that calls it in the library needs a device to build a job.
+Covers the round-1 advisor findings (a RIFF chunk length that wraps, header walks that stay inside the header) and a
+mutation fuzz of the HCA header walk against the oracle's restatement."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import hca_forge
+import oracle_lib as O
+from pycricodecs_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    src = os.path.join(ROOT, "tests", "shim", "host_shim.cpp")
+    host = os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_host.cpp")
+    out = os.path.join(ROOT, "tests", "shim", "libhost_shim.so")
+    deps = [src, host, os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_host.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", src, host, "-o", out], check=True)
+    L = C.CDLL(out)
+    L.shim_wav_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    L.shim_hca_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.shim_hca_crypt_header.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.shim_adx_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    return L
+
+
+def wav_parse(L, b):
+    out = (C.c_uint32 * 10)()
+    return L.shim_wav_parse(b, len(b), out), list(out)
+
+
+@pytest.mark.timeout(30)
+def test_wav_chunk_length_that_wraps_terminates(shim):
+    """A chunk length of 0xFFFFFFF8 makes the reference's 32-bit `size = len + 8` zero: neither cursor advances
+    (pcm.cpp:295-296, 322).  The product (and the oracle) reject every wrapped length with the header error."""
+    w = bytearray(synth.wav(1, 64, 2, 48000))
+    junk = bytearray(b"JUNK" + struct.pack("<I", 0xFFFFFFF8) + bytes(8))
+    crafted = bytes(w[:12]) + bytes(junk) + bytes(w[12:])
+    crafted = crafted[:4] + struct.pack("<I", len(crafted) - 8) + crafted[8:]
+    for wrap in (0xFFFFFFF8, 0xFFFFFFF9, 0xFFFFFFFF):
+        c = bytearray(crafted)
+        c[16:20] = struct.pack("<I", wrap)
+        rc, _ = wav_parse(shim, bytes(c))
+        assert rc == -107
+        with pytest.raises(O.OracleError) as e:
+            O.adx_encode(bytes(c))
+        assert e.value.code == -107
+    # a well-formed unknown chunk in the same place is skipped
+    c = bytearray(crafted)
+    c[16:20] = struct.pack("<I", 8)
+    rc, f = wav_parse(shim, bytes(c))
+    assert rc == 0 and f[0] == 2 and f[6] == 64 * 4
+    assert O.adx_encode(bytes(c)) == O.adx_encode(bytes(w))
+
+
+FIELDS = ["version", "header_size", "channels", "rate", "frame_count", "delay", "padding", "frame_size", "min_res", "max_res",
+          "track_count", "channel_config", "stereo_type", "total_bands", "base_bands", "stereo_bands", "bands_per_hfr_group",
+          "ms_stereo", "ath_type", "loop_start_frame", "loop_end_frame", "loop_start_delay", "loop_end_padding", "loop_flag",
+          "ciph_type", "comment_len", "hfr_group_count"]
+
+
+def parse_header(L, b, size_arg=None):
+    out = (C.c_uint32 * 32)()
+    hs = int.from_bytes(b[6:8], "big") if size_arg is None else size_arg
+    rc = L.shim_hca_parse_header(b, len(b), hs, out)
+    return rc, dict(zip(FIELDS, list(out)))
+
+
+def test_v1_header_forms_parse(shim):
+    """dec / vbr / ath / rva / comm chunk forms (hca.cpp:710-830) through the product's header walk."""
+    base = O.hca_encode(synth.wav(3, 3000, 2, 48000), 1)
+    h = hca_forge.forge_header(base, version=0x0101, dec=dict(stereo_type=0), ath=None)
+    rc, f = parse_header(shim, h)
+    assert rc == 0 and f["ath_type"] == 1 and f["bands_per_hfr_group"] == 0 and f["stereo_bands"] == 0 and f["total_bands"] == f["base_bands"]
+    h = hca_forge.forge_header(base, version=0x0102, dec=dict(stereo_type=1, base=60), ath=0, rva=1.5, comm=b"hello world")
+    rc, f = parse_header(shim, h)
+    assert rc == 0 and f["ath_type"] == 0 and f["stereo_type"] == 1 and f["base_bands"] == 60 and f["stereo_bands"] == f["total_bands"] - 60
+    assert f["comment_len"] == 11
+    h = hca_forge.forge_header(base, version=0x0200, vbr=(0x100, 3))
+    assert parse_header(shim, h)[0] == -201                     # vbr needs frame_size == 0 (hca.cpp:738-739), and frame_size 0 is rejected later
+    h = hca_forge.forge_header(base, version=0x0200, ath=2)
+    assert parse_header(shim, h)[0] == -201                     # unknown ATH type (hca.cpp:451-485)
+
+
+def test_crypt_header_stays_inside_the_header(shim):
+    """a v1.1 header HCA+fmt+dec+ath+crc (44 bytes).  The `ath` chunk does not shrink `size` (hca.cpp:3203-3206), so
+    the later chunk tests still pass their size check at the very end of the header; every magic compare and every write
+    must nevertheless stay inside it."""
+    base = O.hca_encode(synth.wav(3, 3000, 2, 48000), 1)
+    h = hca_forge.forge_header(base, version=0x0101, dec=dict(stereo_type=0), ath=1, ciph=None, pad=False)
+    hs = int.from_bytes(h[6:8], "big")
+    assert hs == 44
+    for tail in (b"ciph\x00\x38\x00\x00", b"\xe3\xe9\xf0\xe8\x00\x38", b"comm\x05abcde", b"rva\x00\x3f\x80\x00\x00", b"pad\x00"):
+        guard = tail + bytes(64)
+        buf = C.create_string_buffer(h[:hs] + guard, hs + len(guard))
+        shim.shim_hca_crypt_header(buf, hs, 1, 56)
+        assert buf.raw[hs:] == guard, tail                      # nothing outside the header was touched
+        got = buf.raw[:hs]
+        assert got[:3] == bytes(x ^ 0x80 for x in h[:3]) and O.crc16(got) == 0
+        # and it agrees with the oracle's walk on the same bytes (one-frame stream so that the oracle's crypt accepts it)
+    one = hca_forge.one_frame_stream(h)
+    enc = O.hca_crypt(one, 1, 56, 0x1234)
+    buf = C.create_string_buffer(one[:hs], hs)
+    shim.shim_hca_crypt_header(buf, hs, 1, 56)
+    assert buf.raw[:hs] == enc[:hs]
+
+
+def test_header_walk_mutation_fuzz_vs_oracle(shim):
+    """Random edits of valid headers of every chunk form: the product's walk and the oracle's accept / reject alike, and
+    (through HcaCrypt on a one-frame stream) produce the same rewritten header."""
+    rng = np.random.default_rng(5)
+    base = O.hca_encode(synth.wav(3, 3000, 2, 48000), 1)
+    forms = [hca_forge.forge_header(base, version=0x0200),
+             hca_forge.forge_header(base, version=0x0101, dec=dict(stereo_type=0), ath=None),
+             hca_forge.forge_header(base, version=0x0102, dec=dict(stereo_type=1, base=60), ath=1, rva=0.5, comm=b"c" * 7),
+             hca_forge.forge_header(base, version=0x0103, dec=dict(stereo_type=0), ath=0, loop=(0, 1, 0, 0), comm=b""),
+             hca_forge.forge_header(base, version=0x0300, ath=0, rva=2.0, ciph=56)]
+    agree = accepted = 0
+    for it in range(3000):
+        h = bytearray(hca_forge.one_frame_stream(forms[it % len(forms)]))
+        hs = int.from_bytes(h[6:8], "big")
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(4, hs - 2))
+            h[k] = int(rng.integers(0, 256)) if rng.random() < 0.5 else h[k] ^ (1 << int(rng.integers(0, 8)))
+        if rng.random() < 0.8:
+            hs2 = int.from_bytes(h[6:8], "big")
+            if 8 <= hs2 <= len(h):
+                h[hs2 - 2:hs2] = struct.pack(">H", hca_forge.crc16(bytes(h[:hs2 - 2])))
+        b = bytes(h)
+        rc, f = parse_header(shim, b)
+        try:
+            enc = O.hca_crypt(b, 1, 1, 0)
+            ok = True
+        except O.OracleError:
+            ok = False
+        frames_fit = rc == 0 and f["header_size"] + f["frame_count"] * f["frame_size"] <= len(b)
+        assert ok == frames_fit, (it, rc, f)
+        agree += 1
+        if ok:
+            accepted += 1
+            hsx = f["header_size"]
+            buf = C.create_string_buffer(b[:hsx], hsx)
+            shim.shim_hca_crypt_header(buf, hsx, 1, 1)
+            assert buf.raw[:hsx] == enc[:hsx], it
+    assert accepted > 300
