@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the ADX / HCA hot path on MI355X.
+"""bench.py -- benchmark of the ADX / HCA hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--workload hca_decode|adx_roundtrip]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hca_decode|hca_encode|adx_roundtrip|awb_mixed] ...
 
-Default workload = BASELINE.json configs[2], the one north_star quotes its target on: HCA v2.0 decode of 10 000
-encrypted (key 0xCF222F1FE0748978) 48 kHz stereo streams of 10 s each (469 frames x 682 B per stream), inputs
-resident in HBM before the timed region.  A "step" is one pass of the decode path over the whole batch.  With
-N > 1 every rank decodes its own 10 000 streams (file-sharded, no data-path collective: weak scaling).
+Workloads = BASELINE.json configs (a "step" is one pass of the path over the whole batch, inputs resident in HBM):
+  hca_decode     configs[2] (default, the one north_star quotes its target on): HCA v2.0 decode of 10 000 encrypted
+                 (key 0xCF222F1FE0748978) 48 kHz stereo streams x 10 s (469 frames x 682 B each)
+  hca_encode     configs[3]: HCA encode (v2.0, quality High) of 10 000 x 30 s 48 kHz stereo WAVs (1407 frames each)
+  adx_roundtrip  configs[1]: ADX encode + decode of 1 000 x 10 s 48 kHz stereo WAVs (bs 18 / bd 4), the decode job reading the
+                 encode job's output buffer
+  awb_mixed      configs[4]: AFS2 bank(s) of short ADX + HCA clips through the AWB front door, decoded PCM gathered on rank 0
 
-The 10 000 streams are a tiling of `--unique` (default 64) distinct seeded streams produced by the CPU oracle
-(encode + encrypt); every copy occupies its own HBM, so the traffic is real.  Says so in "data".
+--gpus N > 1: one process per GPU.  Without torchrun's environment this script launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (rendezvous on 127.0.0.1); under torchrun it reads RANK / WORLD_SIZE /
+LOCAL_RANK.  Every rank works on its own batch (file-sharded, weak scaling, no data-path collective; awb_mixed adds the
+RCCL gather of the PCM to rank 0 inside the timed region), timing is barrier + synchronize on both sides, MAX over ranks.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the launch stream
-inside the timed steps; `cpu_baseline` is the real reference (oracle/_ref/criref, single thread) when that binary
-travelled with the repo, else the C restatement ("port").
+Every output of every timed batch is verified after the timed region, not item 0: each item is compared on the device, byte
+for byte, with the CPU oracle's result for the unique input it is a copy of (so offsets past 4 GiB and 16 GiB are covered).
+
+The batches are tilings of `--unique` distinct seeded inputs produced with the CPU oracle; every copy occupies its own HBM.
+--data picks the signal family: tonal (sines + noise floor: every HCA frame qualifies for the int8 record form), wide
+(full-scale noise / square / clicks: wide bands, int16 records) or mixed (alternating).  "data" in the line says which, and
+the record-form census of the run is in config.record_forms.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the launch stream inside
+the timed steps, plus the end-to-end figure (algorithmic bytes / step time); `cpu_baseline` is the real reference
+(oracle/_ref/criref, single thread) when that binary travelled with the repo, else the C restatement ("port").
 """
 import argparse
+import glob
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -29,6 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 KEY = 0xCF222F1FE0748978
 HBM_PEAK_GBPS = 8000.0
+QNAME = {0: "Highest", 1: "High", 2: "Middle", 3: "Low", 4: "Lowest"}
 
 
 def log(*a):
@@ -36,124 +52,314 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_hca_streams(unique, seconds, rank, quality=1):
-    import oracle_lib as O
+# ------------------------------------------------------------------------------------------------ synthetic inputs
+def family_pcm(seed, n, ch, sr, family):
+    """(n, ch) int16.  tonal = pycricodecs_amd.synth; wide = full-scale material, four kinds by seed:
+    white noise, +-full-scale square noise, sparse clicks on a noise floor, loud detuned tones + noise."""
+    import numpy as np
     from pycricodecs_amd import synth
-    out = []
-    for u in range(unique):
-        w = synth.wav(1000 * rank + u, int(48000 * seconds) // 32 * 32, 2, 48000)
-        out.append(O.hca_crypt(O.hca_encode(w, quality), 1, 56, KEY))
-    return out
+    if family == "tonal" or (family == "mixed" and seed % 2 == 0):
+        return synth.pcm16(seed, n, ch, sr)
+    rng = np.random.default_rng(10_000 + seed)
+    kind = (seed // (2 if family == "mixed" else 1)) % 4
+    if kind == 0:
+        x = rng.integers(-32768, 32768, (n, ch))
+    elif kind == 1:
+        x = rng.integers(0, 2, (n, ch)) * 65535 - 32768
+    elif kind == 2:
+        x = rng.normal(0, 300, (n, ch))
+        idx = rng.integers(0, n, max(1, n // 40))
+        x[idx] = rng.integers(-32768, 32768, (len(idx), ch))
+    else:
+        t = np.arange(n)[:, None] / sr
+        x = sum(9000.0 * np.sin(2 * np.pi * f * t + c) for c, f in enumerate(rng.uniform(200, 18000, 6))) + rng.normal(0, 4000, (n, ch))
+    # quadratic fade-in over 512 samples, as in synth.pcm16: an ADX file whose FIRST block needs a scale >= 0x100 is one the
+    # reference's own decoder rejects (its 7-byte "(c)CRI" compare runs into the scale word, adx.cpp:345-348)
+    m = min(512, n)
+    x = x.astype(np.float64)
+    x[:m] *= ((np.arange(m) / 512.0) ** 2)[:, None]
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
 
 
-def cpu_baseline_hca_decode(stream, seconds=10.0):
-    """Single-thread CPU decode of one of the workload's streams, repeated for ~`seconds`."""
-    frames = int.from_bytes(stream[16:20], "big")
+def family_wav(seed, seconds, family, ch=2, sr=48000):
+    from pycricodecs_amd import synth
+    return synth.wav_bytes(family_pcm(seed, int(sr * seconds) // 32 * 32, ch, sr, family), sr)
+
+
+def tile(uniq, n):
+    return [uniq[i % len(uniq)] for i in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def criref():
     tool = os.path.join(ROOT, "oracle", "_ref", "criref")
-    if os.path.exists(tool) and os.access(tool, os.X_OK):
-        with tempfile.NamedTemporaryFile(suffix=".hca", delete=False) as f:
-            f.write(stream)
-            path = f.name
+    return tool if os.path.exists(tool) and os.access(tool, os.X_OK) else None
+
+
+def criref_bench(what, data, seconds, key=0):
+    """(repetitions, elapsed seconds) of the real reference on one file, single thread."""
+    with tempfile.NamedTemporaryFile(delete=False) as f:
+        f.write(data)
+        path = f.name
+    try:
+        p = subprocess.run([criref(), "bench", what, path, str(seconds), hex(key)], capture_output=True, text=True, timeout=seconds * 6 + 120)
+        reps, secs = p.stdout.split()
+        return int(reps), float(secs)
+    finally:
+        os.unlink(path)
+
+
+def timed_loop(fn, seconds):
+    t0, reps = time.time(), 0
+    while time.time() - t0 < seconds or reps == 0:
+        fn()
+        reps += 1
+    return reps, time.time() - t0
+
+
+def cpu_baseline(kind, sample, frames, seconds=10.0):
+    """kind: hcadec (sample = encrypted stream), hcaenc (sample = WAV), adxrt (sample = WAV: encode, then decode of the result).
+    `frames` = the metric's units one repetition processes."""
+    import oracle_lib as O
+    what = {"hcadec": "HCA decode of one stream of this workload", "hcaenc": "HCA encode (High) of one WAV of this workload",
+            "adxrt": "ADX encode + decode of one WAV of this workload"}[kind]
+    if criref():
         try:
-            p = subprocess.run([tool, "bench", "hcadec", path, str(seconds), hex(KEY)], capture_output=True, text=True, timeout=seconds * 6 + 60)
-            reps, secs = p.stdout.split()
-            return {"value": round(int(reps) * frames / float(secs), 1), "unit": "frames/s", "cores": 1, "kind": "reference",
-                    "sample": "%d x decode of one 10 s stream (%d frames) of this workload, reference C++ built from /root/reference (oracle/_ref/criref), single thread" % (int(reps), frames)}
+            if kind == "adxrt":
+                r1, s1 = criref_bench("adxenc", sample, seconds / 2)
+                r2, s2 = criref_bench("adxdec", O.adx_encode(sample), seconds / 2)
+                value, reps = frames / (s1 / r1 + s2 / r2), r1 + r2
+            else:
+                reps, secs = criref_bench(kind, sample, seconds, KEY if kind == "hcadec" else 0)
+                value = reps * frames / secs
+            return {"value": round(value, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+                    "sample": "%d x %s (%d frames each), reference C++ built from /root/reference (oracle/_ref/criref), single thread" % (reps, what, frames)}
         except Exception as e:  # fall through to the port
             log("criref bench failed:", e)
-        finally:
-            os.unlink(path)
-    import oracle_lib as O
-    t0 = time.time()
-    reps = 0
-    while time.time() - t0 < seconds:
-        O.hca_decode(stream, KEY)
-        reps += 1
-    secs = time.time() - t0
+    if kind == "hcadec":
+        reps, secs = timed_loop(lambda: O.hca_decode(sample, KEY), seconds)
+    elif kind == "hcaenc":
+        reps, secs = timed_loop(lambda: O.hca_encode(sample, 1), seconds)
+    else:
+        reps, secs = timed_loop(lambda: O.adx_decode(O.adx_encode(sample)), seconds)
     return {"value": round(reps * frames / secs, 1), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d x decode of one 10 s stream (%d frames), oracle/cri_oracle.c, single thread" % (reps, frames)}
+            "sample": "%d x %s (%d frames each), oracle/cri_oracle.c, single thread" % (reps, what, frames)}
 
 
-def measure(job, dev, steps=3, warmup=1):
+# ------------------------------------------------------------------------------------------------ device helpers
+class Dist:
+    """torch.distributed plumbing of one rank (world 1: no process group)."""
+    def __init__(self):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+        # Launcher smoke test on a box with fewer GPUs than ranks (CRICODECS_BENCH_SHARE_GPU=1): ranks share device 0 and
+        # rendezvous over gloo, since RCCL refuses two ranks on one device.  Never the measured configuration.
+        self.shared = os.environ.get("CRICODECS_BENCH_SHARE_GPU") == "1"
+        dev_index = self.local % torch.cuda.device_count() if self.shared else self.local
+        assert dev_index < torch.cuda.device_count(), "rank %d has no GPU: %d visible" % (self.local, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        self.dev = "cuda:%d" % dev_index
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.shared:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(self.dev))
+
+    def barrier(self):
+        import torch
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce(self, values, op="max"):
+        """list of floats -> list reduced over ranks"""
+        if self.world == 1:
+            return list(values)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if self.shared else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def verify_items(d_out, offsets, which, refs, what):
+    """Every output item i equals refs[which[i]] byte for byte (compared on the device).  Returns a summary dict; raises on the
+    first batch of mismatches."""
     import torch
-    bufs = job.alloc(dev)
-    job.enable_events(True)
+    dev = d_out.device
+    d_refs = [torch.frombuffer(bytearray(r), dtype=torch.uint8).to(dev) for r in refs]
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    total = 0
+    for i, u in enumerate(which):
+        o, n = int(offsets[i]), d_refs[u].numel()
+        bad += (d_out[o:o + n] != d_refs[u]).any()
+        total += n
+    nbad = int(bad.item())
+    if nbad:
+        first = next(i for i, u in enumerate(which) if not torch.equal(d_out[int(offsets[i]):int(offsets[i]) + d_refs[u].numel()], d_refs[u]))
+        raise AssertionError("%s: %d of %d outputs differ from the oracle (first: item %d at offset %d)" % (what, nbad, len(which), first, int(offsets[first])))
+    return {"items": len(which), "bytes": total, "max_offset": int(offsets[len(which) - 1]) if len(which) else 0,
+            "how": "every item compared on the device, byte for byte, with the CPU oracle's output for its unique input"}
+
+
+def run_timed(D, step, steps, warmup, jobs):
+    """warmup, barrier, `steps` timed steps (HIP-event read-out included), barrier; returns (seconds per step MAX over ranks,
+    {kernel class: ms per step})."""
     for _ in range(warmup):
-        job.run(*bufs)
-    torch.cuda.synchronize()
+        step()
+    D.barrier()
     kms = {}
     t0 = time.perf_counter()
     for _ in range(steps):
-        job.run(*bufs)
-        for k, v in job.event_ms().items():
-            kms[k] = kms.get(k, 0.0) + v
-    torch.cuda.synchronize()
+        step()
+        for job in jobs:
+            for k, v in job.event_ms().items():                # waits only for this step's own kernels; part of the measured time
+                kms[k] = kms.get(k, 0.0) + v
+    D.barrier()
     dt = (time.perf_counter() - t0) / steps
-    assert int((bufs[3] != 0).sum().item()) == 0
-    dom = max(kms, key=kms.get)
-    return bufs, {"ms_per_step": round(dt * 1e3, 3), "units_per_s": round(job.units / dt, 1), "units2_per_s": round(job.units2 / dt, 1),
-                  "kernel_ms": {k: round(v / steps, 3) for k, v in kms.items()},
-                  "achieved_GBps": round(job.algorithmic_bytes / (kms[dom] / steps * 1e-3) / 1e9, 2)}
+    dt = D.reduce([dt], "max")[0]
+    return dt, {k: v / steps for k, v in kms.items()}
 
 
-def secondary_measurements(args, dev, rank):
-    """HCA encode and ADX encode/decode on `--secondary-streams` 10 s stereo WAVs (tiled from the unique set)."""
+def roofline_of(alg_bytes, alg_bytes_path, kernel_ms, dt, traffic=None, extra=None):
+    """alg_bytes: algorithmic bytes the dominant kernel's launches cover; alg_bytes_path: of the whole step."""
+    dom = max(kernel_ms, key=kernel_ms.get)
+    achieved = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    e2e = alg_bytes_path / dt / 1e9
+    r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+         "end_to_end": {"achieved": round(e2e, 2), "frac": round(e2e / HBM_PEAK_GBPS, 5),
+                        "what": "algorithmic bytes of the whole path / wall time of a step (all kernels of the path, launch gaps included)"},
+         "algorithmic_bytes_per_launch": int(alg_bytes),
+         "kernel_ms_per_step": {k: round(v, 3) for k, v in kernel_ms.items()}}
+    if traffic:
+        r.update(traffic)
+    if extra:
+        r.update(extra)
+    return r
+
+
+def committed_traffic(units, dom):
+    """HBM bytes per step from the committed rocprofv3 counter passes of this same command (PMC counters cannot be collected from
+    inside the process): the newest profiles/r*_traffic.json, path total and dominant kernel."""
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not tfiles:
+        return None
+    with open(tfiles[-1]) as fh:
+        tj = json.load(fh)
+    ks = tj.get("kernels", {})
+    total = tj.get("total_hbm_bytes_per_frame") or sum(k["hbm_bytes_per_frame"] for k in ks.values())
+    out = {"traffic": int(round(total * units)),
+           "traffic_source": "profiles/%s: %.0f B/frame over the path's kernels (FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate --pmc passes) x %d frames"
+                             % (os.path.basename(tfiles[-1]), total, units)}
+    key = dom if dom in ks else next((k for k in ks if k.startswith(dom) or dom.startswith(k)), None)
+    if key:
+        out["traffic_dominant_kernel"] = int(round(ks[key]["hbm_bytes_per_frame"] * units))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def make_hca_streams(unique, seconds, rank, quality, family):
+    import oracle_lib as O
+    return [O.hca_crypt(O.hca_encode(family_wav(1000 * rank + u, seconds, family), quality), 1, 56, KEY) for u in range(unique)]
+
+
+def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True):
+    """Decode of `streams` copies of `unique` streams.  Returns a result dict (rank-local verification, rank-reduced timing)."""
     import torch
     import oracle_lib as O
-    from pycricodecs_amd import synth
     from pycricodecs_amd.batch import Job
-    n = args.secondary_streams
-    uniq = [synth.wav(5000 + 1000 * rank + u, int(48000 * args.seconds) // 32 * 32, 2, 48000) for u in range(min(args.unique, 16))]
-    wavs = [uniq[i % len(uniq)] for i in range(n)]
-    res = {}
-    job = Job.hca_encode(wavs, quality=1)
-    bufs, r = measure(job, dev)
-    blob = bytes(bufs[1][:int(job.output_offsets[1])].cpu().numpy())
-    ref = O.hca_encode(wavs[0], 1)
-    assert blob[:len(ref)] == ref, "GPU HCA encode differs from the oracle"
-    r.update(workload="HCA encode (quality High), %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), unit="frames/s", frames=job.units)
-    res["hca_encode"] = r
+    uniq = make_hca_streams(unique, seconds, D.rank, quality, family)
+    items = tile(uniq, streams)
+    job = Job.hca_decode(items, keys=[KEY] * len(items))
+    assert not job.host_status.any(), "synthetic inputs rejected at the header stage"
+    bufs = job.alloc(D.dev)
+    job.enable_events(True)
+    dt, kms = run_timed(D, lambda: job.run(*bufs), steps, warmup, [job])
+    assert int((bufs[3] != 0).sum().item()) == 0, "items failed on the device"
+    res = {"job": job, "dt": dt, "kernel_ms": kms, "units": job.units, "alg_bytes": job.algorithmic_bytes,
+           "frame_size": int.from_bytes(uniq[0][0x1C:0x1E], "big"), "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
+           "census": job.record_census(bufs[2]), "sample": uniq[0],
+           "bytes": {"in": job.input_bytes, "out": job.output_bytes, "scratch": job.scratch_bytes}}
+    if verify:
+        refs = [O.hca_decode(h, KEY) for h in uniq]
+        res["verified"] = verify_items(bufs[1], job.output_offsets, [i % len(uniq) for i in range(streams)], refs, "HCA decode")
     del bufs
     torch.cuda.empty_cache()
-    job = Job.adx_encode(wavs)
-    bufs, r = measure(job, dev)
-    adx0 = bytes(bufs[1][:int(job.output_offsets[1])].cpu().numpy())
-    ref = O.adx_encode(wavs[0])
-    assert adx0[:len(ref)] == ref, "GPU ADX encode differs from the oracle"
-    r.update(workload="ADX encode bs18/bd4/mode3/v4, %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), unit="frames/s (units2 = blocks/s)",
-             chains=2 * n, blocks=job.units2)
-    res["adx_encode"] = r
+    return res
+
+
+def census_text(c):
+    if not c["frames"]:
+        return "n/a"
+    return "%d of %d frames crossed scratch as int8 records, %d as int16" % (c["narrow"], c["frames"], c["frames"] - c["narrow"])
+
+
+def hca_encode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True):
+    import torch
+    import oracle_lib as O
+    from pycricodecs_amd.batch import Job
+    uniq = [family_wav(5000 + 1000 * D.rank + u, seconds, family) for u in range(unique)]
+    job = Job.hca_encode(tile(uniq, streams), quality=quality)
+    assert not job.host_status.any()
+    bufs = job.alloc(D.dev)
+    job.enable_events(True)
+    dt, kms = run_timed(D, lambda: job.run(*bufs), steps, warmup, [job])
+    assert int((bufs[3] != 0).sum().item()) == 0
+    head = bytes(bufs[1][:96].cpu().numpy())                   # the first item's HCA header
+    res = {"job": job, "dt": dt, "kernel_ms": kms, "units": job.units, "alg_bytes": job.algorithmic_bytes, "sample": uniq[0],
+           "frames_per_stream": int.from_bytes(head[16:20], "big"), "frame_size": int.from_bytes(head[0x1C:0x1E], "big"),
+           "bytes": {"in": job.input_bytes, "out": job.output_bytes, "scratch": job.scratch_bytes}}
+    if verify:
+        refs = [O.hca_encode(w, quality) for w in uniq]
+        res["verified"] = verify_items(bufs[1], job.output_offsets, [i % len(uniq) for i in range(streams)], refs, "HCA encode")
     del bufs
     torch.cuda.empty_cache()
+    return res
+
+
+def adx_roundtrip_run(D, streams, unique, seconds, family, steps, warmup, verify=True):
+    """ADX encode of the WAVs, then decode of the encoder's output where it lies (the decode job's input buffer IS the encode
+    job's output buffer).  Both results are checked against the oracle for every file."""
+    import torch
+    import oracle_lib as O
+    from pycricodecs_amd.batch import Job
+    uniq = [family_wav(3000 + 1000 * D.rank + u, seconds, family) for u in range(unique)]
     adx_u = [O.adx_encode(w) for w in uniq]
-    job = Job.adx_decode([adx_u[i % len(adx_u)] for i in range(n)])
-    bufs, r = measure(job, dev)
-    wav0 = bytes(bufs[1][:int(job.output_offsets[1])].cpu().numpy())
-    ref = O.adx_decode(adx_u[0])
-    assert wav0[:len(ref)] == ref, "GPU ADX decode differs from the oracle"
-    r.update(workload="ADX decode of the same files", unit="frames/s (units2 = blocks/s)", chains=2 * n, blocks=job.units2)
-    res["adx_decode"] = r
-    del bufs
+    which = [i % len(uniq) for i in range(streams)]
+    enc = Job.adx_encode(tile(uniq, streams))
+    dec = Job.adx_decode(tile(adx_u, streams), offsets=enc.output_offsets)       # planned from the oracle's files: same headers, same layout
+    assert not enc.host_status.any() and not dec.host_status.any()
+    e_in, e_out, e_scr, e_st = enc.alloc(D.dev)
+    _, d_out, d_scr, d_st = dec.alloc(D.dev, upload=False)
+    enc.enable_events(True); dec.enable_events(True)
+
+    def step():
+        enc.run(e_in, e_out, e_scr, e_st)
+        dec.run(e_out, d_out, d_scr, d_st)
+    dt, kms = run_timed(D, step, steps, warmup, [enc, dec])
+    assert int((e_st != 0).sum().item()) == 0 and int((d_st != 0).sum().item()) == 0
+    res = {"dt": dt, "kernel_ms": kms, "units": enc.units + dec.units, "units2": enc.units2 + dec.units2,
+           "alg_bytes": enc.algorithmic_bytes + dec.algorithmic_bytes, "alg_bytes_by_kernel": {enc.dominant_kernel: enc.algorithmic_bytes, dec.dominant_kernel: dec.algorithmic_bytes},
+           "sample": uniq[0], "frames_per_stream": enc.units // streams,
+           "bytes": {"in": enc.input_bytes, "adx": enc.output_bytes, "out": dec.output_bytes}}
+    if verify:
+        v1 = verify_items(e_out, enc.output_offsets, which, adx_u, "ADX encode")
+        v2 = verify_items(d_out, dec.output_offsets, which, [O.adx_decode(a) for a in adx_u], "ADX decode of the encoder's output")
+        res["verified"] = {"items": v1["items"] + v2["items"], "bytes": v1["bytes"] + v2["bytes"], "max_offset": max(v1["max_offset"], v2["max_offset"]),
+                           "how": "every ADX file and every decoded WAV compared on the device, byte for byte, with the CPU oracle's (bit-exact check of configs[1])"}
+    del e_in, e_out, e_scr, d_out, d_scr
     torch.cuda.empty_cache()
-    # USM audio layer: the ADX files as masked @SFA chunk streams, then the demux of a container made of them (HBM-bound copies)
-    from pycricodecs_amd import usm
-    adx_items = [adx_u[i % len(adx_u)] for i in range(n)]
-    # (a container carries at most 256 audio channels: the chunk header's channel number is one byte)
-    key = 0x0123456789ABCDEF
-    job = Job.sfa_pack(adx_items[:250], usm.CODEC_ADX, key, True)
-    bufs, r = measure(job, dev)
-    packed = bufs[1].cpu().numpy().tobytes()
-    r.update(workload="ADX files -> masked @SFA chunk streams (usm.py:584-657), %d x %.0f s" % (len(adx_items[:250]), args.seconds), unit="chunks/s", chunks=job.units)
-    res["sfa_pack"] = r
-    del bufs
-    torch.cuda.empty_cache()
-    crid = b"CRID" + (0x18).to_bytes(4, "big") + bytes([0, 0x18]) + bytes(22)      # an empty CRID chunk: only the signature is read here
-    job = Job.usm_audio_demux(crid + packed, key, True)
-    bufs, r = measure(job, dev)
-    first = bytes(bufs[1][:len(adx_items[0])].cpu().numpy())
-    assert first == adx_items[0], "USM demux does not give the ADX stream back"
-    r.update(workload="demux + AudioMask of that container (%d channels, %d chunks)" % (job.n, job.units), unit="chunks/s", chunks=job.units)
-    res["usm_demux"] = r
     return res
 
 
@@ -189,59 +395,127 @@ def build_awb_bank(n_total, rank, world, seed=77):
     return head.ljust(hs, b"\0") + b"".join(parts), uniq, order, subkey
 
 
-def awb_mixed_measurement(args, dev, rank, world=1, gather=False):
+def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True):
     """Decode of a mixed AFS2 bank through the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM.
-    With world > 1 every rank decodes its LPT share of awb_clips x world clips and (gather=True) the decoded PCM of all
+    With world > 1 every rank decodes its LPT share of clips x world clips and (gather=True) the decoded PCM of all
     ranks is collected on rank 0 inside the timed region -- the only collective-like step of the whole path."""
     import torch
-    import torch.distributed as dist
     import oracle_lib as O
     from pycricodecs_amd import shard
     from pycricodecs_amd.batch import Job
-    bank, uniq, order, subkey = build_awb_bank(args.awb_clips * world, rank, world)
+    world = D.world
+    bank, uniq, order, subkey = build_awb_bank(clips * world, D.rank, world)
     n = len(order)
     hj, aj = Job.awb_decode(bank, KEY)
-    d_in, ho, hscr, hst = hj.alloc(dev)
-    _, ao, ascr, ast = aj.alloc(dev, upload=False)
+    d_in, ho, hscr, hst = hj.alloc(D.dev)
+    _, ao, ascr, ast = aj.alloc(D.dev, upload=False)
+    gathered = {}
 
     def step():
         hj.run(d_in, ho, hscr, hst); aj.run(d_in, ao, ascr, ast)
         if gather and world > 1:
-            shard.gather_bytes_to_root(ho[:hj.output_bytes]); shard.gather_bytes_to_root(ao[:aj.output_bytes])
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-    for _ in range(max(args.warmup, 1)):
-        step()
-    barrier()
-    steps = max(args.steps, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    barrier()
-    dt = (time.perf_counter() - t0) / steps
-    hca_units, adx_units = float(hj.units), float(aj.units)
-    if world > 1:
-        t = torch.tensor([dt, 0.0, 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
-        u = torch.tensor([hca_units, adx_units, float(n)], dtype=torch.float64, device=dev)
-        dist.all_reduce(u)
-        dt, hca_units, adx_units, n_all = float(t[0].item()), float(u[0].item()), float(u[1].item()), int(u[2].item())
-    else:
-        n_all = n
+            gathered["hca"] = shard.gather_bytes_to_root(ho[:hj.output_bytes]); gathered["adx"] = shard.gather_bytes_to_root(ao[:aj.output_bytes])
+    dt, _ = run_timed(D, step, max(steps, 1), max(warmup, 1), [])
+    hca_units, adx_units, n_all = D.reduce([float(hj.units), float(aj.units), float(n)], "sum")
     assert int((hst < 0).sum().item()) == 0 and int((ast < 0).sum().item()) == 0
-    k_h = next(i for i in range(n) if uniq[order[i]][0] == "hca"); k_a = next(i for i in range(n) if uniq[order[i]][0] == "adx")
-    ref = O.hca_decode(uniq[order[k_h]][1], KEY, subkey)
-    assert bytes(ho[int(hj.output_offsets[k_h]):int(hj.output_offsets[k_h]) + len(ref)].cpu().numpy()) == ref, "AWB HCA item differs from the oracle"
-    ref = O.adx_decode(uniq[order[k_a]][1])
-    assert bytes(ao[int(aj.output_offsets[k_a]):int(aj.output_offsets[k_a]) + len(ref)].cpu().numpy()) == ref, "AWB ADX item differs from the oracle"
-    return {"workload": "AFS2 bank(s) of %d clips%s (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV%s"
-                        % (n_all, " over %d GPUs, LPT-sharded" % world if world > 1 else "", ", PCM gathered on rank 0 (RCCL send/recv)" if gather and world > 1 else ""),
-            "bank_bytes_rank0": len(bank), "pcm_bytes_rank0": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
-            "hca_frames": int(hca_units), "adx_frames": int(adx_units), "frames_per_s": round((hca_units + adx_units) / dt, 1),
-            "clips_per_s": round(n_all / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)"}
+    res = {"workload": "AFS2 bank(s) of %d clips%s (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV%s"
+                       % (int(n_all), " over %d GPUs, LPT-sharded" % world if world > 1 else "", ", PCM gathered on rank 0 (RCCL send/recv)" if gather and world > 1 else ""),
+           "bank_bytes_rank0": len(bank), "pcm_bytes_rank0": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
+           "hca_frames": int(hca_units), "adx_frames": int(adx_units), "frames_per_s": round((hca_units + adx_units) / dt, 1),
+           "clips_per_s": round(n_all / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)"}
+    if verify:
+        refs = [O.hca_decode(b, KEY, subkey) if k == "hca" else O.adx_decode(b) for k, b in uniq]
+        hi = [i for i in range(n) if uniq[order[i]][0] == "hca"]
+        ai = [i for i in range(n) if uniq[order[i]][0] == "adx"]
+        v1 = verify_items(ho, [hj.output_offsets[i] for i in hi], [order[i] for i in hi], refs, "AWB HCA items")
+        v2 = verify_items(ao, [aj.output_offsets[i] for i in ai], [order[i] for i in ai], refs, "AWB ADX items")
+        res["verified"] = {"items": v1["items"] + v2["items"], "bytes": v1["bytes"] + v2["bytes"], "how": v1["how"]}
+        if gather and world > 1:                               # what arrived on the root: every rank's part, by byte sum and length
+            import torch.distributed as dist
+            sums = [None] * world
+            dist.all_gather_object(sums, [int(ho[:hj.output_bytes].sum(dtype=torch.int64).item()), int(ao[:aj.output_bytes].sum(dtype=torch.int64).item()),
+                                          int(hj.output_bytes), int(aj.output_bytes)])
+            if D.rank == 0:
+                for k, key in enumerate(("hca", "adx")):
+                    got, offs = gathered[key]
+                    assert offs[-1] == got.numel()
+                    for rr in range(world):
+                        part = got[offs[rr]:offs[rr + 1]]
+                        assert part.numel() == sums[rr][2 + k] and int(part.sum(dtype=torch.int64).item()) == sums[rr][k], "gathered PCM of rank %d differs" % rr
+                assert torch.equal(gathered["hca"][0][:hj.output_bytes], ho[:hj.output_bytes])
+                res["gathered_bytes_on_root"] = int(gathered["hca"][0].numel() + gathered["adx"][0].numel())
+    del d_in, ho, hscr, ao, ascr
+    torch.cuda.empty_cache()
+    return res
+
+
+def secondary_measurements(args, D):
+    """Other rows of the path on smaller batches (N = 1 only), every output verified: HCA decode of the other qualities and of
+    wide-band material (int16 records), HCA encode, ADX encode + decode, the USM @SFA layer, the mixed AWB bank."""
+    import torch
+    from pycricodecs_amd import usm
+    from pycricodecs_amd.batch import Job
+    import oracle_lib as O
+    n = args.secondary_streams
+    uq = min(args.unique, 16)
+    out = {}
+    for label, q, fam in (("hca_decode_wide_bands", 1, "wide"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_middle", 2, "tonal"),
+                          ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
+        r = hca_decode_run(D, n, uq, args.seconds, q, fam, 3, 1)
+        out[label] = {"workload": "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (n, args.seconds, QNAME[q], fam),
+                      "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
+                      "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "record_forms": census_text(r["census"]),
+                      "verified_items": r["verified"]["items"]}
+    r = hca_encode_run(D, n, uq, args.seconds, 1, "tonal", 3, 1)
+    out["hca_encode"] = {"workload": "HCA encode (quality High), %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), "frames_per_s": round(r["units"] / r["dt"], 1),
+                         "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"], "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()},
+                         "achieved_GBps": round(r["alg_bytes"] / (max(r["kernel_ms"].values()) * 1e-3) / 1e9, 2), "verified_items": r["verified"]["items"]}
+    r = adx_roundtrip_run(D, n, uq, args.seconds, "tonal", 3, 1)
+    out["adx_roundtrip"] = {"workload": "ADX encode + decode (bs18/bd4/mode3/v4), %d x %.0f s 48 kHz stereo WAVs, decode reads the encoder's output buffer" % (n, args.seconds),
+                            "frames_per_s": round(r["units"] / r["dt"], 1), "blocks_per_s": round(r["units2"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3),
+                            "chains": 2 * n, "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()},
+                            "achieved_GBps": {k: round(r["alg_bytes_by_kernel"][k] / (v * 1e-3) / 1e9, 2) for k, v in r["kernel_ms"].items() if k in r["alg_bytes_by_kernel"]},
+                            "verified_items": r["verified"]["items"]}
+    # USM audio layer: ADX files as masked @SFA chunk streams, then the demux of a container made of them (HBM-bound copies)
+    adx_u = [O.adx_encode(family_wav(3000 + u, args.seconds, "tonal")) for u in range(uq)]
+    adx_items = tile(adx_u, 250)                               # (a container carries at most 256 audio channels)
+    key = 0x0123456789ABCDEF
+    for label, mk in (("sfa_pack", lambda: Job.sfa_pack(adx_items, usm.CODEC_ADX, key, True)),):
+        job = mk()
+        bufs = job.alloc(D.dev)
+        job.enable_events(True)
+        dt, kms = run_timed(D, lambda: job.run(*bufs), 3, 1, [job])
+        packed = bufs[1].cpu().numpy().tobytes()
+        out[label] = {"workload": "ADX files -> masked @SFA chunk streams (usm.py:584-657), %d x %.0f s" % (len(adx_items), args.seconds),
+                      "chunks_per_s": round(job.units / dt, 1), "ms_per_step": round(dt * 1e3, 3), "chunks": job.units}
+        del bufs
+    torch.cuda.empty_cache()
+    crid = b"CRID" + (0x18).to_bytes(4, "big") + bytes([0, 0x18]) + bytes(22)      # an empty CRID chunk: only the signature is read here
+    job = Job.usm_audio_demux(crid + packed, key, True)
+    bufs = job.alloc(D.dev)
+    job.enable_events(True)
+    dt, kms = run_timed(D, lambda: job.run(*bufs), 3, 1, [job])
+    v = verify_items(bufs[1], job.output_offsets, [i % len(adx_u) for i in range(job.n)], adx_u, "USM demux")
+    out["usm_demux"] = {"workload": "demux + AudioMask of that container (%d channels, %d chunks): gives the ADX files back" % (job.n, job.units),
+                        "chunks_per_s": round(job.units / dt, 1), "ms_per_step": round(dt * 1e3, 3), "verified_items": v["items"]}
+    del bufs
+    torch.cuda.empty_cache()
+    out["awb_mixed_decode"] = awb_mixed_run(D, args.awb_clips, 3, 1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
+def relaunch_under_torchrun(args):
+    """--gpus N without torchrun's environment: start N ranks of this script on this node and pass their line through."""
+    import torch
+    have = torch.cuda.device_count()
+    assert have >= args.gpus or os.environ.get("CRICODECS_BENCH_SHARE_GPU") == "1", "--gpus %d but only %d GPU(s) visible" % (args.gpus, have)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log("launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -249,147 +523,86 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=10000)
-    ap.add_argument("--unique", type=int, default=64)
-    ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "adx_roundtrip", "awb_mixed"])
+    ap.add_argument("--workload", default="hca_decode", choices=["hca_decode", "hca_encode", "adx_roundtrip", "awb_mixed"])
+    ap.add_argument("--streams", type=int, default=None, help="items per GPU (default: 10000; adx_roundtrip 1000)")
+    ap.add_argument("--unique", type=int, default=None, help="distinct inputs tiled to --streams (default 64; hca_encode 16)")
+    ap.add_argument("--seconds", type=float, default=None, help="seconds per item (default 10; hca_encode 30)")
+    ap.add_argument("--data", default="tonal", choices=["tonal", "wide", "mixed"], help="signal family of the synthetic inputs")
+    ap.add_argument("--quality", type=int, default=1, help="HCA quality: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR), 4 Lowest")
     ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
-    ap.add_argument("--quality", type=int, default=1, help="HCA quality of the decode workload: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
-    ap.add_argument("--awb-clips", type=int, default=12500, help="clips of the mixed AWB secondary figure (100 000 / 8 GPUs)")
+    ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        log("note: --gpus %d but WORLD_SIZE=%s; the launcher's world size is used" % (args.gpus, os.environ["WORLD_SIZE"]))
+    D = Dist()
+    wl = args.workload
+    streams = args.streams or (1000 if wl == "adx_roundtrip" else 10000)
+    unique = args.unique or (16 if wl == "hca_encode" else 64)
+    seconds = args.seconds or (30.0 if wl == "hca_encode" else 10.0)
+    verify = not args.no_verify
+    args.streams, args.unique, args.seconds = streams, unique, seconds
+    common = {"n_gpus": D.world, **({"launcher_smoke_test": "ranks share one GPU over gloo; not a measurement"} if D.shared and D.world > 1 else {}), "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
+    par = "file-sharded x%d, one process per GPU, no data-path collective" % D.world
+    t_setup = time.time()
 
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = "cuda:%d" % local
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
-
-    from pycricodecs_amd.batch import Job
-    from pycricodecs_amd import synth
-
-    if args.workload == "awb_mixed":                          # BASELINE configs[4]; its own line, not the headline metric
-        r = awb_mixed_measurement(args, dev, rank, world, gather=not args.no_gather)
-        if rank == 0:
-            print(json.dumps({"metric": "audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", "value": r["frames_per_s"], "unit": "frames/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f32+int32", "data": "synthetic (24 unique durations x 2 codecs, tiled)",
-                              "config": r}), flush=True)
-        if world > 1:
-            dist.destroy_process_group()
+    if wl == "awb_mixed":                                      # BASELINE configs[4]; its own metric line
+        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify)
+        if D.rank == 0:
+            print(json.dumps(dict(common, metric="audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", value=r["frames_per_s"], unit="frames/s",
+                                  ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (24 unique durations x 2 codecs, tiled; tonal family)",
+                                  config=r)), flush=True)
+        D.close()
         return
 
-    t_setup = time.time()
-    extra = {}
-    if args.workload == "hca_decode":
-        uniq = make_hca_streams(args.unique, args.seconds, rank, args.quality)
-        items = [uniq[i % len(uniq)] for i in range(args.streams)]
-        job = Job.hca_decode(items, keys=[KEY] * len(items))
-        metric_cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality %s, frame %d B, key 0xCF222F1FE0748978) per GPU"
-                      % (args.streams, args.seconds, {0: "Highest", 1: "High", 2: "Middle", 3: "Low", 4: "Lowest"}.get(args.quality, "?"), int.from_bytes(uniq[0][0x1C:0x1E], "big")), "streams_per_gpu": args.streams, "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
-                      "unique_streams": len(uniq), "parallelism": "file-sharded x%d, no collective" % world}
-        unit_bytes = "frame_size + 2*1024*channels = 682 + 4096 = 4778 B per frame"
+    if wl == "hca_decode":
+        r = hca_decode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify)
+        cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality %s, frame %d B, key 0xCF222F1FE0748978) per GPU"
+                           % (streams, seconds, QNAME.get(args.quality, "?"), r["frame_size"]),
+               "streams_per_gpu": streams, "frames_per_stream": r["frames_per_stream"], "unique_streams": unique, "parallelism": par,
+               "record_forms": census_text(r["census"])}
+        dtype, unit_bytes = "f32", "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"]
+        cpu = ("hcadec", r["sample"], r["frames_per_stream"])
+    elif wl == "hca_encode":
+        r = hca_encode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify)
+        cfg = {"workload": "BASELINE configs[3]: HCA encode (v2.0, quality %s), %d 48 kHz stereo WAVs x %.0f s per GPU" % (QNAME.get(args.quality, "?"), streams, seconds),
+               "streams_per_gpu": streams, "frames_per_stream": r["frames_per_stream"], "unique_wavs": unique, "parallelism": par}
+        dtype, unit_bytes = "f32", "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"]
+        cpu = ("hcaenc", r["sample"], r["frames_per_stream"])
     else:
-        import oracle_lib as O
-        wavs_u = [synth.wav(1000 * rank + u, int(48000 * args.seconds) // 32 * 32, 2, 48000) for u in range(args.unique)]
-        wavs = [wavs_u[i % len(wavs_u)] for i in range(args.streams)]
-        job = Job.adx_encode(wavs)
-        metric_cfg = {"workload": "BASELINE configs[1]: ADX encode (bs18/bd4/mode3/v4), %d 48 kHz stereo WAVs x %.0f s per GPU" % (args.streams, args.seconds),
-                      "chains": 2 * args.streams, "parallelism": "file-sharded x%d, no collective" % world}
-        unit_bytes = "blocksize + 2*samples_per_block = 18 + 64 = 82 B per block"
-    assert not job.host_status.any(), "synthetic inputs rejected at the header stage"
-    d_in, d_out, d_scratch, d_status = job.alloc(dev)
-    job.enable_events(True)
-    torch.cuda.synchronize()
-    log("setup %.1fs: %d items, %.2f GB in, %.2f GB out, %.2f GB scratch, %d units" %
-        (time.time() - t_setup, job.n, job.input_bytes / 1e9, job.output_bytes / 1e9, job.scratch_bytes / 1e9, job.units))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        job.run(d_in, d_out, d_scratch, d_status)
-    barrier()
-    kernel_ms = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.run(d_in, d_out, d_scratch, d_status)
-        # event read-out waits only for this step's own kernels; it is part of the measured time
-        for k, v in job.event_ms().items():
-            kernel_ms[k] = kernel_ms.get(k, 0.0) + v
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    bad = int((d_status != 0).sum().item())
-    assert bad == 0, "%d items failed on the device" % bad
-
-    # cheap end-to-end check outside the timed region: item 0 equals the oracle's decode
-    if args.workload == "hca_decode":
-        import oracle_lib as O
-        n0 = int(job.output_offsets[1])
-        got = bytes(d_out[:n0].cpu().numpy())
-        ref = O.hca_decode(items[0], KEY)
-        assert got[:len(ref)] == ref, "GPU output differs from the oracle"
-
-    units = job.units
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = units * world / (elapsed / args.steps)
-    dom = max(kernel_ms, key=kernel_ms.get)
-    dom_ms = kernel_ms[dom] / args.steps
-    achieved = job.algorithmic_bytes / (dom_ms * 1e-3) / 1e9
-    # HBM bytes of the dominant kernel per launch: PMC counters cannot be collected from inside this process, so the
-    # per-frame figure comes from the committed rocprofv3 counter passes of this same command (profiles/, tools/prof_traffic.sh)
-    traffic, traffic_src = None, None
-    import glob
-    tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
-    tpath = tfiles[-1] if tfiles else ""
-    if args.workload == "hca_decode" and args.quality == 1 and tpath:
-        with open(tpath) as fh:
-            tj = json.load(fh)
-        if dom in tj.get("kernels", {}):
-            traffic = int(round(tj["kernels"][dom]["hbm_bytes_per_frame"] * units))
-            traffic_src = "profiles/%s: %.0f B/frame (FETCH_SIZE x%.0f + WRITE_SIZE, separate --pmc passes) x %d frames" % (
-                os.path.basename(tpath), tj["kernels"][dom]["hbm_bytes_per_frame"], tj["kernels"][dom]["fetch_correction"], units)
-    out = {
-        "metric": "audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline",
-        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.workload == "hca_decode" else "int32", "data": "synthetic (seeded sines+noise; %d unique streams tiled to %d, each copy in its own HBM)" % (args.unique, args.streams),
-        "config": metric_cfg,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": job.algorithmic_bytes, "bytes_per_unit": unit_bytes,
-                     "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kernel_ms.items()}},
-    }
-    # ---- secondary figures of the same hot path (smaller batches, few steps): HCA encode, ADX encode + decode (configs[1], [3])
-    if rank == 0 and world == 1 and not args.no_secondary:     # (single-GPU run only: the other ranks of a scaling run must not wait)
-        del d_in, d_out, d_scratch, d_status
-        torch.cuda.empty_cache()
-        out["secondary"] = secondary_measurements(args, dev, rank)
-        torch.cuda.empty_cache()
-        out["secondary"]["awb_mixed_decode"] = awb_mixed_measurement(args, dev, rank)
-    if rank == 0 and world == 1 and not args.no_cpu:
-        if args.workload == "hca_decode":
-            out["cpu_baseline"] = cpu_baseline_hca_decode(items[0])
-        else:
-            out["cpu_baseline"] = None
-    if rank == 0:
-        out.update(extra)
+        r = adx_roundtrip_run(D, streams, unique, seconds, args.data, args.steps, args.warmup, verify)
+        cfg = {"workload": "BASELINE configs[1]: ADX encode + decode round trip (bs18/bd4/mode3/v4), %d 48 kHz stereo WAVs x %.0f s per GPU; a frame = one block row (32 samples x 2 channels), counted once for the encode and once for the decode"
+                           % (streams, seconds), "files_per_gpu": streams, "chains": 2 * streams, "unique_wavs": unique, "parallelism": par}
+        dtype, unit_bytes = "int32", "blocksize + 2*samples_per_block = 18 + 64 = 82 B per block, encode and decode each"
+        cpu = ("adxrt", r["sample"], 2 * r["frames_per_stream"])
+    log("%s: setup + run + verify %.1fs; %s" % (wl, time.time() - t_setup, {k: "%.2f GB" % (v / 1e9) for k, v in r["bytes"].items()}))
+    if verify:
+        cfg["verified"] = r["verified"]
+        ok = D.reduce([float(r["verified"]["items"])], "sum")[0]
+        cfg["verified"]["items_all_ranks"] = int(ok)
+    units, dt, kms = r["units"], r["dt"], r["kernel_ms"]
+    dom = max(kms, key=kms.get)
+    alg_dom = r.get("alg_bytes_by_kernel", {}).get(dom, r["alg_bytes"])
+    traffic = committed_traffic(units, dom) if (wl == "hca_decode" and args.quality == 1 and args.data == "tonal") else None
+    roof = roofline_of(alg_dom, r["alg_bytes"], kms, dt, traffic, {"bytes_per_unit": unit_bytes})
+    out = dict(common, metric="audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline", value=round(units * D.world / dt, 1), unit="frames/s",
+               ms_per_step=round(dt * 1e3, 3), dtype=dtype,
+               data="synthetic, %s family (%s); %d unique inputs tiled to %d, each copy in its own HBM" % (
+                   args.data, {"tonal": "seeded sines + noise floor", "wide": "full-scale noise / square / clicks / loud tones", "mixed": "tonal and wide alternating"}[args.data], unique, streams),
+               config=cfg, roofline=roof)
+    # other rows of the same hot path and the host-core baseline: single-GPU run only (ranks of a scaling run must not wait)
+    if D.rank == 0 and D.world == 1 and wl == "hca_decode" and not args.no_secondary:
+        out["secondary"] = secondary_measurements(args, D)
+    if D.rank == 0 and D.world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(*cpu)
+    if D.rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

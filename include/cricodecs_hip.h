@@ -111,6 +111,14 @@ typedef struct cri_adx_encode_params {
     uint32_t bitdepth, blocksize, encoding_mode, highpass_frequency, filter, adx_version, force_no_looping;
 } cri_adx_encode_params;
 
+/* Items given one by one instead of as one blob (the *_items creators): n host pointers + lengths -- several items may point
+ * at the same host bytes, so a batch that repeats files costs no host copy, and a binding can pass its list of buffers as it
+ * is.  offsets[n+1] places the items in the DEVICE input handed to cri_job_run (item i at offsets[i], offsets[n] = its size;
+ * offsets[i+1] - offsets[i] >= lens[i], e.g. the 64-byte aligned output offsets of the job that produced them); NULL =
+ * packed back to back.  cri_job_input_offsets() returns the layout either way.  Host data is only read while the job is
+ * created (headers); cri_job_run_host* need the blob form. */
+typedef struct cri_items { const uint8_t* const* ptrs; const uint64_t* lens; const uint64_t* offsets; uint32_t n; } cri_items;
+
 /* keys / subkeys: per-item arrays, or NULL for all-zero. */
 int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n,
                               const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
@@ -160,6 +168,12 @@ const uint32_t* cri_job_item_tags(const cri_job* job);      /* n entries (jobs t
 const uint64_t* cri_job_item_sizes(const cri_job* job);     /* byte length of every output item (these two job kinds), else NULL */
 int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,
                              const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
+int cri_job_create_hca_decode_items(const cri_items* items, const uint64_t* keys, const uint16_t* subkeys, cri_job** job);
+int cri_job_create_adx_decode_items(const cri_items* items, cri_job** job);
+int cri_job_create_adx_encode_items(const cri_items* items, const cri_adx_encode_params* params, cri_job** job);
+int cri_job_create_hca_encode_items(const cri_items* items, uint32_t force_no_looping, uint32_t quality, cri_job** job);
+int cri_job_create_hca_crypt_items(const cri_items* items, uint32_t encrypt, uint32_t type, const uint64_t* keys, const uint16_t* subkeys,
+                                   cri_job** job);
 
 int cri_job_device(const cri_job* job);                     /* device the job is bound to (see cri_set_device) */
 uint32_t cri_job_kind(const cri_job* job);
@@ -167,6 +181,7 @@ uint32_t cri_job_items(const cri_job* job);
 uint64_t cri_job_input_bytes(const cri_job* job);
 uint64_t cri_job_output_bytes(const cri_job* job);
 const uint64_t* cri_job_output_offsets(const cri_job* job); /* n+1 entries */
+const uint64_t* cri_job_input_offsets(const cri_job* job);  /* n+1 entries: where cri_job_run expects item i in d_in */
 const int32_t* cri_job_host_status(const cri_job* job);     /* n entries, header-stage result per item */
 uint64_t cri_job_scratch_bytes(const cri_job* job);         /* device scratch the run needs (may be 0) */
 /* Work units of the job in the metric's unit: HCA frames (1024 samples x all channels) or ADX frames
@@ -190,6 +205,15 @@ int cri_job_run(cri_job* job, const void* d_in, void* d_out, void* d_scratch, in
 uint64_t cri_job_float_count(const cri_job* job);
 const uint64_t* cri_job_float_offsets(const cri_job* job);  /* n+1 entries, in floats; NULL for other job kinds */
 int cri_job_run_floats(cri_job* job, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, float* d_floats, void* hip_stream);
+
+/* Frame-record layout of an HCA decode job's scratch, one entry per format group (launch set), for diagnostics: the word at
+ * first_record_offset + g * record_bytes + flags_offset of frame g (0 <= g < frames) has narrow_flag set when that frame's
+ * quantised lines went through scratch in the narrow (int8) form.  Returns the number of groups (fills at most cap). */
+typedef struct cri_hca_group_info {
+    uint32_t channels, frames, record_bytes, flags_offset, narrow_flag, narrow_capable, plain, pad;
+    uint64_t first_record_offset;
+} cri_hca_group_info;
+int cri_job_hca_groups(const cri_job* job, cri_hca_group_info* out, int cap);
 
 /* Name of the job's dominant kernel (for profiling cross-checks). */
 const char* cri_job_dominant_kernel(const cri_job* job);

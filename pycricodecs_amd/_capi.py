@@ -21,7 +21,8 @@ SYMBOLS = [
     "cri_job_output_bytes", "cri_job_output_offsets", "cri_job_host_status", "cri_job_scratch_bytes", "cri_job_units",
     "cri_job_units2", "cri_job_algorithmic_bytes", "cri_job_run", "cri_job_dominant_kernel", "cri_job_destroy", "cri_job_run_host", "cri_job_enable_events",
     "cri_job_event_ms", "cri_awb_index", "cri_job_create_awb_decode", "cri_job_run_host_into",
-    "cri_device_count", "cri_set_device", "cri_get_device", "cri_job_device", "cri_job_run_floats", "cri_job_float_count", "cri_job_float_offsets",
+    "cri_job_create_hca_decode_items", "cri_job_create_adx_decode_items", "cri_job_create_adx_encode_items",
+    "cri_job_create_hca_encode_items", "cri_job_create_hca_crypt_items", "cri_job_input_offsets", "cri_device_count", "cri_set_device", "cri_get_device", "cri_job_device", "cri_job_run_floats", "cri_job_float_count", "cri_job_float_offsets",
     "cri_usm_audio_mask", "cri_usm_index", "cri_job_create_usm_audio_demux", "cri_job_create_sfa_pack", "cri_job_item_tags", "cri_job_item_sizes",
 ]
 
@@ -30,6 +31,11 @@ class UsmChunk(C.Structure):
     _fields_ = [("fourcc", C.c_char * 4), ("chno", C.c_uint32), ("type", C.c_uint32), ("padding", C.c_uint32),
                 ("payload_offset", C.c_uint64), ("payload_len", C.c_uint32), ("frame_time", C.c_uint32),
                 ("frame_rate", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class HcaGroupInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("channels", "frames", "record_bytes", "flags_offset", "narrow_flag", "narrow_capable", "plain", "pad")] + \
+               [("first_record_offset", C.c_uint64)]
 
 
 class AdxEncodeParams(C.Structure):
@@ -77,6 +83,14 @@ def lib():
     L.cri_job_dominant_kernel.argtypes = [vp]
     L.cri_job_dominant_kernel.restype = C.c_char_p
     L.cri_job_run.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.cri_job_create_hca_decode_items.argtypes = [vp, u64p, C.POINTER(C.c_uint16), C.POINTER(vp)]
+    L.cri_job_create_adx_decode_items.argtypes = [vp, C.POINTER(vp)]
+    L.cri_job_create_adx_encode_items.argtypes = [vp, C.POINTER(AdxEncodeParams), C.POINTER(vp)]
+    L.cri_job_create_hca_encode_items.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.cri_job_create_hca_crypt_items.argtypes = [vp, C.c_uint32, C.c_uint32, u64p, C.POINTER(C.c_uint16), C.POINTER(vp)]
+    L.cri_job_hca_groups.argtypes = [vp, C.POINTER(HcaGroupInfo), C.c_int]
+    L.cri_job_input_offsets.argtypes = [vp]
+    L.cri_job_input_offsets.restype = u64p
     L.cri_set_device.argtypes = [C.c_int]
     L.cri_job_device.argtypes = [vp]
     L.cri_job_run_floats.argtypes = [vp, vp, vp, vp, vp, vp, vp]

@@ -19,12 +19,38 @@ def pack(items):
     return b"".join(items), offs
 
 
-class Job:
-    """Owns a cri_job.  Create with one of the classmethods; `run()` enqueues it on torch's current stream."""
+class CriItems(C.Structure):
+    _fields_ = [("ptrs", C.POINTER(C.c_void_p)), ("lens", C.POINTER(C.c_uint64)), ("offsets", C.POINTER(C.c_uint64)), ("n", C.c_uint32)]
 
-    def __init__(self, handle, blob, offsets):
+
+def items_struct(items, offsets=None):
+    """cri_items over a list of bytes objects (no copy: the library reads the host bytes only while it plans the job).
+    offsets: device offsets uint64[n+1] (e.g. another job's output offsets), or None for packed.  Returns (struct, keepalive)."""
+    n = len(items)
+    ptrs = (C.c_void_p * max(n, 1))()
+    lens = (C.c_uint64 * max(n, 1))()
+    keep = []
+    for i, b in enumerate(items):
+        cp = C.c_char_p(b)
+        keep.append(cp)
+        ptrs[i] = C.cast(cp, C.c_void_p).value
+        lens[i] = len(b)
+    offs = None
+    if offsets is not None:
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        assert offs.shape == (n + 1,)
+    st = CriItems(C.cast(ptrs, C.POINTER(C.c_void_p)), C.cast(lens, C.POINTER(C.c_uint64)),
+                  offs.ctypes.data_as(C.POINTER(C.c_uint64)) if offs is not None else None, n)
+    return st, (ptrs, lens, keep, offs, items)
+
+
+class Job:
+    """Owns a cri_job.  Create with one of the classmethods; `run()` enqueues it on torch's current stream.
+    Batches are handed to the library item by item (cri_items): a list that repeats the same bytes object costs no host copy."""
+
+    def __init__(self, handle, blob, offsets, items=None):
         self._h = handle
-        self.blob, self.offsets = blob, offsets
+        self._blob, self.items = blob, items
         L = _capi.lib()
         self.n = L.cri_job_items(handle)
         self.kind = KIND_NAMES[L.cri_job_kind(handle)]
@@ -36,6 +62,7 @@ class Job:
         self.algorithmic_bytes = L.cri_job_algorithmic_bytes(handle)
         self.dominant_kernel = L.cri_job_dominant_kernel(handle).decode()
         self.output_offsets = np.ctypeslib.as_array(L.cri_job_output_offsets(handle), shape=(self.n + 1,)).copy()
+        self.offsets = np.ctypeslib.as_array(L.cri_job_input_offsets(handle), shape=(self.n + 1,)).copy() if offsets is None else offsets
         self.host_status = np.ctypeslib.as_array(L.cri_job_host_status(handle), shape=(max(self.n, 1),)).copy()[:self.n]
         tags = L.cri_job_item_tags(handle)
         self.item_tags = np.ctypeslib.as_array(tags, shape=(self.n,)).copy() if tags else None
@@ -50,6 +77,17 @@ class Job:
         except Exception:
             pass
 
+    @property
+    def blob(self):
+        """The device input as one host bytes object (built on first use for jobs created from an item list)."""
+        if self._blob is None:
+            buf = bytearray(int(self.input_bytes))
+            for i, b in enumerate(self.items):
+                o = int(self.offsets[i])
+                buf[o:o + len(b)] = b
+            self._blob = bytes(buf)
+        return self._blob
+
     # ---- constructors
     @staticmethod
     def _blob_args(items):
@@ -57,19 +95,24 @@ class Job:
         return blob, offs, (blob if blob else b"\0")      # bytes are passed by pointer, no copy
 
     @classmethod
-    def _finish(cls, rc, h, blob, offs):
+    def _finish(cls, rc, h, blob, offs, items=None):
         if rc:
             _capi.raise_for(rc)
-        return cls(h, blob, offs)
+        return cls(h, blob, offs, items)
+
+    @staticmethod
+    def _as_bytes(items):
+        return [b if isinstance(b, bytes) else bytes(b) for b in items]
 
     @classmethod
-    def hca_decode(cls, items, keys=None, subkeys=None):
-        blob, offs, buf = cls._blob_args(items)
-        k = None if keys is None else (C.c_uint64 * len(items))(*[x & 0xFFFFFFFFFFFFFFFF for x in keys])
-        s = None if subkeys is None else (C.c_uint16 * len(items))(*subkeys)
+    def hca_decode(cls, items, keys=None, subkeys=None, offsets=None):
+        items = cls._as_bytes(items)
+        st, keep = items_struct(items, offsets)
+        k = None if keys is None else (C.c_uint64 * max(len(items), 1))(*[x & 0xFFFFFFFFFFFFFFFF for x in keys])
+        s = None if subkeys is None else (C.c_uint16 * max(len(items), 1))(*subkeys)
         h = C.c_void_p()
-        rc = _capi.lib().cri_job_create_hca_decode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), k, s, C.byref(h))
-        return cls._finish(rc, h, blob, offs)
+        rc = _capi.lib().cri_job_create_hca_decode_items(C.byref(st), k, s, C.byref(h))
+        return cls._finish(rc, h, None, None, items)
 
     @classmethod
     def awb_decode(cls, awb, key=0):
@@ -105,46 +148,73 @@ class Job:
         return cls._finish(rc, h, blob, offs)
 
     @classmethod
-    def adx_decode(cls, items):
-        blob, offs, buf = cls._blob_args(items)
+    def adx_decode(cls, items, offsets=None):
+        items = cls._as_bytes(items)
+        st, keep = items_struct(items, offsets)
         h = C.c_void_p()
-        rc = _capi.lib().cri_job_create_adx_decode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), C.byref(h))
-        return cls._finish(rc, h, blob, offs)
+        rc = _capi.lib().cri_job_create_adx_decode_items(C.byref(st), C.byref(h))
+        return cls._finish(rc, h, None, None, items)
 
     @classmethod
-    def adx_encode(cls, items, bitdepth=4, blocksize=18, mode=3, highpass=500, filt=0, version=4, force_no_loop=False):
-        blob, offs, buf = cls._blob_args(items)
+    def adx_encode(cls, items, bitdepth=4, blocksize=18, mode=3, highpass=500, filt=0, version=4, force_no_loop=False, offsets=None):
+        items = cls._as_bytes(items)
+        st, keep = items_struct(items, offsets)
         p = _capi.AdxEncodeParams(bitdepth, blocksize, mode, highpass, filt, version, int(force_no_loop))
         h = C.c_void_p()
-        rc = _capi.lib().cri_job_create_adx_encode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), C.byref(p), C.byref(h))
-        return cls._finish(rc, h, blob, offs)
+        rc = _capi.lib().cri_job_create_adx_encode_items(C.byref(st), C.byref(p), C.byref(h))
+        return cls._finish(rc, h, None, None, items)
 
     @classmethod
-    def hca_encode(cls, items, quality=1, force_no_loop=False):
-        blob, offs, buf = cls._blob_args(items)
+    def hca_encode(cls, items, quality=1, force_no_loop=False, offsets=None):
+        items = cls._as_bytes(items)
+        st, keep = items_struct(items, offsets)
         h = C.c_void_p()
-        rc = _capi.lib().cri_job_create_hca_encode(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), int(force_no_loop), quality, C.byref(h))
-        return cls._finish(rc, h, blob, offs)
+        rc = _capi.lib().cri_job_create_hca_encode_items(C.byref(st), int(force_no_loop), quality, C.byref(h))
+        return cls._finish(rc, h, None, None, items)
 
     @classmethod
-    def hca_crypt(cls, items, encrypt, ctype, keys=None, subkeys=None):
-        blob, offs, buf = cls._blob_args(items)
-        k = None if keys is None else (C.c_uint64 * len(items))(*[x & 0xFFFFFFFFFFFFFFFF for x in keys])
-        s = None if subkeys is None else (C.c_uint16 * len(items))(*subkeys)
+    def hca_crypt(cls, items, encrypt, ctype, keys=None, subkeys=None, offsets=None):
+        items = cls._as_bytes(items)
+        st, keep = items_struct(items, offsets)
+        k = None if keys is None else (C.c_uint64 * max(len(items), 1))(*[x & 0xFFFFFFFFFFFFFFFF for x in keys])
+        s = None if subkeys is None else (C.c_uint16 * max(len(items), 1))(*subkeys)
         h = C.c_void_p()
-        rc = _capi.lib().cri_job_create_hca_crypt(buf, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(items), int(encrypt), ctype, k, s, C.byref(h))
-        return cls._finish(rc, h, blob, offs)
+        rc = _capi.lib().cri_job_create_hca_crypt_items(C.byref(st), int(encrypt), ctype, k, s, C.byref(h))
+        return cls._finish(rc, h, None, None, items)
 
     # ---- device execution (torch tensors are only buffers here)
     def alloc(self, device="cuda:0", upload=True):
         import torch
         d_in = torch.empty(max(self.input_bytes, 1), dtype=torch.uint8, device=device)
         if upload and self.input_bytes:
-            d_in[:self.input_bytes].copy_(torch.frombuffer(bytearray(self.blob), dtype=torch.uint8))
+            self.upload(d_in)
         d_out = torch.zeros(max(self.output_bytes, 1), dtype=torch.uint8, device=device)
         d_scratch = torch.empty(max(self.scratch_bytes, 1), dtype=torch.uint8, device=device)
         d_status = torch.zeros(max(self.n, 1), dtype=torch.int32, device=device)
         return d_in, d_out, d_scratch, d_status
+
+    def upload(self, d_in):
+        """Fill the device input.  Item lists go up one distinct bytes object at a time; repeats are device-to-device copies."""
+        import warnings
+        import torch
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                    # (read-only buffers: they are only read)
+            if self.items is None:
+                d_in[:self.input_bytes].copy_(torch.frombuffer(memoryview(self._blob), dtype=torch.uint8)[:self.input_bytes])
+                return
+            if self.n and int(self.offsets[self.n]) != sum(len(b) for b in self.items):
+                d_in.zero_()                                   # gaps between items (aligned layouts) are defined
+            first = {}
+            for i, b in enumerate(self.items):
+                if not len(b):
+                    continue
+                o = int(self.offsets[i])
+                src = first.get(id(b))
+                if src is None:
+                    d_in[o:o + len(b)].copy_(torch.frombuffer(memoryview(b), dtype=torch.uint8))
+                    first[id(b)] = o
+                else:
+                    d_in[o:o + len(b)].copy_(d_in[src:src + len(b)])
 
     def run(self, d_in, d_out, d_scratch, d_status, stream=None):
         import torch
@@ -169,6 +239,23 @@ class Job:
             _capi.raise_for(rc)
         return d_f, offs
 
+    def record_census(self, d_scratch):
+        """HCA decode diagnostics after a run: {"frames": n, "narrow": frames whose quantised lines crossed scratch as int8}."""
+        import torch
+        L = _capi.lib()
+        arr = (_capi.HcaGroupInfo * 64)()
+        n = L.cri_job_hca_groups(self._h, arr, 64)
+        frames = narrow = 0
+        words = d_scratch.view(torch.int32)
+        for g in arr[:n]:
+            if not g.frames:
+                continue
+            base = (g.first_record_offset + g.flags_offset) // 4
+            fl = words[base:base + (g.frames - 1) * (g.record_bytes // 4) + 1:g.record_bytes // 4]
+            frames += g.frames
+            narrow += int(((fl & g.narrow_flag) != 0).sum().item())
+        return {"frames": frames, "narrow": narrow}
+
     def enable_events(self, on=True):
         _capi.lib().cri_job_enable_events(self._h, 1 if on else 0)
 
@@ -186,7 +273,8 @@ class Job:
         if getattr(self, "_host_out", None) is None or self._host_out.size < n:
             self._host_out = np.empty(n, dtype=np.uint8)
         status = (C.c_int32 * max(self.n, 1))()
-        rc = _capi.lib().cri_job_run_host_into(self._h, self.blob if self.blob else b"\0", self._host_out.ctypes.data, status)
+        blob = self.blob
+        rc = _capi.lib().cri_job_run_host_into(self._h, blob if blob else b"\0", self._host_out.ctypes.data, status)
         if rc:
             _capi.raise_for(rc)
         return self.split(memoryview(self._host_out)), np.array(status[:self.n], dtype=np.int32)
@@ -197,7 +285,7 @@ class Job:
         if self.kind in ("adx_decode", "hca_decode"):
             return int.from_bytes(blob[o + 4:o + 8], "little") + 8 if blob[o:o + 4] == b"RIFF" else 0
         if self.kind == "hca_crypt":
-            return int(self.offsets[i + 1] - self.offsets[i])
+            return len(self.items[i]) if self.items is not None else int(self.offsets[i + 1] - self.offsets[i])
         if self.item_sizes is not None:
             return int(self.item_sizes[i])
         return None

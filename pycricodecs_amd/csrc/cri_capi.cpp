@@ -65,6 +65,7 @@ struct cri_job {
     std::vector<Image> images;
     // launch plans (device pointers for in/out/scratch/status are filled at run time)
     std::vector<HcaDecArgs> hca_dec;
+    std::vector<uint64_t> hca_group_first_record; // per launch set: scratch offset of its first frame record
     AdxArgs adx{};
     uint32_t adx_streams = 0;                    // number of valid ADX streams
     bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
@@ -188,6 +189,7 @@ extern "C" uint32_t cri_job_items(const cri_job* j) { return j ? j->n : 0; }
 extern "C" uint64_t cri_job_input_bytes(const cri_job* j) { return j ? j->in_bytes : 0; }
 extern "C" uint64_t cri_job_output_bytes(const cri_job* j) { return j ? j->out_bytes : 0; }
 extern "C" const uint64_t* cri_job_output_offsets(const cri_job* j) { return j ? j->out_offsets.data() : nullptr; }
+extern "C" const uint64_t* cri_job_input_offsets(const cri_job* j) { return j ? j->in_offsets.data() : nullptr; }
 extern "C" const int32_t* cri_job_host_status(const cri_job* j) { return j ? j->host_status.data() : nullptr; }
 extern "C" uint64_t cri_job_scratch_bytes(const cri_job* j) { return j ? j->scratch_bytes : 0; }
 extern "C" uint64_t cri_job_units(const cri_job* j) { return j ? j->units : 0; }
@@ -196,6 +198,36 @@ extern "C" uint64_t cri_job_algorithmic_bytes(const cri_job* j) { return j ? j->
 extern "C" const char* cri_job_dominant_kernel(const cri_job* j) { return j ? j->dominant.c_str() : ""; }
 extern "C" void cri_job_destroy(cri_job* j) { if (!j) return; DeviceGuard g(j->device); delete j; }
 extern "C" int cri_job_device(const cri_job* j) { return j ? j->device : -1; }
+
+// Where a job's items are on the host while it is planned, and where they will be on the device when it runs.
+//  blob form    one host blob + offsets[n+1]; the device input is a byte-identical copy of the blob
+//  items form   n host pointers + lengths (several items may share one host buffer: a tiled batch costs no host copy),
+//               device offsets[n+1] (offsets[n] = device input size) or NULL for "packed back to back"
+struct ItemSrc {
+    const uint8_t* blob = nullptr; const uint64_t* offsets = nullptr;
+    const uint8_t* const* ptrs = nullptr; const uint64_t* lens = nullptr;
+    std::vector<uint64_t> packed;                // items form without offsets: prefix sums of lens
+    uint32_t n = 0;
+    static ItemSrc from_blob(const uint8_t* b, const uint64_t* o, uint32_t n) { ItemSrc s; s.blob = b; s.offsets = o; s.n = n; return s; }
+    static int from_items(const cri_items* it, ItemSrc& s) {
+        if (!it || (it->n && (!it->ptrs || !it->lens))) return CRI_ERR_INVALID_ARG;
+        s.ptrs = it->ptrs; s.lens = it->lens; s.n = it->n; s.offsets = it->offsets;
+        if (!s.offsets) {
+            s.packed.assign((size_t)it->n + 1, 0);
+            for (uint32_t i = 0; i < it->n; i++) s.packed[i + 1] = s.packed[i] + it->lens[i];
+            s.offsets = s.packed.data();
+        } else {
+            for (uint32_t i = 0; i < it->n; i++)           // items may not overlap or run past the next one's start
+                if (it->offsets[i] > it->offsets[i + 1] || it->offsets[i + 1] - it->offsets[i] < it->lens[i]) return CRI_ERR_INVALID_ARG;
+        }
+        for (uint32_t i = 0; i < it->n; i++) if (!it->ptrs[i] && it->lens[i]) return CRI_ERR_INVALID_ARG;
+        return 0;
+    }
+    bool ok() const { return offsets && (blob || ptrs || n == 0); }
+    const uint8_t* ptr(uint32_t i) const { return ptrs ? ptrs[i] : blob + offsets[i]; }
+    size_t len(uint32_t i) const { return (size_t)(lens ? lens[i] : offsets[i + 1] - offsets[i]); }
+    uint64_t off(uint32_t i) const { return offsets[i]; }   // device offset of item i
+};
 
 static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
     cri_job* j = new cri_job();
@@ -207,13 +239,15 @@ static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
     j->out_offsets.assign(n + 1, 0);
     return j;
 }
+static cri_job* new_job(uint32_t kind, const ItemSrc& it) { return new_job(kind, it.offsets, it.n); }
 
 // ------------------------------------------------------------------------------------------------ HCA decode
-static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const uint64_t* keys, const uint16_t* subkeys,
+static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint16_t* subkeys,
                              const uint32_t* header_sizes, cri_job** out, const uint8_t* take = nullptr, uint8_t take_kind = 0) {
-    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+    const uint32_t n = it.n;
+    if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
-    cri_job* j = new_job(CRI_JOB_HCA_DECODE, offsets, n);
+    cri_job* j = new_job(CRI_JOB_HCA_DECODE, it);
     j->dominant = "k_hca_transform";
     std::vector<HcaFormat> formats; std::vector<HcaStream> streams;
     std::vector<uint8_t> cipher, ath(128, 0);
@@ -227,8 +261,8 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         j->out_offsets[i] = out_pos;
         j->float_offsets[i] = float_pos;
         if (take && take[i] != take_kind) { j->host_status[i] = CRI_ITEM_SKIPPED; continue; }
-        const uint8_t* d = blob + offsets[i];
-        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const uint8_t* d = it.ptr(i);
+        size_t len = it.len(i);
         HcaHeader h;
         uint32_t hs_arg = header_sizes ? header_sizes[i] : (len >= 8 ? be16(d + 6) : 0);
         int rc = hca_parse_header(d, len, hs_arg, h);
@@ -276,7 +310,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         uint32_t wh = wav_write_header(im.bytes.data(), h.channels, h.rate, spc, h.loop_flag != 0, ls, le);
         j->images.push_back(std::move(im));
         HcaStream S; memset(&S, 0, sizeof S);
-        S.src_offset = offsets[i] + hs_arg; S.dst_offset = out_pos + wh; S.format = fidx; S.cipher = cidx; S.frames = frames;
+        S.src_offset = it.off(i) + hs_arg; S.dst_offset = out_pos + wh; S.format = fidx; S.cipher = cidx; S.frames = frames;
         S.delay = h.delay; S.samples = spc; S.item = i; S.float_offset = float_pos;
         float_pos += (uint64_t)frames * 1024 * h.channels;
         streams.push_back(S);
@@ -312,6 +346,7 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
         a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
+        j->hca_group_first_record.push_back(streams[b].scratch_offset);
         b = e;
     }
     // word tiles and per-frame prepare status of every format group follow the frame records
@@ -337,7 +372,12 @@ static int create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint3
 
 extern "C" int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const uint64_t* keys,
                                          const uint16_t* subkeys, cri_job** job) {
-    return create_hca_decode(blob, offsets, n, keys, subkeys, nullptr, job);
+    if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
+    return create_hca_decode(ItemSrc::from_blob(blob, offsets, n), keys, subkeys, nullptr, job);
+}
+extern "C" int cri_job_create_hca_decode_items(const cri_items* items, const uint64_t* keys, const uint16_t* subkeys, cri_job** job) {
+    ItemSrc it; int rc = ItemSrc::from_items(items, it);
+    return rc ? rc : create_hca_decode(it, keys, subkeys, nullptr, job);
 }
 
 
@@ -392,10 +432,11 @@ struct AdxWavePlan {
 };
 
 // ------------------------------------------------------------------------------------------------ ADX decode
-static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out, const uint8_t* take = nullptr, uint8_t take_kind = 0) {
-    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* take = nullptr, uint8_t take_kind = 0) {
+    const uint32_t n = it.n;
+    if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
-    cri_job* j = new_job(CRI_JOB_ADX_DECODE, offsets, n);
+    cri_job* j = new_job(CRI_JOB_ADX_DECODE, it);
     j->dominant = "k_adx_decode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history;
     AdxWavePlan plan;
@@ -404,8 +445,8 @@ static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint3
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
         if (take && take[i] != take_kind) { j->host_status[i] = CRI_ITEM_SKIPPED; continue; }
-        const uint8_t* d = blob + offsets[i];
-        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const uint8_t* d = it.ptr(i);
+        size_t len = it.len(i);
         AdxHeader h;
         int rc = adx_parse_header(d, len, h);
         if (rc) { j->host_status[i] = rc; continue; }
@@ -414,7 +455,7 @@ static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint3
         uint32_t wh = wav_write_header(im.bytes.data(), h.channels, h.rate, h.sample_count, h.looping, h.loop_start, h.loop_end);
         j->images.push_back(std::move(im));
         AdxStream S; memset(&S, 0, sizeof S);
-        S.src_offset = offsets[i] + h.data_offset + 4; S.src_end = offsets[i + 1]; S.dst_offset = out_pos + wh;
+        S.src_offset = it.off(i) + h.data_offset + 4; S.src_end = it.off(i) + it.len(i); S.dst_offset = out_pos + wh;
         if (S.src_offset > S.src_end) S.src_offset = S.src_end;
         S.frames = h.blocks; S.channels = h.channels; S.blocksize = h.blocksize; S.bitdepth = h.bitdepth; S.mode = h.mode;
         S.samples_per_block = h.samples_per_block; S.coef0 = h.coef[0]; S.coef1 = h.coef[1]; S.samples = h.sample_count;
@@ -449,7 +490,12 @@ static int create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint3
 }
 
 extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out) {
-    return create_adx_decode(blob, offsets, n, out);
+    if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
+    return create_adx_decode(ItemSrc::from_blob(blob, offsets, n), out);
+}
+extern "C" int cri_job_create_adx_decode_items(const cri_items* items, cri_job** job) {
+    ItemSrc it; int rc = ItemSrc::from_items(items, it);
+    return rc ? rc : create_adx_decode(it, job);
 }
 
 // ------------------------------------------------------------------------------------------------ AWB (AFS2) front door
@@ -503,9 +549,10 @@ extern "C" int cri_job_create_awb_decode(const uint8_t* awb, size_t len, uint64_
     rc = cri_awb_index(awb, len, &n, nullptr, &subkey, nullptr, offsets.data(), kinds.data(), n);
     if (rc) return rc;
     std::vector<uint64_t> keys(n ? n : 1, key); std::vector<uint16_t> subkeys(n ? n : 1, subkey);   // awb.py:72: HCA(i, key=key, subkey=self.subkey)
-    rc = create_hca_decode(awb, offsets.data(), n, keys.data(), subkeys.data(), nullptr, hca_job, kinds.data(), CRI_AWB_HCA);
+    const ItemSrc it = ItemSrc::from_blob(awb, offsets.data(), n);
+    rc = create_hca_decode(it, keys.data(), subkeys.data(), nullptr, hca_job, kinds.data(), CRI_AWB_HCA);
     if (rc) return rc;
-    rc = create_adx_decode(awb, offsets.data(), n, adx_job, kinds.data(), CRI_AWB_ADX);
+    rc = create_adx_decode(it, adx_job, kinds.data(), CRI_AWB_ADX);
     if (rc) { cri_job_destroy(*hca_job); *hca_job = nullptr; }
     return rc;
 }
@@ -688,8 +735,9 @@ static void sfa_chunk_header(std::vector<uint8_t>& h, uint32_t size, uint32_t pa
 extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t codec, uint64_t key,
                                        uint32_t encrypt_audio, cri_job** out) {
     if (!blob || !offsets || !out || (codec != CRI_USM_CODEC_ADX && codec != CRI_USM_CODEC_HCA)) return CRI_ERR_INVALID_ARG;
+    const ItemSrc it = ItemSrc::from_blob(blob, offsets, n);
     if (!cri_device_available()) return CRI_ERR_HIP;
-    cri_job* j = new_job(CRI_JOB_SFA_PACK, offsets, n);
+    cri_job* j = new_job(CRI_JOB_SFA_PACK, it);
     std::vector<Segment> segs;
     uint64_t out_pos = 0;
     std::vector<uint8_t> hdr;
@@ -718,20 +766,20 @@ extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offs
     };
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
-        const uint8_t* d = blob + offsets[i];
-        const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const uint8_t* d = it.ptr(i);
+        const size_t len = it.len(i);
         uint32_t chunks = 0;
         if (codec == CRI_USM_CODEC_HCA) {                        // usm.py:659-716
             HcaHeader h;
             const uint32_t hs = len >= 8 ? (((uint32_t)d[6] << 8) | d[7]) : 0;
             int rc = hca_parse_header(d, len, hs, h);
             if (rc) { j->host_status[i] = rc; j->item_tags.push_back(0); continue; }
-            emit(i, offsets[i], h.header_size, 0, false); chunks++;
+            emit(i, it.off(i), h.header_size, 0, false); chunks++;
             uint32_t t = 0;
             for (uint32_t f = 0; f < h.frame_count; f++) {       // hca.py:297-301 get_frames: FrameSize bytes each
                 const uint64_t fo = (uint64_t)h.header_size + (uint64_t)f * h.frame_size;
                 if (fo + h.frame_size > len) break;
-                emit(i, offsets[i] + fo, h.frame_size, t, false); chunks++;
+                emit(i, it.off(i) + fo, h.frame_size, t, false); chunks++;
                 t += 64;                                         // base_interval_per_SFA_chunk, usm.py:1177
             }
             contents_end(i);
@@ -754,12 +802,12 @@ extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offs
                 } else take = chunk;
                 take = (uint32_t)std::min<uint64_t>(take, len - tell);
                 if (take == 0) break;
-                emit(i, offsets[i] + tell, take, interval, encrypt_audio != 0); chunks++;
+                emit(i, it.off(i) + tell, take, interval, encrypt_audio != 0); chunks++;
                 tell += take;
                 interval = (uint32_t)(int64_t)((double)count * 99.9);                    // usm.py:619, 1168 (the builder is VP9 only)
                 count++;
             }
-            emit(i, offsets[i] + tell, (uint32_t)std::min<uint64_t>(h.blocksize, len - tell), interval, false); chunks++;
+            emit(i, it.off(i) + tell, (uint32_t)std::min<uint64_t>(h.blocksize, len - tell), interval, false); chunks++;
             contents_end(i);
         }
         j->item_tags.push_back(chunks);
@@ -780,10 +828,11 @@ extern "C" const uint64_t* cri_job_item_sizes(const cri_job* j) { return j && j-
 extern "C" const uint32_t* cri_job_item_tags(const cri_job* j) { return j && j->item_tags.size() == j->n && j->n ? j->item_tags.data() : nullptr; }
 
 // ------------------------------------------------------------------------------------------------ ADX encode
-extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const cri_adx_encode_params* p, cri_job** out) {
-    if (!blob || !offsets || !out || !p) return CRI_ERR_INVALID_ARG;
+static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, cri_job** out) {
+    const uint32_t n = it.n;
+    if (!it.ok() || !out || !p) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
-    cri_job* j = new_job(CRI_JOB_ADX_ENCODE, offsets, n);
+    cri_job* j = new_job(CRI_JOB_ADX_ENCODE, it);
     j->dominant = "k_adx_encode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history; std::vector<uint8_t> stale;
     AdxWavePlan plan;
@@ -791,8 +840,8 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
-        const uint8_t* d = blob + offsets[i];
-        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const uint8_t* d = it.ptr(i);
+        size_t len = it.len(i);
         WavInfo w;
         int rc = wav_parse(d, len, w);
         if (rc) { j->host_status[i] = rc; continue; }
@@ -809,13 +858,13 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
           for (uint32_t k = 0; k < 4 && k < bs; k++) tail.bytes[k] = t4[k]; }
         j->images.push_back(std::move(tail));
         AdxStream S; memset(&S, 0, sizeof S);
-        S.src_offset = offsets[i] + w.data_offset; S.src_end = offsets[i + 1]; S.dst_offset = out_pos + hs;
+        S.src_offset = it.off(i) + w.data_offset; S.src_end = it.off(i) + it.len(i); S.dst_offset = out_pos + hs;
         S.frames = pl.frames; S.channels = pl.channels; S.blocksize = bs; S.bitdepth = p->bitdepth; S.mode = p->encoding_mode;
         S.samples_per_block = pl.samples_per_block; S.coef0 = pl.coef[0]; S.coef1 = pl.coef[1]; S.samples = pl.samples_per_channel;
         if (!plan.place(chain_stream, history, pl.channels, pl.channels * pl.samples_per_block * 2, pl.channels * bs)) {
             j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); j->images.pop_back(); continue;
         }
-        if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(offsets[i] + w.data_offset, w); S.src_end = S.src_offset + 2ull * w.column_size; S.src_in_scratch = 1; }
+        if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(it.off(i) + w.data_offset, w); S.src_end = S.src_offset + 2ull * w.column_size; S.src_in_scratch = 1; }
         if (!(bs == 18 && p->bitdepth == 4 && pl.channels <= 2 && pl.image.size() <= hs + 1)) all_std = false;
         S.filter_bits = p->filter << 13; S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
         if (pl.image.size() > hs) { S.stale_offset = (uint32_t)stale.size(); S.stale_len = (uint32_t)(pl.image.size() - hs);
@@ -845,20 +894,30 @@ extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* of
     return 0;
 }
 
+extern "C" int cri_job_create_adx_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const cri_adx_encode_params* p, cri_job** out) {
+    if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
+    return create_adx_encode(ItemSrc::from_blob(blob, offsets, n), p, out);
+}
+extern "C" int cri_job_create_adx_encode_items(const cri_items* items, const cri_adx_encode_params* p, cri_job** out) {
+    ItemSrc it; int rc = ItemSrc::from_items(items, it);
+    return rc ? rc : create_adx_encode(it, p, out);
+}
+
 // ------------------------------------------------------------------------------------------------ HCA crypt
-static int create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type, const uint64_t* keys,
+static int create_hca_crypt(const ItemSrc& it, uint32_t encrypt, uint32_t type, const uint64_t* keys,
                             const uint16_t* subkeys, const uint32_t* header_sizes, cri_job** out) {
-    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+    const uint32_t n = it.n;
+    if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
-    cri_job* j = new_job(CRI_JOB_HCA_CRYPT, offsets, n);
+    cri_job* j = new_job(CRI_JOB_HCA_CRYPT, it);
     j->dominant = "k_hca_crypt";
     std::vector<HcaStream> streams; std::vector<uint32_t> frame_sizes, first_frame{0}; std::vector<uint8_t> cipher;
     std::map<std::tuple<uint32_t, uint64_t, uint32_t>, uint32_t> cipher_index;
     uint64_t out_pos = 0; uint32_t frames_total = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
-        const uint8_t* d = blob + offsets[i];
-        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const uint8_t* d = it.ptr(i);
+        size_t len = it.len(i);
         HcaHeader h;
         uint32_t hs = header_sizes ? header_sizes[i] : (len >= 8 ? be16(d + 6) : 0);
         int rc = hca_parse_header(d, len, hs, h);
@@ -883,7 +942,7 @@ static int create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32
         uint64_t body_end = (uint64_t)hs + (uint64_t)h.frame_count * h.frame_size;
         if (body_end < len) { Image tail; tail.dst = out_pos + body_end; tail.bytes.assign(d + body_end, d + len); j->images.push_back(std::move(tail)); }
         HcaStream S; memset(&S, 0, sizeof S);
-        S.src_offset = offsets[i] + hs; S.dst_offset = out_pos + hs; S.cipher = cidx; S.frames = h.frame_count; S.item = i;
+        S.src_offset = it.off(i) + hs; S.dst_offset = out_pos + hs; S.cipher = cidx; S.frames = h.frame_count; S.item = i;
         streams.push_back(S); frame_sizes.push_back(h.frame_size);
         frames_total += h.frame_count; first_frame.push_back(frames_total);
         out_pos = align_up(out_pos + len, 64);
@@ -903,7 +962,12 @@ static int create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32
 }
 extern "C" int cri_job_create_hca_crypt(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t encrypt, uint32_t type,
                                         const uint64_t* keys, const uint16_t* subkeys, cri_job** job) {
-    return create_hca_crypt(blob, offsets, n, encrypt, type, keys, subkeys, nullptr, job);
+    if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
+    return create_hca_crypt(ItemSrc::from_blob(blob, offsets, n), encrypt, type, keys, subkeys, nullptr, job);
+}
+extern "C" int cri_job_create_hca_crypt_items(const cri_items* items, uint32_t encrypt, uint32_t type, const uint64_t* keys, const uint16_t* subkeys, cri_job** job) {
+    ItemSrc it; int rc = ItemSrc::from_items(items, it);
+    return rc ? rc : create_hca_crypt(it, encrypt, type, keys, subkeys, nullptr, job);
 }
 
 // ------------------------------------------------------------------------------------------------ HCA encode
@@ -913,18 +977,19 @@ static uint16_t crc_xpow_bytes(uint32_t nbytes) {            // x^(8*nbytes) mod
     return (uint16_t)v;
 }
 
-extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t force_no_looping, uint32_t quality, cri_job** out) {
-    if (!blob || !offsets || !out) return CRI_ERR_INVALID_ARG;
+static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint32_t quality, cri_job** out) {
+    const uint32_t n = it.n;
+    if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
-    cri_job* j = new_job(CRI_JOB_HCA_ENCODE, offsets, n);
+    cri_job* j = new_job(CRI_JOB_HCA_ENCODE, it);
     j->dominant = "k_hca_encode";
     std::vector<HcaFormat> formats; std::vector<HcaStream> streams;
     std::map<std::vector<uint32_t>, uint32_t> fmt_index;
     uint64_t out_pos = 0;
     for (uint32_t i = 0; i < n; i++) {
         j->out_offsets[i] = out_pos;
-        const uint8_t* d = blob + offsets[i];
-        size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+        const uint8_t* d = it.ptr(i);
+        size_t len = it.len(i);
         WavInfo w;
         int rc = wav_parse(d, len, w);
         if (rc) { j->host_status[i] = rc; continue; }
@@ -951,7 +1016,7 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
         hca_pack_header(e, head.bytes.data());
         j->images.push_back(std::move(head));
         HcaStream S; memset(&S, 0, sizeof S);
-        S.src_offset = offsets[i] + w.data_offset; S.dst_offset = out_pos + e.header_size; S.format = fidx; S.frames = e.frame_count;
+        S.src_offset = it.off(i) + w.data_offset; S.dst_offset = out_pos + e.header_size; S.format = fidx; S.frames = e.frame_count;
         S.samples = e.samples_per_channel; S.item = i;
         if (looping) {
             const uint32_t have = w.column_size / w.channels;
@@ -959,7 +1024,7 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
             S.enc_loop = 1; S.enc_pre = e.pre_samples; S.enc_pre_zero = e.pre_samples > 1024 ? ((e.pre_samples - 1) / 1024) * 1024 : 0;
             S.enc_post = e.post_samples; S.enc_loop_src = e.loop_start; S.enc_loop_src_end = std::min(seen_end, have); S.enc_have = have;
         }
-        if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(offsets[i] + w.data_offset, w); S.src_in_scratch = 1; }
+        if (!wav_is_pcm16(w)) { S.src_offset = j->add_convert(it.off(i) + w.data_offset, w); S.src_in_scratch = 1; }
         streams.push_back(S);
         out_pos = align_up(out_pos + e.header_size + (uint64_t)e.frame_count * e.frame_size, 64);
         j->units += e.frame_count;
@@ -994,6 +1059,15 @@ extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* of
     if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     *out = j;
     return 0;
+}
+
+extern "C" int cri_job_create_hca_encode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, uint32_t force_no_looping, uint32_t quality, cri_job** out) {
+    if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
+    return create_hca_encode(ItemSrc::from_blob(blob, offsets, n), force_no_looping, quality, out);
+}
+extern "C" int cri_job_create_hca_encode_items(const cri_items* items, uint32_t force_no_looping, uint32_t quality, cri_job** out) {
+    ItemSrc it; int rc = ItemSrc::from_items(items, it);
+    return rc ? rc : create_hca_encode(it, force_no_looping, quality, out);
 }
 
 // ------------------------------------------------------------------------------------------------ run
@@ -1076,6 +1150,24 @@ extern "C" int cri_job_run_floats(cri_job* j, const void* d_in, void* d_out, voi
 }
 extern "C" uint64_t cri_job_float_count(const cri_job* j) { return j && !j->float_offsets.empty() ? j->float_offsets.back() : 0; }
 extern "C" const uint64_t* cri_job_float_offsets(const cri_job* j) { return j && !j->float_offsets.empty() ? j->float_offsets.data() : nullptr; }
+
+// Layout of an HCA decode job's frame records in scratch, per format group (= per launch set): lets a caller take a census of
+// the record forms a run used (bench.py reports it next to the throughput) without knowing cri_types.h.
+extern "C" int cri_job_hca_groups(const cri_job* j, cri_hca_group_info* out, int cap) {
+    if (!j || j->kind != CRI_JOB_HCA_DECODE) return 0;
+    int n = 0;
+    for (const auto& a : j->hca_dec) {
+        if (out && n < cap) {
+            cri_hca_group_info g; memset(&g, 0, sizeof g);
+            g.channels = a.channels; g.frames = a.frames; g.record_bytes = hca_record_bytes(a.channels);
+            g.flags_offset = HCA_REC_TAIL(a.channels) + 8; g.narrow_flag = HCA_REC_NARROW; g.narrow_capable = a.narrow;
+            g.plain = a.plain; g.first_record_offset = j->hca_group_first_record[n];
+            out[n] = g;
+        }
+        n++;
+    }
+    return n;
+}
 
 extern "C" int cri_job_enable_events(cri_job* j, int on) {
     if (!j) return CRI_ERR_INVALID_ARG;
@@ -1189,7 +1281,7 @@ extern "C" int cri_hca_decode(const uint8_t* hca, size_t len, uint32_t header_si
     if (!hca || !out || !out_len) return CRI_ERR_INVALID_ARG;
     uint64_t offs[2] = {0, len};
     cri_job* j = nullptr;
-    int rc = create_hca_decode(hca, offs, 1, &key, &subkey, &header_size, &j);
+    int rc = create_hca_decode(ItemSrc::from_blob(hca, offs, 1), &key, &subkey, &header_size, &j);
     if (rc) return rc;
     size_t item = 0;
     if (!j->host_status[0]) item = (size_t)(le32(j->images[0].bytes.data() + 4) + 8);
@@ -1202,7 +1294,7 @@ extern "C" int cri_hca_crypt(uint8_t* hca, size_t len, uint32_t encrypt, uint32_
     if (!hca) return CRI_ERR_INVALID_ARG;
     uint64_t offs[2] = {0, len};
     cri_job* j = nullptr;
-    int rc = create_hca_crypt(hca, offs, 1, encrypt, type, &key, &subkey, &header_size, &j);
+    int rc = create_hca_crypt(ItemSrc::from_blob(hca, offs, 1), encrypt, type, &key, &subkey, &header_size, &j);
     if (rc) return rc;
     uint8_t* res = nullptr; size_t n = 0;
     rc = run_single(j, hca, &res, &n, len);
