@@ -20,9 +20,10 @@ Every output of every timed batch is verified after the timed region, not item 0
 for byte, with the CPU oracle's result for the unique input it is a copy of (so offsets past 4 GiB and 16 GiB are covered).
 
 The batches are tilings of `--unique` distinct seeded inputs produced with the CPU oracle; every copy occupies its own HBM.
---data picks the signal family: tonal (sines + noise floor: every HCA frame qualifies for the int8 record form), wide
-(full-scale noise / square / clicks: wide bands, int16 records) or mixed (alternating).  "data" in the line says which, and
-the record-form census of the run is in config.record_forms.
+--data picks the signal family (family_pcm): tonal (sines + noise floor: every HCA frame qualifies for the int8 record form),
+sparse (clean narrow-band material: bands of resolution 12..15, int16 records), noise (full-scale broadband material) or
+mixed (tonal and sparse alternating).  "data" in the line says which, and the record-form census of the run is in
+config.record_forms.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the launch stream inside
 the timed steps, plus the end-to-end figure (algorithmic bytes / step time); `cpu_baseline` is the real reference
@@ -54,29 +55,54 @@ def log(*a):
 
 # ------------------------------------------------------------------------------------------------ synthetic inputs
 def family_pcm(seed, n, ch, sr, family):
-    """(n, ch) int16.  tonal = pycricodecs_amd.synth; wide = full-scale material, four kinds by seed:
-    white noise, +-full-scale square noise, sparse clicks on a noise floor, loud detuned tones + noise."""
+    """(n, ch) int16 of one of the signal families:
+      tonal   pycricodecs_amd.synth: two sines + a noise floor per channel.  The encoder spends its bits on
+              many bands: resolutions stay <= 11, i.e. every symbol fits 8 bits -> int8 frame records.
+      sparse  sparse spectra (one loud sine, two sines, a quiet sine, low-passed noise; by seed): few bands get all the
+              bits, resolutions 12..15 (up to 12-bit symbols) -> int16 frame records.  What clean tonal material does.
+      noise   full-scale material (white noise, +-full-scale square noise, clicks on a noise floor, loud tones in noise):
+              every band is loud, the noise level is high, resolutions are low -> int8 records, maximal symbol count.
+      mixed   tonal and sparse alternating by seed (tiles hold both record forms)."""
     import numpy as np
     from pycricodecs_amd import synth
-    if family == "tonal" or (family == "mixed" and seed % 2 == 0):
+    if family == "mixed":
+        family = "tonal" if seed % 2 == 0 else "sparse"
+        seed //= 2
+    if family == "tonal":
         return synth.pcm16(seed, n, ch, sr)
     rng = np.random.default_rng(10_000 + seed)
-    kind = (seed // (2 if family == "mixed" else 1)) % 4
-    if kind == 0:
-        x = rng.integers(-32768, 32768, (n, ch))
-    elif kind == 1:
-        x = rng.integers(0, 2, (n, ch)) * 65535 - 32768
-    elif kind == 2:
-        x = rng.normal(0, 300, (n, ch))
-        idx = rng.integers(0, n, max(1, n // 40))
-        x[idx] = rng.integers(-32768, 32768, (len(idx), ch))
+    kind = seed % 4
+    t = np.arange(n)[:, None] / sr
+    if family == "sparse":
+        f1, f2 = rng.uniform(200, 4000), rng.uniform(4000, 12000)
+        ph = np.arange(ch)[None, :] * 0.7
+        if kind == 0:
+            x = 0.9 * 32767 * np.sin(2 * np.pi * f1 * t + ph)
+        elif kind == 1:
+            x = 0.45 * 32767 * (np.sin(2 * np.pi * f1 * t + ph) + np.sin(2 * np.pi * f2 * t))
+        elif kind == 2:
+            x = 0.05 * 32767 * np.sin(2 * np.pi * f1 * t + ph)
+        else:
+            X = np.fft.rfft(rng.normal(0, 1, (n, ch)), axis=0)
+            X[len(X) // 20:] = 0
+            x = np.fft.irfft(X, n, axis=0)
+            x = x / np.abs(x).max() * 30000
     else:
-        t = np.arange(n)[:, None] / sr
-        x = sum(9000.0 * np.sin(2 * np.pi * f * t + c) for c, f in enumerate(rng.uniform(200, 18000, 6))) + rng.normal(0, 4000, (n, ch))
+        assert family == "noise", family
+        if kind == 0:
+            x = rng.integers(-32768, 32768, (n, ch))
+        elif kind == 1:
+            x = rng.integers(0, 2, (n, ch)) * 65535 - 32768
+        elif kind == 2:
+            x = rng.normal(0, 300, (n, ch))
+            idx = rng.integers(0, n, max(1, n // 40))
+            x[idx] = rng.integers(-32768, 32768, (len(idx), ch))
+        else:
+            x = sum(9000.0 * np.sin(2 * np.pi * f * t + c) for c, f in enumerate(rng.uniform(200, 18000, 6))) + rng.normal(0, 4000, (n, ch))
     # quadratic fade-in over 512 samples, as in synth.pcm16: an ADX file whose FIRST block needs a scale >= 0x100 is one the
     # reference's own decoder rejects (its 7-byte "(c)CRI" compare runs into the scale word, adx.cpp:345-348)
     m = min(512, n)
-    x = x.astype(np.float64)
+    x = np.asarray(x, dtype=np.float64)
     x[:m] *= ((np.arange(m) / 512.0) ** 2)[:, None]
     return np.clip(np.round(x), -32768, 32767).astype(np.int16)
 
@@ -459,7 +485,7 @@ def secondary_measurements(args, D):
     n = args.secondary_streams
     uq = min(args.unique, 16)
     out = {}
-    for label, q, fam in (("hca_decode_wide_bands", 1, "wide"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_middle", 2, "tonal"),
+    for label, q, fam in (("hca_decode_sparse_spectra", 1, "sparse"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_noise", 1, "noise"), ("hca_decode_middle", 2, "tonal"),
                           ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
         r = hca_decode_run(D, n, uq, args.seconds, q, fam, 3, 1)
         out[label] = {"workload": "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (n, args.seconds, QNAME[q], fam),
@@ -527,7 +553,7 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="items per GPU (default: 10000; adx_roundtrip 1000)")
     ap.add_argument("--unique", type=int, default=None, help="distinct inputs tiled to --streams (default 64; hca_encode 16)")
     ap.add_argument("--seconds", type=float, default=None, help="seconds per item (default 10; hca_encode 30)")
-    ap.add_argument("--data", default="tonal", choices=["tonal", "wide", "mixed"], help="signal family of the synthetic inputs")
+    ap.add_argument("--data", default="tonal", choices=["tonal", "sparse", "noise", "mixed"], help="signal family of the synthetic inputs (see family_pcm)")
     ap.add_argument("--quality", type=int, default=1, help="HCA quality: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR), 4 Lowest")
     ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
     ap.add_argument("--no-cpu", action="store_true")
@@ -593,7 +619,8 @@ def main():
     out = dict(common, metric="audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline", value=round(units * D.world / dt, 1), unit="frames/s",
                ms_per_step=round(dt * 1e3, 3), dtype=dtype,
                data="synthetic, %s family (%s); %d unique inputs tiled to %d, each copy in its own HBM" % (
-                   args.data, {"tonal": "seeded sines + noise floor", "wide": "full-scale noise / square / clicks / loud tones", "mixed": "tonal and wide alternating"}[args.data], unique, streams),
+                   args.data, {"tonal": "seeded sines + noise floor", "sparse": "pure / sparse tones and low-passed noise", "noise": "full-scale noise / square / clicks / loud tones in noise",
+                               "mixed": "tonal and sparse alternating"}[args.data], unique, streams),
                config=cfg, roofline=roof)
     # other rows of the same hot path and the host-core baseline: single-GPU run only (ranks of a scaling run must not wait)
     if D.rank == 0 and D.world == 1 and wl == "hca_decode" and not args.no_secondary:

@@ -326,6 +326,8 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
     std::stable_sort(streams.begin(), streams.end(), [](const HcaStream& a, const HcaStream& b) { return a.format < b.format; });
     uint64_t scratch = 0;
     j->n_cipher = (uint32_t)(cipher.size() / 256);
+    bool cipher_identity = j->n_cipher <= 1;                  // one table, and it maps every byte to itself
+    for (size_t k = 0; k < cipher.size() && cipher_identity; k++) if (cipher[k] != (uint8_t)k) cipher_identity = false;
     for (size_t b = 0; b < streams.size();) {
         size_t e = b; uint32_t frames = 0, runs = 0;
         const HcaFormat& F = formats[streams[b].format];
@@ -337,14 +339,14 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         }
         HcaDecArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames; a.runs = runs;
-        a.n_cipher = j->n_cipher; a.rows = (F.frame_size + 3) / 4; a.channels = F.channels;
+        a.n_cipher = j->n_cipher; a.chunks = ((F.frame_size + 3) / 4 + 1 + 3) / 4; a.channels = F.channels;
+        a.cipher_identity = cipher_identity ? 1 : 0; a.in_bytes = j->in_bytes;
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.noise_fill = F.min_res == 0 ? 1 : 0;
         if (a.noise_fill) a.plain = 0;                                 // noise reconstruction lives in the general variant of the transform
         a.narrow = (a.plain && a.channels <= 2) ? 1 : 0;          // (k_hca_transform_plain<1>, <2> are the instances that read int8 lines)
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
-        a.prep_chunk_rows = std::min<uint32_t>(a.rows, 64);           // 16 KB of LDS per prepare wave
         j->hca_dec.push_back(a);
         j->hca_group_first_record.push_back(streams[b].scratch_offset);
         b = e;
@@ -353,7 +355,7 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
     for (auto& a : j->hca_dec) {
         scratch = align_up(scratch, 256);
         a.tile_offset = scratch;
-        scratch += (uint64_t)((a.frames + 63) / 64) * (a.rows + 1) * 256;
+        scratch += (uint64_t)((a.frames + 63) / 64) * a.chunks * 1024;
         a.fstat_offset = scratch;
         scratch += align_up((uint64_t)a.frames * 4, 256);
         a.resg_offset = scratch;

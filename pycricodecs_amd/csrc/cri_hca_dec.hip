@@ -21,6 +21,8 @@
 //                    (the DCT is the same register network); k_hca_noise_scan gives it the generator state each frame starts from.
 // All float work is single IEEE binary32 operations in the reference's order (compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "cri_kernels.h"
 #include "cri_device.h"
 #include "../../include/cricodecs_hip.h"
@@ -31,29 +33,31 @@
 namespace cri {
 
 // ------------------------------------------------------------------------------------------------------------
-// k_hca_prepare
+// k_hca_prepare: one lane per frame, no staging
 // ------------------------------------------------------------------------------------------------------------
-size_t hca_prepare_lds_bytes(uint32_t chunk_rows, uint32_t n_cipher) {
-    return (size_t)chunk_rows * 260 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256 + 16;
-}
+// A lane walks its own frame 16 bytes at a time (chunks of a frame are consecutive in memory, so the lines a wave touches
+// are re-used by its next loads out of L1 / L2), checksums and deciphers the four words in registers and stores them as one
+// uint4 into the tile: [tile][chunk][64 lanes] uint4, i.e. 1 KB contiguous per wave store, and 16 contiguous bytes per lane
+// for k_hca_parse's feed.  Loads run one group of HCA_PREP_GROUP chunks ahead.  No LDS besides the cipher tables, no barriers.
+//
+// CRC-16 (poly 0x8005, init 0, MSB first; hca.cpp:186-211) without a table and 32 message bits per step.  The frame is valid
+// iff its polynomial M(x) (CRC field included) is divisible by P = x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1):
+//   modulo x + 1          the remainder is the parity of M: one xor per word, one popcount at the end;
+//   modulo Q = x^15+x+1   x^15 = x + 1, hence x^32 = (x^15)^2 x^2 = (x^2 + 1) x^2 = x^4 + x^2: appending a word W to a running
+//                         value R gives T = W ^ R<<4 ^ R<<2, and one fold of T's bits from 15 up (T>>15 times x + 1) brings it
+//                         back under 18 bits.  R is only reduced completely at the end.
+// (hca.cpp:1159-1169 checks sync word and checksum, then deciphers: the checksum is over the bytes as stored.)
+#ifndef HCA_PREP_GROUP
+#define HCA_PREP_GROUP 4
+#endif
+#ifndef HCA_PREP_WAVES
+#define HCA_PREP_WAVES 8
+#endif
+size_t hca_prepare_lds_bytes(uint32_t n_cipher) { return (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256 + 16; }
 
-// CRC-16 (poly 0x8005, MSB first) byte step without a table: T[t] = t*x^16 mod P = parity(t)*0x8003 ^ (t<<1) ^ (t<<2)
-__device__ __forceinline__ uint32_t crc16_step(uint32_t crc, uint32_t b) {
-    uint32_t t = (crc >> 8) ^ b;
-    uint32_t tt = (t << 1) ^ (t << 2) ^ ((__builtin_popcount(t) & 1) ? 0x8003u : 0u);
-    return ((crc << 8) & 0xFFFF) ^ tt;
-}
-// the same for 16 message bits at once: crc' = t * x^16 mod P with t = crc ^ bits.  P = (x + 1)(x^15 + x + 1): modulo the
-// second factor x^16 = x^2 + x, so t * (x^2 + x) folds its three top bits back as h ^ h << 1; modulo x + 1 the remainder
-// is the parity of t, which decides whether x^15 + x + 1 (0x8003) is added.
-__device__ __forceinline__ uint32_t crc16_step16(uint32_t crc, uint32_t bits16) {
-    const uint32_t t = crc ^ bits16;
-    const uint32_t u = (t << 1) ^ (t << 2), h = u >> 15;
-    const uint32_t r = (u & 0x7FFF) ^ h ^ (h << 1);
-    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)__builtin_popcount(r ^ t), 0, 1);     // all ones if the parities differ
-    return r ^ (m & 0x8003u);
-}
-
+__device__ __forceinline__ uint32_t crcq_fold(uint32_t t) { const uint32_t h = t >> 15; return (t & 0x7FFFu) ^ h ^ (h << 1); }
+__device__ __forceinline__ uint32_t crcq_word(uint32_t r, uint32_t w_be) { return crcq_fold(w_be ^ (r << 4) ^ (r << 2)); }
+__device__ __forceinline__ uint32_t crcq_byte(uint32_t r, uint32_t b) { return crcq_fold((r << 8) ^ b); }   // x^8 needs no reduction: r < 2^18
 
 // Format parameters held in registers (scalar) for the whole kernel: reading them through the HcaFormat pointer inside the
 // loops would turn every use into a memory load.
@@ -75,103 +79,112 @@ __device__ __forceinline__ Fmt load_fmt(const HcaFormat* f) {
     return m;
 }
 
-__global__ __launch_bounds__(64) void k_hca_prepare(HcaDecArgs a) {
+__device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+
+template <bool IDENTITY>
+__global__ __launch_bounds__(64, HCA_PREP_WAVES) void k_hca_prepare(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const Fmt F = load_fmt(a.formats + a.format);
-    const uint32_t R = a.rows, RC = a.prep_chunk_rows, lane = threadIdx.x, tile = blockIdx.x;
-    const int fs = (int)F.frame_size;
-    uint32_t* rows = (uint32_t*)smem;
-    uint8_t* cipher_lds = smem + (size_t)RC * 260;       // rows are 65 words apart: lane-strided and row-strided accesses both spread over the banks
+    const uint32_t lane = threadIdx.x, tile = blockIdx.x, K = a.chunks;
+    const uint32_t fs = a.formats[a.format].frame_size;
+    uint8_t* cipher_lds = smem;
     const bool cipher_in_lds = a.n_cipher <= 16;
-    if (cipher_in_lds) for (uint32_t i = lane; i < a.n_cipher * 256; i += 64) cipher_lds[i] = a.cipher_tables[i];
+    if (!IDENTITY && cipher_in_lds) { for (uint32_t i = lane; i < a.n_cipher * 64; i += 64) ((uint32_t*)cipher_lds)[i] = ((const uint32_t*)a.cipher_tables)[i]; }
 
     const uint32_t g = tile * 64 + lane;
     const bool valid = g < a.frames;
     uint32_t si = a.stream_begin, f = 0;
     if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
     const HcaStream st = a.streams[si];
-    const uint8_t* src = a.in + st.src_offset + (uint64_t)f * (uint32_t)fs;
+    const uint8_t* src = a.in + st.src_offset + (uint64_t)f * fs;
     // padding lanes of the last tile load (and discard) the tile's first frame: lane 0 is always a real frame, whereas a
     // stream without frames at the start of the group may sit at the very end of the input blob
     if (!valid) src = (const uint8_t*)readlane64((uint64_t)src, 0);
+    const uint8_t* in_end = a.in + a.in_bytes;
     const uint8_t* ct = cipher_in_lds ? cipher_lds + st.cipher * 256 : a.cipher_tables + st.cipher * 256;
-    uint32_t* tb = (uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64;
-    uint32_t crc = 0;
-    int status = 0;
+    uint4* tb = (uint4*)(a.scratch + a.tile_offset) + (uint64_t)tile * K * 64 + lane;
     wave_lds_sync();
-    for (uint32_t r0 = 0; r0 < R; r0 += RC) {
-        const uint32_t nr = R - r0 < RC ? R - r0 : RC;
-        // coalesced staging: 256 contiguous bytes of one frame per wave load, 16 frames' loads in flight at a time
-        // (one load + one LDS write per frame in sequence made this kernel pay the HBM latency 64 times per chunk)
-        {
-            const uint32_t rr = r0 + lane;                                  // this lane's word of every frame (nr <= 64)
-            const bool whole = lane < nr && (int)(4 * rr + 4) <= fs, part = lane < nr && !whole && (int)(4 * rr) < fs;
-#pragma unroll 1
-            for (uint32_t fb = 0; fb < 64; fb += 16) {
-                uint32_t v[16];
+
+    // 16 bytes of the frame from byte 16*k on; bytes at or past the end of the input blob read as 0 (only the last frame of the
+    // blob can get there, and only in its last, partial chunk)
+    auto load_chunk = [&](uint32_t k) {
+        const uint8_t* p = src + 16 * k;
+        if (__builtin_expect(p + 16 <= in_end, 1)) return ld_u128_unaligned(p);
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++) if (p + i < in_end) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    auto decipher = [&](uint32_t raw) {                       // -> big-endian word of the deciphered bytes
+        if (IDENTITY) return __builtin_bswap32(raw);
+        uint32_t be = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) {
-                    const bool fv = __builtin_amdgcn_readlane((int)valid, fb + k) != 0;
-                    const uint8_t* p = (const uint8_t*)readlane64((uint64_t)src, fb + k);
-                    const uint32_t w = ld_u32_unaligned(p + 4 * (whole ? rr : 0u));     // always a readable address (the tile's first frame for padding lanes)
-                    v[k] = fv && whole ? w : 0u;
-                }
-                if (__any(part)) {                                          // the last, partial word of a frame (frame_size % 4 != 0)
-#pragma unroll 1
-                    for (uint32_t k = 0; k < 16; k++) {
-                        const bool fv = __builtin_amdgcn_readlane((int)valid, fb + k) != 0;
-                        const uint8_t* p = (const uint8_t*)readlane64((uint64_t)src, fb + k);
-                        if (fv && part) { uint32_t t = 0; for (int q = 0; 4 * (int)rr + q < fs; q++) t |= (uint32_t)p[4 * rr + q] << (8 * q); v[k] = t; }
-                    }
-                }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b = (raw >> (8 * k)) & 0xFF;
+            be |= (cipher_in_lds ? (uint32_t)ct[b] : (uint32_t)__ldg(ct + b)) << (24 - 8 * k);
+        }
+        return be;
+    };
+    uint32_t r = 0, par = 0;
+    int status = 0;
+    const uint32_t kfull = fs >> 4;                           // chunks that lie entirely inside the frame
+    // a group of G chunks per visit, the next group's loads in flight while this one is processed: a lane then takes a whole
+    // run of G*16 bytes out of the cache lines it touches before other waves' traffic can push them out
+    constexpr uint32_t G = HCA_PREP_GROUP;
+    uint4 cur[G], nxt[G];
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) if (lane < nr) rows[lane * 65 + fb + k] = v[k];
+    for (uint32_t d = 0; d < G; d++) cur[d] = d < kfull ? load_chunk(d) : make_uint4(0, 0, 0, 0);
+    if (kfull) { if ((cur[0].x & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4); }          // hca.cpp:1162-1164
+    for (uint32_t k0 = 0; k0 < kfull; k0 += G) {
+#pragma unroll
+        for (uint32_t d = 0; d < G; d++) nxt[d] = k0 + G + d < kfull ? load_chunk(k0 + G + d) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t d = 0; d < G; d++) {
+            const uint32_t k = k0 + d;
+            if (k < kfull) {                                  // (wave-uniform)
+                const uint32_t w[4] = {cur[d].x, cur[d].y, cur[d].z, cur[d].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    r = crcq_word(r, __builtin_bswap32(w[j]));
+                    par ^= w[j];
+                    o[j] = decipher(w[j]);
+                }
+                tb[(uint64_t)k * 64] = valid ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
             }
         }
-        wave_lds_sync();
-        if (valid) {
-            for (uint32_t r = 0; r < nr; r++) {
-                const uint32_t raw = rows[r * 65 + lane];
-                uint32_t be = 0;
-                int nb = fs - 4 * (int)(r0 + r); nb = nb > 4 ? 4 : nb;
-                if (r0 + r == 0 && (raw & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4);   // hca.cpp:1162-1164
-                if (nb == 4) {                                    // (wave-uniform) whole word: the checksum takes 16 bits per step
-                    const uint32_t sw = __builtin_amdgcn_perm(raw, raw, 0x00010203u);     // bytes in stream order, first byte on top
-                    crc = crc16_step16(crc16_step16(crc, sw >> 16), sw & 0xFFFF);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t b = (raw >> (8 * k)) & 0xFF;
-                        const uint32_t d = cipher_in_lds ? ct[b] : __ldg(ct + b);
-                        be |= d << (24 - 8 * k);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (k < nb) {
-                            const uint32_t b = (raw >> (8 * k)) & 0xFF;
-                            crc = crc16_step(crc, b);
-                            const uint32_t d = cipher_in_lds ? ct[b] : __ldg(ct + b);
-                            be |= d << (24 - 8 * k);
-                        }
-                    }
-                }
-                rows[r * 65 + lane] = be;
-            }
-        }
-        wave_lds_sync();
-        for (uint32_t r = 0; r < nr; r++) tb[(uint64_t)(r0 + r) * 64 + lane] = rows[r * 65 + lane];
-        wave_lds_sync();
+        for (uint32_t d = 0; d < G; d++) cur[d] = nxt[d];
     }
-    tb[(uint64_t)R * 64 + lane] = 0;
+    // the partial chunk (frame_size % 16 bytes), byte by byte, and the zero chunks up to K (the parser's feed may read one word
+    // past the frame)
+    for (uint32_t k = kfull; k < K; k++) {
+        uint32_t o[4] = {0, 0, 0, 0};
+        if (16 * k < fs) {
+            const uint4 c = load_chunk(k);
+            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+            if (k == 0 && (w[0] & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4);
+            for (uint32_t i = 0; 16 * k + i < fs && i < 16; i++) {
+                const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                r = crcq_byte(r, b);
+                par ^= b;
+                const uint32_t dcp = IDENTITY ? b : (cipher_in_lds ? (uint32_t)ct[b] : (uint32_t)__ldg(ct + b));
+                o[i >> 2] |= dcp << (24 - 8 * (i & 3));
+            }
+        }
+        tb[(uint64_t)k * 64] = valid ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
+    }
     if (valid) {
-        if (status == 0 && crc != 0) status = CRI_ERR_HCA_FRAME(3);                            // hca.cpp:1166-1167
+        r = crcq_fold(r);                                     // < 2^15: the remainder modulo x^15 + x + 1
+        if (status == 0 && (r != 0 || (__builtin_popcount(par) & 1))) status = CRI_ERR_HCA_FRAME(3);   // hca.cpp:1166-1167
         ((int32_t*)(a.scratch + a.fstat_offset))[g] = status;
     }
 }
 
 void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
-    hipLaunchKernelGGL(k_hca_prepare, dim3((a.frames + 63) / 64), dim3(64), hca_prepare_lds_bytes(a.prep_chunk_rows, a.n_cipher), s, a);
+    // (experiments: CRI_PREP_LDS_KB pads the LDS request to cap the waves per CU)
+    static const size_t pad = getenv("CRI_PREP_LDS_KB") ? (size_t)atoi(getenv("CRI_PREP_LDS_KB")) * 1024 : 0;
+    if (a.cipher_identity) hipLaunchKernelGGL(k_hca_prepare<true>, dim3((a.frames + 63) / 64), dim3(64), std::max<size_t>(16, pad), s, a);
+    else hipLaunchKernelGGL(k_hca_prepare<false>, dim3((a.frames + 63) / 64), dim3(64), std::max(hca_prepare_lds_bytes(a.n_cipher), pad), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -183,22 +196,24 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
 // 16-band block, written once by the scalefactor pass and re-read (coalesced, L2-resident) by each of the 8 subframes.
 //
 // Bit feed.  HBM latency under load is microseconds and the parse is an in-order serial chain, so words travel
-//   tile (global) --bulk request at a checkpoint--> VGPRs --landed at the NEXT checkpoint--> per-lane LDS ring
+//   tile (global) --16-byte chunk requested at a checkpoint--> VGPRs --landed at the NEXT checkpoint--> per-lane LDS ring
 //   --one word prefetched per symbol--> 64-bit shift register.
-// Checkpoints sit every 16 symbols (at most 16*12 bits = 6 words consumed in between); a checkpoint requests up to
-// FEED_MAX = 6 words to refill the ring to RING_WORDS = 16, so after landing the ring always holds >= 10 words.
-#define RING_WORDS 16       // (+ one spare row: the sink of feed_land)
-#define FEED_MAX 6
-size_t hca_parse_lds_bytes(uint32_t channels) { (void)channels; return (size_t)(RING_WORDS + 1) * 256 + 16 * 66 * 4 + 96; }
+// Checkpoints sit every 16 symbols (at most 16*12 bits = 6 words consumed in between).  A checkpoint asks for as many whole
+// chunks (4 words; k_hca_prepare lays a frame's words out as one uint4 per chunk and lane) as the ring has room for, at most
+// two: with h words in the ring after landing, r = min(8, 4*floor((16-h)/4)) are requested and c <= 6 consumed before they
+// land, so h' = h - c + r >= 7 whenever h >= 7, and h' <= 16.  The second chunk is rare (a lane that burned > 4 words in one
+// block) and sits behind a wave-uniform branch.
+#define RING_WORDS 16       // (+ 4 spare rows: the sink of a lane that lands nothing)
+size_t hca_parse_lds_bytes(uint32_t channels) { (void)channels; return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96; }
 
 struct BitFeed {
-    const uint32_t* next;    // next word of this lane in the tile (stride 64 words)
-    int rows_left;           // words not yet requested from the tile
+    const uint4* next;       // next chunk of this lane in the tile (stride 64 uint4)
+    int chunks_left;         // chunks of the frame not yet requested (requests past the frame land zeros)
     uint32_t* ring;          // LDS ring base of this lane (slot stride 64 words)
-    uint32_t wr;             // words landed in the ring
-    uint32_t nfl;            // words in flight
-    uint32_t live;           // bit k: fl[k] is a word of the frame (otherwise it reads as 0: past the frame end)
-    uint32_t fl[FEED_MAX];
+    uint32_t wr;             // words landed in the ring (a multiple of 4)
+    uint32_t nfl;            // chunks in flight: 0, 1 or 2
+    uint32_t live;           // bit k: chunk k in flight is part of the frame (otherwise it lands as zeros)
+    uint4 fl0, fl1;
 };
 struct BitBuf {
     uint32_t hi, lo;         // frame words k and k+1 (big-endian): a 64-bit window the reader moves through
@@ -209,27 +224,29 @@ struct BitBuf {
     uint32_t nw;             // frame word k + 2 (LDS read issued one refill earlier)
 };
 
-// A checkpoint is two halves with the pending record stores in between (see PendingFlush): the loads asked for at the
-// previous checkpoint land in the ring, the stores of the last two blocks go out, the next loads are asked for.  vmcnt
+// A checkpoint is two halves with the pending record stores in between (see PendingFlush): the chunks asked for at the
+// previous checkpoint land in the ring, the stores of the last two blocks go out, the next chunks are asked for.  vmcnt
 // counts loads and stores together and in order, so the wait at the next checkpoint covers those stores too -- by then
-// they have had a whole block of parsing to complete.  Both halves are branch-free: a word that was not asked for is
-// parked in the ring's spare row, a load past the lane's frame reads a word nobody uses.
+// they have had a whole block of parsing to complete.
+__device__ __forceinline__ void feed_land_chunk(BitFeed& f, const uint4& c, uint32_t k) {
+    const bool on = k < f.nfl, zero = !((f.live >> k) & 1);
+    uint32_t* slot = f.ring + (on ? ((f.wr + 4 * k) & (RING_WORDS - 1)) : (uint32_t)RING_WORDS) * 64;
+    slot[0] = zero ? 0u : c.x; slot[64] = zero ? 0u : c.y; slot[128] = zero ? 0u : c.z; slot[192] = zero ? 0u : c.w;
+}
 __device__ __forceinline__ void feed_land(BitFeed& f) {
-#pragma unroll
-    for (uint32_t k = 0; k < FEED_MAX; k++) {
-        const bool on = k < f.nfl;
-        f.ring[(on ? ((f.wr + k) & (RING_WORDS - 1)) : (uint32_t)RING_WORDS) * 64] = ((f.live >> k) & 1) ? f.fl[k] : 0u;
-    }
-    f.wr += f.nfl;
+    feed_land_chunk(f, f.fl0, 0);
+    if (__any(f.nfl > 1)) feed_land_chunk(f, f.fl1, 1);
+    f.wr += 4 * f.nfl;
 }
 __device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b) {
     const uint32_t room = RING_WORDS - (f.wr - b.rd);
-    const uint32_t n = room < FEED_MAX ? room : FEED_MAX;
-    const int adv = (int)n < f.rows_left ? (int)n : f.rows_left;                 // words of the frame among the n (the rest read as 0)
-#pragma unroll
-    for (uint32_t k = 0; k < FEED_MAX; k++) f.fl[k] = f.next[((int)k < adv ? k : 0u) * 64];
-    f.live = (1u << adv) - 1;
-    f.next += (size_t)adv * 64; f.rows_left -= adv;
+    const uint32_t n = room >> 2 > 2 ? 2u : room >> 2;                          // chunks asked for
+    const int have = f.chunks_left;
+    f.live = have >= 2 ? 3u : (uint32_t)have;                                   // (have is 0, 1, or more)
+    if (n > 0) f.fl0 = f.next[0];                                               // past the frame these read the next lanes' / tiles' words
+    if (__any(n > 1)) { if (n > 1) f.fl1 = f.next[64]; }                        //   (inside scratch) and are landed as zeros
+    const int adv = (int)n < have ? (int)n : have;
+    f.next += (size_t)adv * 64; f.chunks_left = have - adv;
     f.nfl = n;
 }
 __device__ __forceinline__ void feed_checkpoint(BitFeed& f, const BitBuf& b) { feed_land(f); feed_request(f, b); }
@@ -330,9 +347,9 @@ struct PendingFlush {
 __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
-    const uint32_t R = a.rows, C = F.channels, lane = threadIdx.x, tile = blockIdx.x;
-    uint32_t* ring = (uint32_t*)smem + lane;           // [RING_WORDS + 1][64]
-    uint32_t* ostage = (uint32_t*)(smem + (RING_WORDS + 1) * 256);   // [16][OST]
+    const uint32_t C = F.channels, lane = threadIdx.x, tile = blockIdx.x;
+    uint32_t* ring = (uint32_t*)smem + lane;           // [RING_WORDS + 4][64]
+    uint32_t* ostage = (uint32_t*)(smem + (RING_WORDS + 4) * 256);   // [16][OST]
     uint8_t* curve = (uint8_t*)(ostage + 16 * OST);    // 96 bytes reserved
     for (uint32_t i = lane; i < 66; i += 64) curve[i] = HCA_CURVE_TO_RES[i];
 
@@ -350,11 +367,20 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 
     PendingFlush pend; pend.set(0, 0);
     BitFeed fd;
-    fd.next = (const uint32_t*)(a.scratch + a.tile_offset) + (uint64_t)tile * (R + 1) * 64 + lane;
-    fd.rows_left = (int)R + 1; fd.ring = ring; fd.wr = 0; fd.nfl = 0; fd.live = 0;
+    fd.next = (const uint4*)(a.scratch + a.tile_offset) + (uint64_t)tile * a.chunks * 64 + lane;
+    fd.chunks_left = (int)a.chunks; fd.ring = ring; fd.wr = 0; fd.nfl = 0; fd.live = 0;
     BitBuf bb;
     bb.hi = 0; bb.lo = 0; bb.off = 0; bb.pos = 0; bb.size = (int)F.frame_size * 8; bb.rd = 0; bb.nw = 0;
-    feed_checkpoint(fd, bb); feed_checkpoint(fd, bb); feed_checkpoint(fd, bb);   // prime: 12 words landed, 4 in flight
+    {   // prime: the ring's 16 words (the words of a frame shorter than that are followed by zeros)
+#pragma unroll
+        for (uint32_t k = 0; k < RING_WORDS / 4; k++) {
+            const bool in = (int)k < fd.chunks_left;
+            const uint4 c = fd.next[in ? k * 64 : 0];
+            ring[(4 * k) * 64] = in ? c.x : 0u; ring[(4 * k + 1) * 64] = in ? c.y : 0u; ring[(4 * k + 2) * 64] = in ? c.z : 0u; ring[(4 * k + 3) * 64] = in ? c.w : 0u;
+        }
+        const int adv = fd.chunks_left < RING_WORDS / 4 ? fd.chunks_left : RING_WORDS / 4;
+        fd.next += (size_t)adv * 64; fd.chunks_left -= adv; fd.wr = RING_WORDS;
+    }
     bb.hi = ring[0]; bb.lo = ring[64]; bb.nw = ring[128]; bb.rd = 2;
     bb_skip(bb, 16);                                             // sync word, checked by k_hca_prepare
     uint32_t packed = 0, flags = 0, draws = 0, wide_bits = 0;

@@ -116,13 +116,20 @@ def test_device_floats_vs_oracle(cc, ch, q, v3):
     job = Job.hca_decode(items)
     outs, status, (d_f, offs) = run_job(job, floats=True)
     fl = d_f.cpu().numpy()
-    assert not status.any()
+    good = 0
     for i, h in enumerate(items):
-        ref = O.hca_decode_float(h)
+        try:
+            ref = O.hca_decode_float(h)
+        except O.OracleError:                                  # (a forged v3.0 header on frames of another layout: both sides reject it)
+            assert status[i] != 0, i
+            continue
+        assert status[i] == 0, i
+        good += 1
         mine = fl[int(offs[i]):int(offs[i + 1])]
         assert mine.size == ref.size
         assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), (i, int(np.argmax(mine.view(np.uint32) != ref.view(np.uint32))))
         assert outs[i] == O.hca_decode(h)
+    assert good >= 2
 
 
 def test_device_floats_random_frames(cc):
