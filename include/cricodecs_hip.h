@@ -221,7 +221,7 @@ const char* cri_job_dominant_kernel(const cri_job* job);
 /* Per-kernel timing with HIP events recorded on the run's own stream.  After cri_job_enable_events(job, 1) every
  * cri_job_run brackets each kernel class with events; cri_job_event_ms waits for the last run and returns the
  * elapsed milliseconds per class (summed over the job's launches of that class) and the class names.
- * Classes: HCA decode {k_hca_unpack, k_hca_transform}; other jobs have one class.  Returns the class count. */
+ * Classes: HCA decode {k_hca_parse, k_hca_transform}; other jobs have one class.  Returns the class count. */
 int cri_job_enable_events(cri_job* job, int on);
 int cri_job_event_ms(cri_job* job, float* ms, const char** names, int max_classes);
 

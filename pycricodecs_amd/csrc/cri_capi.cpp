@@ -339,7 +339,7 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         }
         HcaDecArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames; a.runs = runs;
-        a.n_cipher = j->n_cipher; a.chunks = ((F.frame_size + 3) / 4 + 1 + 3) / 4; a.channels = F.channels;
+        a.n_cipher = j->n_cipher; a.channels = F.channels;
         a.cipher_identity = cipher_identity ? 1 : 0; a.in_bytes = j->in_bytes;
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.noise_fill = F.min_res == 0 ? 1 : 0;
@@ -351,13 +351,9 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         j->hca_group_first_record.push_back(streams[b].scratch_offset);
         b = e;
     }
-    // word tiles and per-frame prepare status of every format group follow the frame records
+    // the band code descriptions of every format group follow the frame records
     for (auto& a : j->hca_dec) {
         scratch = align_up(scratch, 256);
-        a.tile_offset = scratch;
-        scratch += (uint64_t)((a.frames + 63) / 64) * a.chunks * 1024;
-        a.fstat_offset = scratch;
-        scratch += align_up((uint64_t)a.frames * 4, 256);
         a.resg_offset = scratch;
         scratch += (uint64_t)((a.frames + 63) / 64) * a.channels * 8 * 64 * 16;
     }
@@ -1094,9 +1090,8 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p;
                 a.float_out = d_floats;
-                j->mark(0, true, s); launch_hca_prepare(a, s); j->mark(0, false, s);
-                j->mark(1, true, s); launch_hca_parse(a, s); j->mark(1, false, s);
-                j->mark(2, true, s); launch_hca_transform(a, s); j->mark(2, false, s);
+                j->mark(0, true, s); launch_hca_parse(a, s); j->mark(0, false, s);
+                j->mark(1, true, s); launch_hca_transform(a, s); j->mark(1, false, s);
             }
             break;
         case CRI_JOB_ADX_DECODE:
@@ -1174,7 +1169,7 @@ extern "C" int cri_job_hca_groups(const cri_job* j, cri_hca_group_info* out, int
 extern "C" int cri_job_enable_events(cri_job* j, int on) {
     if (!j) return CRI_ERR_INVALID_ARG;
     if (j->class_names.empty()) {
-        if (j->kind == CRI_JOB_HCA_DECODE) j->class_names = {"k_hca_prepare", "k_hca_parse", "k_hca_transform"};
+        if (j->kind == CRI_JOB_HCA_DECODE) j->class_names = {"k_hca_parse", "k_hca_transform"};
         else j->class_names = {j->dominant};
         j->class_events.resize(j->class_names.size());
         j->class_used.assign(j->class_names.size(), 0);

@@ -33,12 +33,11 @@
 namespace cri {
 
 // ------------------------------------------------------------------------------------------------------------
-// k_hca_prepare: one lane per frame, no staging
+// frame intake: sync word, checksum, decipher (the head of clHCA_DecodeBlock_unpack, hca.cpp:1159-1169)
 // ------------------------------------------------------------------------------------------------------------
-// A lane walks its own frame 16 bytes at a time (chunks of a frame are consecutive in memory, so the lines a wave touches
-// are re-used by its next loads out of L1 / L2), checksums and deciphers the four words in registers and stores them as one
-// uint4 into the tile: [tile][chunk][64 lanes] uint4, i.e. 1 KB contiguous per wave store, and 16 contiguous bytes per lane
-// for k_hca_parse's feed.  Loads run one group of HCA_PREP_GROUP chunks ahead.  No LDS besides the cipher tables, no barriers.
+// There is no separate pass over the compressed frames: k_hca_parse's bit feed takes its lane's frame from the input blob 16
+// bytes at a time and checksums and deciphers the four words on their way into the lane's LDS ring (feed_land), so the
+// deciphered words never exist in HBM.
 //
 // CRC-16 (poly 0x8005, init 0, MSB first; hca.cpp:186-211) without a table and 32 message bits per step.  The frame is valid
 // iff its polynomial M(x) (CRC field included) is divisible by P = x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1):
@@ -46,15 +45,7 @@ namespace cri {
 //   modulo Q = x^15+x+1   x^15 = x + 1, hence x^32 = (x^15)^2 x^2 = (x^2 + 1) x^2 = x^4 + x^2: appending a word W to a running
 //                         value R gives T = W ^ R<<4 ^ R<<2, and one fold of T's bits from 15 up (T>>15 times x + 1) brings it
 //                         back under 18 bits.  R is only reduced completely at the end.
-// (hca.cpp:1159-1169 checks sync word and checksum, then deciphers: the checksum is over the bytes as stored.)
-#ifndef HCA_PREP_GROUP
-#define HCA_PREP_GROUP 4
-#endif
-#ifndef HCA_PREP_WAVES
-#define HCA_PREP_WAVES 8
-#endif
-size_t hca_prepare_lds_bytes(uint32_t n_cipher) { return (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256 + 16; }
-
+// (the checksum is over the bytes as stored, before the decipher.)
 __device__ __forceinline__ uint32_t crcq_fold(uint32_t t) { const uint32_t h = t >> 15; return (t & 0x7FFFu) ^ h ^ (h << 1); }
 __device__ __forceinline__ uint32_t crcq_word(uint32_t r, uint32_t w_be) { return crcq_fold(w_be ^ (r << 4) ^ (r << 2)); }
 __device__ __forceinline__ uint32_t crcq_byte(uint32_t r, uint32_t b) { return crcq_fold((r << 8) ^ b); }   // x^8 needs no reduction: r < 2^18
@@ -81,112 +72,6 @@ __device__ __forceinline__ Fmt load_fmt(const HcaFormat* f) {
 
 __device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 
-template <bool IDENTITY>
-__global__ __launch_bounds__(64, HCA_PREP_WAVES) void k_hca_prepare(HcaDecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t lane = threadIdx.x, tile = blockIdx.x, K = a.chunks;
-    const uint32_t fs = a.formats[a.format].frame_size;
-    uint8_t* cipher_lds = smem;
-    const bool cipher_in_lds = a.n_cipher <= 16;
-    if (!IDENTITY && cipher_in_lds) { for (uint32_t i = lane; i < a.n_cipher * 64; i += 64) ((uint32_t*)cipher_lds)[i] = ((const uint32_t*)a.cipher_tables)[i]; }
-
-    const uint32_t g = tile * 64 + lane;
-    const bool valid = g < a.frames;
-    uint32_t si = a.stream_begin, f = 0;
-    if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
-    const HcaStream st = a.streams[si];
-    const uint8_t* src = a.in + st.src_offset + (uint64_t)f * fs;
-    // padding lanes of the last tile load (and discard) the tile's first frame: lane 0 is always a real frame, whereas a
-    // stream without frames at the start of the group may sit at the very end of the input blob
-    if (!valid) src = (const uint8_t*)readlane64((uint64_t)src, 0);
-    const uint8_t* in_end = a.in + a.in_bytes;
-    const uint8_t* ct = cipher_in_lds ? cipher_lds + st.cipher * 256 : a.cipher_tables + st.cipher * 256;
-    uint4* tb = (uint4*)(a.scratch + a.tile_offset) + (uint64_t)tile * K * 64 + lane;
-    wave_lds_sync();
-
-    // 16 bytes of the frame from byte 16*k on; bytes at or past the end of the input blob read as 0 (only the last frame of the
-    // blob can get there, and only in its last, partial chunk)
-    auto load_chunk = [&](uint32_t k) {
-        const uint8_t* p = src + 16 * k;
-        if (__builtin_expect(p + 16 <= in_end, 1)) return ld_u128_unaligned(p);
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 16; i++) if (p + i < in_end) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    };
-    auto decipher = [&](uint32_t raw) {                       // -> big-endian word of the deciphered bytes
-        if (IDENTITY) return __builtin_bswap32(raw);
-        uint32_t be = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t b = (raw >> (8 * k)) & 0xFF;
-            be |= (cipher_in_lds ? (uint32_t)ct[b] : (uint32_t)__ldg(ct + b)) << (24 - 8 * k);
-        }
-        return be;
-    };
-    uint32_t r = 0, par = 0;
-    int status = 0;
-    const uint32_t kfull = fs >> 4;                           // chunks that lie entirely inside the frame
-    // a group of G chunks per visit, the next group's loads in flight while this one is processed: a lane then takes a whole
-    // run of G*16 bytes out of the cache lines it touches before other waves' traffic can push them out
-    constexpr uint32_t G = HCA_PREP_GROUP;
-    uint4 cur[G], nxt[G];
-#pragma unroll
-    for (uint32_t d = 0; d < G; d++) cur[d] = d < kfull ? load_chunk(d) : make_uint4(0, 0, 0, 0);
-    if (kfull) { if ((cur[0].x & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4); }          // hca.cpp:1162-1164
-    for (uint32_t k0 = 0; k0 < kfull; k0 += G) {
-#pragma unroll
-        for (uint32_t d = 0; d < G; d++) nxt[d] = k0 + G + d < kfull ? load_chunk(k0 + G + d) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (uint32_t d = 0; d < G; d++) {
-            const uint32_t k = k0 + d;
-            if (k < kfull) {                                  // (wave-uniform)
-                const uint32_t w[4] = {cur[d].x, cur[d].y, cur[d].z, cur[d].w};
-                uint32_t o[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    r = crcq_word(r, __builtin_bswap32(w[j]));
-                    par ^= w[j];
-                    o[j] = decipher(w[j]);
-                }
-                tb[(uint64_t)k * 64] = valid ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (uint32_t d = 0; d < G; d++) cur[d] = nxt[d];
-    }
-    // the partial chunk (frame_size % 16 bytes), byte by byte, and the zero chunks up to K (the parser's feed may read one word
-    // past the frame)
-    for (uint32_t k = kfull; k < K; k++) {
-        uint32_t o[4] = {0, 0, 0, 0};
-        if (16 * k < fs) {
-            const uint4 c = load_chunk(k);
-            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-            if (k == 0 && (w[0] & 0xFFFF) != 0xFFFF) status = CRI_ERR_HCA_FRAME(4);
-            for (uint32_t i = 0; 16 * k + i < fs && i < 16; i++) {
-                const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xFF;
-                r = crcq_byte(r, b);
-                par ^= b;
-                const uint32_t dcp = IDENTITY ? b : (cipher_in_lds ? (uint32_t)ct[b] : (uint32_t)__ldg(ct + b));
-                o[i >> 2] |= dcp << (24 - 8 * (i & 3));
-            }
-        }
-        tb[(uint64_t)k * 64] = valid ? make_uint4(o[0], o[1], o[2], o[3]) : make_uint4(0, 0, 0, 0);
-    }
-    if (valid) {
-        r = crcq_fold(r);                                     // < 2^15: the remainder modulo x^15 + x + 1
-        if (status == 0 && (r != 0 || (__builtin_popcount(par) & 1))) status = CRI_ERR_HCA_FRAME(3);   // hca.cpp:1166-1167
-        ((int32_t*)(a.scratch + a.fstat_offset))[g] = status;
-    }
-}
-
-void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
-    if (!a.frames) return;
-    // (experiments: CRI_PREP_LDS_KB pads the LDS request to cap the waves per CU)
-    static const size_t pad = getenv("CRI_PREP_LDS_KB") ? (size_t)atoi(getenv("CRI_PREP_LDS_KB")) * 1024 : 0;
-    if (a.cipher_identity) hipLaunchKernelGGL(k_hca_prepare<true>, dim3((a.frames + 63) / 64), dim3(64), std::max<size_t>(16, pad), s, a);
-    else hipLaunchKernelGGL(k_hca_prepare<false>, dim3((a.frames + 63) / 64), dim3(64), std::max(hca_prepare_lds_bytes(a.n_cipher), pad), s, a);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // k_hca_parse: one lane per frame
 // ------------------------------------------------------------------------------------------------------------
@@ -196,23 +81,28 @@ void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s) {
 // 16-band block, written once by the scalefactor pass and re-read (coalesced, L2-resident) by each of the 8 subframes.
 //
 // Bit feed.  HBM latency under load is microseconds and the parse is an in-order serial chain, so words travel
-//   tile (global) --16-byte chunk requested at a checkpoint--> VGPRs --landed at the NEXT checkpoint--> per-lane LDS ring
-//   --one word prefetched per symbol--> 64-bit shift register.
+//   input blob (global) --16-byte chunk requested at a checkpoint--> VGPRs --checksummed, deciphered and landed at the NEXT
+//   checkpoint--> per-lane LDS ring --one word prefetched per symbol--> 64-bit shift register.
 // Checkpoints sit every 16 symbols (at most 16*12 bits = 6 words consumed in between).  A checkpoint asks for as many whole
-// chunks (4 words; k_hca_prepare lays a frame's words out as one uint4 per chunk and lane) as the ring has room for, at most
-// two: with h words in the ring after landing, r = min(8, 4*floor((16-h)/4)) are requested and c <= 6 consumed before they
-// land, so h' = h - c + r >= 7 whenever h >= 7, and h' <= 16.  The second chunk is rare (a lane that burned > 4 words in one
-// block) and sits behind a wave-uniform branch.
+// chunks (16 bytes of the lane's frame) as the ring has room for, at most two: with h words in the ring after landing,
+// r = min(8, 4*floor((16-h)/4)) are requested and c <= 6 consumed before they land, so h' = h - c + r >= 7 whenever
+// h >= 7, and h' <= 16.  The lanes of a wave parse the same block of their frames at the same time, so their requests
+// mostly fall on the same checkpoints and a landing step works for most of the wave at once; the second chunk is rare (a
+// lane that burned more than 4 words in one block) and sits behind a wave-uniform branch, and so do the frame's last,
+// partial chunk and a chunk that would reach past the end of the input blob.
 #define RING_WORDS 16       // (+ 4 spare rows: the sink of a lane that lands nothing)
-size_t hca_parse_lds_bytes(uint32_t channels) { (void)channels; return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96; }
+size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
 
 struct BitFeed {
-    const uint4* next;       // next chunk of this lane in the tile (stride 64 uint4)
-    int chunks_left;         // chunks of the frame not yet requested (requests past the frame land zeros)
+    const uint8_t* next;     // next chunk of this lane's frame in the input blob
+    const uint8_t* in_end;   // end of the input blob
+    const uint8_t* ct;       // this lane's cipher table (LDS, or global when the job has more than 16)
+    int bytes_left;          // bytes of the frame not yet requested (requests past the frame land zeros)
     uint32_t* ring;          // LDS ring base of this lane (slot stride 64 words)
     uint32_t wr;             // words landed in the ring (a multiple of 4)
     uint32_t nfl;            // chunks in flight: 0, 1 or 2
-    uint32_t live;           // bit k: chunk k in flight is part of the frame (otherwise it lands as zeros)
+    uint32_t nb0, nb1;       // bytes of the frame in each chunk in flight (16, less for the last one, 0 past the frame)
+    uint32_t r, par;         // checksum state (crcq_*)
     uint4 fl0, fl1;
 };
 struct BitBuf {
@@ -224,32 +114,98 @@ struct BitBuf {
     uint32_t nw;             // frame word k + 2 (LDS read issued one refill earlier)
 };
 
+// big-endian word of the deciphered bytes of a raw (little-endian) word
+template <bool IDENTITY, bool CT_LDS>
+__device__ __forceinline__ uint32_t decipher_word(const uint8_t* ct, uint32_t raw) {
+    if (IDENTITY) return __builtin_bswap32(raw);
+    uint32_t be = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = (raw >> (8 * k)) & 0xFF;
+        be |= (CT_LDS ? (uint32_t)ct[b] : (uint32_t)__ldg(ct + b)) << (24 - 8 * k);
+    }
+    return be;
+}
+// 16 bytes at p; bytes at or past `end` read as 0
+__device__ __forceinline__ uint4 load_chunk_guarded(const uint8_t* p, const uint8_t* end) {
+    if (p + 16 <= end) return ld_u128_unaligned(p);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) if (p + i < end) w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // A checkpoint is two halves with the pending record stores in between (see PendingFlush): the chunks asked for at the
 // previous checkpoint land in the ring, the stores of the last two blocks go out, the next chunks are asked for.  vmcnt
 // counts loads and stores together and in order, so the wait at the next checkpoint covers those stores too -- by then
 // they have had a whole block of parsing to complete.
-__device__ __forceinline__ void feed_land_chunk(BitFeed& f, const uint4& c, uint32_t k) {
-    const bool on = k < f.nfl, zero = !((f.live >> k) & 1);
+template <bool IDENTITY, bool CT_LDS>
+__device__ __forceinline__ void feed_land_chunk(BitFeed& f, const uint4& c, uint32_t k, uint32_t nb) {
+    const bool on = k < f.nfl;
     uint32_t* slot = f.ring + (on ? ((f.wr + 4 * k) & (RING_WORDS - 1)) : (uint32_t)RING_WORDS) * 64;
-    slot[0] = zero ? 0u : c.x; slot[64] = zero ? 0u : c.y; slot[128] = zero ? 0u : c.z; slot[192] = zero ? 0u : c.w;
+    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    uint32_t o[4] = {0, 0, 0, 0};
+    if (__all(!on || nb == 16)) {                              // whole chunks (the usual case): 32 bits per checksum step
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f.r = crcq_word(f.r, __builtin_bswap32(w[j]));
+                f.par ^= w[j];
+                o[j] = decipher_word<IDENTITY, CT_LDS>(f.ct, w[j]);
+            }
+        }
+    } else if (on) {                                           // a frame's last chunk, or nothing of the frame at all: byte by byte
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+            f.r = crcq_byte(f.r, b);
+            f.par ^= b;
+            const uint32_t d = IDENTITY ? b : (CT_LDS ? (uint32_t)f.ct[b] : (uint32_t)__ldg(f.ct + b));
+            o[i >> 2] |= d << (24 - 8 * (i & 3));
+        }
+    }
+    slot[0] = o[0]; slot[64] = o[1]; slot[128] = o[2]; slot[192] = o[3];
 }
+template <bool IDENTITY, bool CT_LDS>
 __device__ __forceinline__ void feed_land(BitFeed& f) {
-    feed_land_chunk(f, f.fl0, 0);
-    if (__any(f.nfl > 1)) feed_land_chunk(f, f.fl1, 1);
+    if (__any(f.nfl > 0)) feed_land_chunk<IDENTITY, CT_LDS>(f, f.fl0, 0, f.nb0);
+    if (__any(f.nfl > 1)) feed_land_chunk<IDENTITY, CT_LDS>(f, f.fl1, 1, f.nb1);
     f.wr += 4 * f.nfl;
+    f.nfl = 0;
 }
-__device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b) {
-    const uint32_t room = RING_WORDS - (f.wr - b.rd);
-    const uint32_t n = room >> 2 > 2 ? 2u : room >> 2;                          // chunks asked for
-    const int have = f.chunks_left;
-    f.live = have >= 2 ? 3u : (uint32_t)have;                                   // (have is 0, 1, or more)
-    if (n > 0) f.fl0 = f.next[0];                                               // past the frame these read the next lanes' / tiles' words
-    if (__any(n > 1)) { if (n > 1) f.fl1 = f.next[64]; }                        //   (inside scratch) and are landed as zeros
-    const int adv = (int)n < have ? (int)n : have;
-    f.next += (size_t)adv * 64; f.chunks_left = have - adv;
-    f.nfl = n;
+// asks for n (0..2) chunks; a lane with `ask` false keeps what it has in flight
+__device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask = true) {
+    const int left = f.bytes_left;
+    const uint32_t nb0 = (uint32_t)(left > 16 ? 16 : left), nb1 = (uint32_t)(left > 32 ? 16 : (left > 16 ? left - 16 : 0));
+    const bool want0 = ask && n > 0 && nb0 > 0, want1 = ask && n > 1 && nb1 > 0;
+    if (__any((want0 && f.next + 16 > f.in_end) || (want1 && f.next + 32 > f.in_end))) {     // the blob's very last frame
+        if (want0) f.fl0 = load_chunk_guarded(f.next, f.in_end);
+        if (want1) f.fl1 = load_chunk_guarded(f.next + 16, f.in_end);
+    } else {
+        if (want0) f.fl0 = ld_u128_unaligned(f.next);
+        if (__any(want1)) { if (want1) f.fl1 = ld_u128_unaligned(f.next + 16); }
+    }
+    if (ask) {
+        const int adv = (int)(n > 1 ? nb0 + nb1 : (n > 0 ? nb0 : 0u));
+        f.next += adv; f.bytes_left = left - adv;
+        f.nb0 = nb0; f.nb1 = nb1; f.nfl = n;
+    }
 }
-__device__ __forceinline__ void feed_checkpoint(BitFeed& f, const BitBuf& b) { feed_land(f); feed_request(f, b); }
+// `eager`: ask whenever there is room (always safe: see the invariant above).  Otherwise only a lane whose ring could run dry
+// asks: `thresh` = the most words the block about to be parsed and the one after it can take, + 2 (the bounds are exact
+// per block, see `needtab` in k_hca_parse; chunks asked for now land before the second of those blocks starts).
+// In the spectra loop the lanes top up together every HCA_FEED_SYNC-th checkpoint and those chunks are only landed
+// HCA_FEED_LAND checkpoints later -- a wave load of 64 lanes' chunks touches 64 cache lines in as many frames and completes
+// with the slowest of them, so it gets two blocks of parsing to do so -- unless a lane would run dry before that.
+#ifndef HCA_FEED_SYNC
+#define HCA_FEED_SYNC 3
+#endif
+#ifndef HCA_FEED_LAND
+#define HCA_FEED_LAND 2
+#endif
+__device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b, bool eager = true, uint32_t thresh = 0) {
+    const uint32_t h = f.wr - b.rd, room = RING_WORDS - h;
+    const bool ask = f.nfl == 0 && (eager || h < thresh);
+    feed_issue(f, room >> 2 > 2 ? 2u : room >> 2, ask);
+}
 // one refill opportunity per symbol; branch-free, the LDS read issued here is consumed by the NEXT call
 __device__ __forceinline__ void bb_refill(BitBuf& b, const uint32_t* ring) {
     const bool need = b.off >= 32;                   // the window's first word is used up: slide by one word
@@ -344,6 +300,7 @@ struct PendingFlush {
     }
 };
 
+template <bool IDENTITY, bool CT_LDS>
 __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
@@ -351,7 +308,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint32_t* ring = (uint32_t*)smem + lane;           // [RING_WORDS + 4][64]
     uint32_t* ostage = (uint32_t*)(smem + (RING_WORDS + 4) * 256);   // [16][OST]
     uint8_t* curve = (uint8_t*)(ostage + 16 * OST);    // 96 bytes reserved
+    uint8_t* needtab = curve + 96;                     // [C][8] most ring words a block of 16 symbols can take, over the wave's 64 frames
+    uint8_t* cipher_lds = needtab + 128;               // [n_cipher][256] (jobs with up to 16 cipher tables)
     for (uint32_t i = lane; i < 66; i += 64) curve[i] = HCA_CURVE_TO_RES[i];
+    if (!IDENTITY && CT_LDS) for (uint32_t i = lane; i < a.n_cipher * 64; i += 64) ((uint32_t*)cipher_lds)[i] = ((const uint32_t*)a.cipher_tables)[i];
 
     const uint32_t g = tile * 64 + lane;
     const bool valid = g < a.frames;
@@ -361,28 +321,36 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint8_t* recq = tile_rec + (uint64_t)(lane >> 2) * F.record_bytes + (lane & 3) * 16;
     const uint32_t rb16 = 16 * F.record_bytes;
     const uint32_t nvalid = a.frames - tile * 64 < 64 ? a.frames - tile * 64 : 64;
-    int status = valid ? ((const int32_t*)(a.scratch + a.fstat_offset))[g] : 0;
-    // every lane parses (frames that failed sync/CRC and the zero padding of the last tile parse to ignored output)
+    int status = 0;
+    // every lane parses (frames that fail sync / checksum parse to ignored output; the padding lanes of the last tile read zeros)
     uint4* metag = (uint4*)(a.scratch + a.resg_offset) + (uint64_t)tile * C * 8 * 64 + lane;
 
     PendingFlush pend; pend.set(0, 0);
     BitFeed fd;
-    fd.next = (const uint4*)(a.scratch + a.tile_offset) + (uint64_t)tile * a.chunks * 64 + lane;
-    fd.chunks_left = (int)a.chunks; fd.ring = ring; fd.wr = 0; fd.nfl = 0; fd.live = 0;
+    {
+        uint32_t si = a.stream_begin, f = 0;
+        if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
+        const uint64_t src_offset = a.streams[si].src_offset;
+        const uint32_t cidx = a.streams[si].cipher;
+        fd.next = a.in + src_offset + (uint64_t)f * F.frame_size;
+        fd.in_end = a.in + a.in_bytes;
+        fd.ct = (CT_LDS ? cipher_lds : a.cipher_tables) + cidx * 256;
+        fd.bytes_left = valid ? (int)F.frame_size : 0;
+    }
+    fd.ring = ring; fd.wr = 0; fd.nfl = 0; fd.nb0 = fd.nb1 = 0; fd.r = 0; fd.par = 0;
+    fd.fl0 = fd.fl1 = make_uint4(0, 0, 0, 0);
     BitBuf bb;
     bb.hi = 0; bb.lo = 0; bb.off = 0; bb.pos = 0; bb.size = (int)F.frame_size * 8; bb.rd = 0; bb.nw = 0;
-    {   // prime: the ring's 16 words (the words of a frame shorter than that are followed by zeros)
-#pragma unroll
-        for (uint32_t k = 0; k < RING_WORDS / 4; k++) {
-            const bool in = (int)k < fd.chunks_left;
-            const uint4 c = fd.next[in ? k * 64 : 0];
-            ring[(4 * k) * 64] = in ? c.x : 0u; ring[(4 * k + 1) * 64] = in ? c.y : 0u; ring[(4 * k + 2) * 64] = in ? c.z : 0u; ring[(4 * k + 3) * 64] = in ? c.w : 0u;
-        }
-        const int adv = fd.chunks_left < RING_WORDS / 4 ? fd.chunks_left : RING_WORDS / 4;
-        fd.next += (size_t)adv * 64; fd.chunks_left -= adv; fd.wr = RING_WORDS;
-    }
+    wave_lds_sync();
+    // prime: the ring's 16 words (the bytes of a frame shorter than that are followed by zeros)
+    feed_issue(fd, 2);
+    const bool sync_bad = valid && (fd.fl0.x & 0xFFFF) != 0xFFFF;                 // hca.cpp:1162-1164 (frame_size >= 8)
+    feed_land<IDENTITY, CT_LDS>(fd);
+    feed_issue(fd, 2);
+    feed_land<IDENTITY, CT_LDS>(fd);
+    wave_lds_sync();
     bb.hi = ring[0]; bb.lo = ring[64]; bb.nw = ring[128]; bb.rd = 2;
-    bb_skip(bb, 16);                                             // sync word, checked by k_hca_prepare
+    bb_skip(bb, 16);                                             // sync word
     uint32_t packed = 0, flags = 0, draws = 0, wide_bits = 0;
     {
         const uint32_t nl = bb_read(bb, ring, 9), eb = bb_read(bb, ring, 7);   // hca.cpp:1175-1178
@@ -401,7 +369,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         const uint32_t expected = (1u << db) - 1;
         // scalefactors + resolutions in blocks of 16 bands (the last block is padded with zeros)
         for (uint32_t blk = 0; blk < 8; blk++) {
-            feed_land(fd); feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);
+            feed_land<IDENTITY, CT_LDS>(fd); feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);
             uint32_t sfw[4] = {0, 0, 0, 0};
             uint32_t mw[4] = {0, 0, 0, 0};
             // far from the frame end (always, in a well-formed frame) the reader's end-of-frame rules cannot apply
@@ -455,6 +423,15 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 for (uint32_t q = 0; q < 4; q++) wide_bits |= ((mw[q] & 0x0F0F0F0Fu) + 0x07070707u) & 0x10101010u;
             }
             metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+            {   // bits the block's 16 symbols can take (the low nibbles), the most over the wave, as ring words: a refill slides the
+                // window by one word, and the window may already be up to 55 bits in when the block starts
+                uint32_t sb = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) sb = __builtin_amdgcn_sad_u8(mw[q] & 0x0F0F0F0Fu, 0u, sb);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)sb, o); sb = t > sb ? t : sb; }
+                if (lane == 0) needtab[c * 8 + blk] = (uint8_t)((sb + 55) >> 5);
+            }
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++) ostage[((blk & 3) * 4 + q) * OST + lane] = sfw[q];
             if ((blk & 3) == 3) {
@@ -533,21 +510,24 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint4 mv_next = metag[first_c * 8 * 64];
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): nothing is pending when the loop is entered, so the
                                                                   // waits the compiler places inside it stay exact counts
+    wave_lds_sync();                                              // (needtab)
+    uint32_t ck = HCA_FEED_LAND;                                  // the first checkpoint lands what the scalefactor pass left in flight
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t nblk = (F.coded(c) + 15) >> 4;
             for (uint32_t blk = 0; blk < nblk; blk++) {
-                feed_land(fd);
-                const uint4 mv = mv_next;
-                {
-                    uint32_t nb = blk + 1, nc = c;
-                    if (nb >= nblk) {                          // the next channel that has blocks (this one again, if it is the only one)
-                        nb = 0;
-                        do { nc = nc + 1 == C ? 0 : nc + 1; } while (F.coded(nc) == 0 && nc != c);
-                    }
-                    mv_next = metag[(nc * 8 + nb) * 64];
+                uint32_t nb = blk + 1, nc = c;
+                if (nb >= nblk) {                              // the next channel that has blocks (this one again, if it is the only one)
+                    nb = 0;
+                    do { nc = nc + 1 == C ? 0 : nc + 1; } while (F.coded(nc) == 0 && nc != c);
                 }
-                feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);
+                const uint32_t thresh = (uint32_t)needtab[c * 8 + blk] + (uint32_t)needtab[nc * 8 + nb] + 2;
+                if (ck == HCA_FEED_LAND || __any(fd.nfl > 0 && fd.wr - bb.rd < thresh)) feed_land<IDENTITY, CT_LDS>(fd);
+                if (ck == HCA_FEED_LAND && sf == 0 && c == first_c && blk == 0) ck = 0;      // (and it is the first eager one)
+                const uint4 mv = mv_next;
+                mv_next = metag[(nc * 8 + nb) * 64];
+                feed_request(fd, bb, ck == 0, thresh); pend.run(ostage, recq, rb16, nvalid, lane);
+                ck = ck + 1 == HCA_FEED_SYNC ? 0 : ck + 1;
                 const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
                 uint32_t words[8];
@@ -585,6 +565,16 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         }
     }
     pend.run(ostage, recq, rb16, nvalid, lane);
+    // whatever the parse left of the frame still goes through the checksum (the ring is no longer read: its room is its size)
+    while (__any(fd.nfl > 0 || fd.bytes_left > 0)) {
+        feed_land<IDENTITY, CT_LDS>(fd);
+        feed_issue(fd, fd.bytes_left > 16 ? 2u : (fd.bytes_left > 0 ? 1u : 0u));
+    }
+    {   // hca.cpp:1162-1167: sync word, then checksum, come before anything the unpack finds
+        const uint32_t rq = crcq_fold(fd.r);                  // < 2^15: the remainder modulo x^15 + x + 1
+        const bool crc_bad = rq != 0 || (__builtin_popcount(fd.par) & 1);
+        status = sync_bad ? CRI_ERR_HCA_FRAME(4) : (crc_bad ? CRI_ERR_HCA_FRAME(3) : status);
+    }
     if (valid) {
         uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
         tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags | (narrow ? HCA_REC_NARROW : 0u); tail[3] = draws;      // k_hca_noise_scan turns tail[3] into a prefix
@@ -593,7 +583,11 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 
 void launch_hca_parse(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
-    hipLaunchKernelGGL(k_hca_parse, dim3((a.frames + 63) / 64), dim3(64), hca_parse_lds_bytes(a.channels), s, a);
+    const dim3 grid((a.frames + 63) / 64), block(64);
+    const size_t lds = hca_parse_lds_bytes(a.cipher_identity ? 0 : a.n_cipher);
+    if (a.cipher_identity) hipLaunchKernelGGL((k_hca_parse<true, true>), grid, block, lds, s, a);
+    else if (a.n_cipher <= 16) hipLaunchKernelGGL((k_hca_parse<false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_hca_parse<false, false>), grid, block, lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -20,24 +20,20 @@ struct HcaDecArgs {
     uint32_t frames;               // total frames of this format group
     uint32_t runs;                 // total runs (8 consecutive frames of one stream) of this format group
     uint32_t n_cipher;
-    uint32_t chunks;               // 16-byte chunks per frame in the word tiles: ceil((ceil(frame_size / 4) + 1) / 4), the last words zero
-    uint32_t cipher_identity;      // 1: every stream of the job is unencrypted (one identity table): k_hca_prepare skips the lookups
+    uint32_t cipher_identity;      // 1: every stream of the job is unencrypted (one identity table): the intake skips the lookups
+    uint32_t pad0;
     uint32_t channels;             // channel count of this format
     uint32_t plain;                // 1: no HFR and no joint stereo in this format (spectra need dequantisation only)
     uint32_t noise_fill;           // 1: min_resolution == 0 (v3.0): k_hca_noise_scan + noise reconstruction in the transform
     uint32_t pairs_even;           // 1: every stereo pair starts on an even channel (a pair then shares a transform pass)
     uint32_t narrow;               // 1: k_hca_transform_plain reads this format's records: int8 lines where the values allow it
     uint32_t pad1;
-    uint64_t tile_offset;          // scratch byte offset of this group's word tiles: [tile][chunk][64 lanes] uint4 (4 big-endian words)
-    uint64_t in_bytes;             // size of the input blob (k_hca_prepare's 16-byte loads stop there)
-    uint64_t fstat_offset;         // scratch byte offset of this group's per-frame prepare status (int32[frames])
+    uint64_t in_bytes;             // size of the input blob (the intake's 16-byte loads stop there)
     uint64_t resg_offset;          // scratch byte offset of this group's band code descriptions: [tile][C][8 blocks][64 lanes] uint4 (16 bands x 1 byte)
     float* float_out;              // validation runs only (cri_job_run_floats), else null: every frame's samples before the int16
                                    // conversion (hca.cpp:1987-1992 wave[][]), [frame][1024][C] floats from HcaStream::float_offset on
 };
-size_t hca_prepare_lds_bytes(uint32_t n_cipher);
-size_t hca_parse_lds_bytes(uint32_t channels);
-void launch_hca_prepare(const HcaDecArgs& a, hipStream_t s);
+size_t hca_parse_lds_bytes(uint32_t n_cipher);
 void launch_hca_parse(const HcaDecArgs& a, hipStream_t s);
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);
 
