@@ -312,7 +312,7 @@ def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, 
     bufs = job.alloc(D.dev)
     job.enable_events(True)
     dt, kms = run_timed(D, lambda: job.run(*bufs), steps, warmup, [job])
-    assert int((bufs[3] != 0).sum().item()) == 0, "items failed on the device"
+    assert not verify or int((bufs[3] != 0).sum().item()) == 0, "items failed on the device"
     res = {"job": job, "dt": dt, "kernel_ms": kms, "units": job.units, "alg_bytes": job.algorithmic_bytes,
            "frame_size": int.from_bytes(uniq[0][0x1C:0x1E], "big"), "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
            "census": job.record_census(bufs[2]), "sample": uniq[0],

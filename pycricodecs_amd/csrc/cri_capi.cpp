@@ -351,9 +351,11 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         j->hca_group_first_record.push_back(streams[b].scratch_offset);
         b = e;
     }
-    // the band code descriptions of every format group follow the frame records
+    // the quantised lines (tile-major) and the band code descriptions of every format group follow the frame records
     for (auto& a : j->hca_dec) {
-        scratch = align_up(scratch, 256);
+        scratch = align_up(scratch, 4096);
+        a.qc_offset = scratch;
+        scratch += (uint64_t)((a.frames + 63) / 64) * HCA_QC_TILE(a.channels);
         a.resg_offset = scratch;
         scratch += (uint64_t)((a.frames + 63) / 64) * a.channels * 8 * 64 * 16;
     }

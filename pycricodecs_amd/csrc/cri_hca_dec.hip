@@ -91,7 +91,7 @@ __device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; 
 // lane that burned more than 4 words in one block) and sits behind a wave-uniform branch, and so do the frame's last,
 // partial chunk and a chunk that would reach past the end of the input blob.
 #define RING_WORDS 16       // (+ 4 spare rows: the sink of a lane that lands nothing)
-size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
+size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
 
 struct BitFeed {
     const uint8_t* next;     // next chunk of this lane's frame in the input blob
@@ -180,8 +180,13 @@ __device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask = tr
         if (want0) f.fl0 = load_chunk_guarded(f.next, f.in_end);
         if (want1) f.fl1 = load_chunk_guarded(f.next + 16, f.in_end);
     } else {
+#ifdef HCA_ABL_NOLOAD
+        if (want0) f.fl0 = make_uint4((uint32_t)(uintptr_t)f.next, 1, 2, 3);                       // (timing experiment: no input loads)
+        if (want1) f.fl1 = make_uint4((uint32_t)(uintptr_t)f.next, 5, 6, 7);
+#else
         if (want0) f.fl0 = ld_u128_unaligned(f.next);
         if (__any(want1)) { if (want1) f.fl1 = ld_u128_unaligned(f.next + 16); }
+#endif
     }
     if (ask) {
         const int adv = (int)(n > 1 ? nb0 + nb1 : (n > 0 ? nb0 : 0u));
@@ -231,16 +236,16 @@ __device__ __forceinline__ uint32_t bb_peek(const BitBuf& b, int n) {
 __device__ __forceinline__ void bb_skip(BitBuf& b, int n) { b.off += n; b.pos += n; }
 __device__ __forceinline__ uint32_t bb_read(BitBuf& b, const uint32_t* ring, int n) { bb_refill(b, ring); uint32_t v = bb_peek<true>(b, n); bb_skip(b, n); return v; }
 
-// One spectral symbol (hca.cpp:1546-1563).  `meta` = bits | nshort << 4 describes the band's code: `bits` = most bits a
-// symbol can take (hcatbdecoder_max_bit_table), and both code families reduce to one rule --
+// One spectral symbol (hca.cpp:1546-1563).  `meta` = bits | T << 4 describes the band's code (band_meta): `bits` = most bits a
+// symbol can take (hcatbdecoder_max_bit_table), nshort = nstab[T], and both code families reduce to one rule --
 //   code < 2*nshort : symbol = code >> 1, one bit is given back          (prefix codes: the short codewords;
 //   otherwise       : symbol = code - nshort                              sign-magnitude, nshort = 1: the zero)
 //   value = +ceil(symbol/2) for odd symbols, -symbol/2 for even ones
 // which reproduces read_bit/read_val for resolutions 1..7 (nshort = 2^bits - (2*res+1)) and the sign-magnitude form
 // with its "zero gives the sign bit back" rule for resolutions 8..15.  The caller refills once per two symbols.
 template <bool CHECKED>
-__device__ __forceinline__ int parse_symbol(BitBuf& bb, uint32_t meta) {
-    const uint32_t bits = meta & 15, ns = (meta >> 4) & 15;
+__device__ __forceinline__ int parse_symbol(BitBuf& bb, uint32_t meta, const uint8_t* nstab) {
+    const uint32_t bits = meta & 15, ns = nstab[(meta >> 4) & 15];
     const uint32_t code = bb_peek<CHECKED>(bb, (int)bits);
     const bool is_short = code < 2 * ns;
     const uint32_t sym = is_short ? (code >> 1) : (code - ns);
@@ -262,10 +267,39 @@ __device__ __forceinline__ uint32_t pairs_to_i8(uint32_t p01, uint32_t p23) { re
 // refill for up to two symbols (24 bits)
 __device__ __forceinline__ void pair_refill(BitBuf& b, const uint32_t* ring) { bb_refill(b, ring); }
 // code description of a band of resolution res (see parse_symbol)
+__device__ __forceinline__ uint32_t band_bits(uint32_t res) { return res > 7 ? res - 3 : (0x44443320u >> (res * 4)) & 15; }   // 0,2,3,3,4,4,4,4,5,...,12
+__device__ __forceinline__ uint32_t band_nshort(uint32_t res) { return res > 7 ? 1u : (0x13571310u >> (res * 4)) & 15; }    // 0,1,3,1,7,5,3,1
+// Code description of a band: bits | T << 4.  For the prefix codes (resolutions 0..7, at most four bits) T is the short-code
+// bound in terms of the NEXT FOUR stream bits: a symbol is short (takes bits - 1) iff those four bits, as a number, are below
+// T = 2 * nshort << (4 - bits) -- 0, 8, 12, 4, 14, 10, 6, 2 for resolutions 0..7, all different, so T / 2 also names the
+// resolution.  Resolutions 8..15 (sign-magnitude, nshort = 1) carry T = 1.
 __device__ __forceinline__ uint32_t band_meta(uint32_t res) {
-    const uint32_t bits = res > 7 ? res - 3 : (0x44443320u >> (res * 4)) & 15;      // 0,2,3,3,4,4,4,4,5,...,12
-    const uint32_t ns = res > 7 ? 1u : (0x13571310u >> (res * 4)) & 15;             // 0,1,3,1,7,5,3,1
-    return bits | (ns << 4);
+    const uint32_t bits = band_bits(res);
+    const uint32_t t = res > 7 ? 1u : (2 * band_nshort(res)) << (4 - bits);
+    return bits | (t << 4);
+}
+
+// Symbol values of the prefix codes: entry [T / 2][next four bits of the stream] = -value & 0xFF, the byte an int8 record line
+// holds (HCA_REC_NARROW).  In a block of 16 bands in which no frame of the wave has a longer code (parse_block path below)
+// a symbol's LENGTH is one compare against T -- the only thing the next symbol waits for -- and its value is a table read
+// that nothing waits for until the bytes are packed.  nstab[T] = nshort for the arithmetic path (parse_symbol).
+#define HCA_LUT_BYTES 128
+__device__ __forceinline__ void build_symbol_lut(uint8_t* lut, uint8_t* nstab, uint32_t lane) {
+#pragma unroll
+    for (uint32_t e = lane; e < 128; e += 64) {
+        const uint32_t res = e >> 4, idx = e & 15, bits = band_bits(res), ns = band_nshort(res);
+        const uint32_t code = idx >> (4 - bits);
+        const bool is_short = code < 2 * ns;
+        const uint32_t sym = is_short ? (code >> 1) : (code - ns);
+        const uint32_t negv = (sym >> 1) ^ (uint32_t)__builtin_amdgcn_sbfe(sym, 0, 1);
+        lut[(band_meta(res) >> 5) * 16 + idx] = (uint8_t)negv;
+    }
+    if (lane < 16) {
+        uint32_t ns = 1;                                      // T = 1: resolutions 8..15
+#pragma unroll
+        for (uint32_t res = 0; res < 8; res++) if ((band_meta(res) >> 4) == lane) ns = band_nshort(res);
+        nstab[lane] = (uint8_t)ns;
+    }
 }
 
 // transposed flush of the 16 staged words of every lane: frame fr's words go to its record + byte_off, 64 B per frame.
@@ -283,6 +317,29 @@ __device__ __forceinline__ void flush16(const uint32_t* ostage, uint8_t* recq, u
         const uint32_t* src = ostage + wq * OST + fr;
         const uint4 v = make_uint4(src[0], src[OST], src[2 * OST], src[3 * OST]);
         uint4* dst = (uint4*)(recq + (size_t)it * rb16 + byte_off);
+#ifdef HCA_ABL_NOSTORE
+        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)          // (timing experiment: the stores practically never happen)
+#endif
+        if (all) *dst = v;
+        else if (fr < nvalid && wq < nwords) *dst = v;
+    }
+    wave_lds_sync();
+}
+// the same for quantised lines: 64 B of each of the tile's 64 frames go to one quarter of a row (cri_types.h), which is 4 KB of
+// contiguous memory -- lane l's 16 bytes of step `it` sit at qoff + it * 1 KB + l * 16
+__device__ __forceinline__ void flush16_qc(const uint32_t* ostage, uint8_t* qc_tile, uint32_t nvalid, uint32_t lane, uint32_t qoff, uint32_t nwords) {
+    wave_lds_sync();
+    const uint32_t wq = (lane & 3) * 4, fq = lane >> 2;
+    const bool all = nvalid == 64 && nwords == 16;
+#pragma unroll
+    for (uint32_t it = 0; it < 4; it++) {
+        const uint32_t fr = it * 16 + fq;
+        const uint32_t* src = ostage + wq * OST + fr;
+        const uint4 v = make_uint4(src[0], src[OST], src[2 * OST], src[3 * OST]);
+        uint4* dst = (uint4*)(qc_tile + qoff + it * 1024 + lane * 16);
+#ifdef HCA_ABL_NOSTORE
+        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
+#endif
         if (all) *dst = v;
         else if (fr < nvalid && wq < nwords) *dst = v;
     }
@@ -293,9 +350,11 @@ __device__ __forceinline__ void flush16(const uint32_t* ostage, uint8_t* recq, u
 // before the next ones are asked for (feed_land), so that no checkpoint waits on stores it has just issued.
 struct PendingFlush {
     uint32_t byte_off, nwords;               // nwords == 0: nothing pending (wave-uniform)
-    __device__ __forceinline__ void set(uint32_t off, uint32_t n) { byte_off = off; nwords = n; }
-    __device__ __forceinline__ void run(const uint32_t* ostage, uint8_t* recq, uint32_t rb16, uint32_t nvalid, uint32_t lane) {
-        if (nwords) flush16(ostage, recq, rb16, nvalid, lane, byte_off, nwords);
+    bool qc;                                 // byte_off is a quarter-row offset inside the tile's quantised lines, not a record offset
+    __device__ __forceinline__ void set(uint32_t off, uint32_t n) { byte_off = off; nwords = n; qc = false; }
+    __device__ __forceinline__ void set_qc(uint32_t off, uint32_t n) { byte_off = off; nwords = n; qc = true; }
+    __device__ __forceinline__ void run(const uint32_t* ostage, uint8_t* recq, uint8_t* qc_tile, uint32_t rb16, uint32_t nvalid, uint32_t lane) {
+        if (nwords) { if (qc) flush16_qc(ostage, qc_tile, nvalid, lane, byte_off, nwords); else flush16(ostage, recq, rb16, nvalid, lane, byte_off, nwords); }
         nwords = 0;
     }
 };
@@ -308,8 +367,11 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint32_t* ring = (uint32_t*)smem + lane;           // [RING_WORDS + 4][64]
     uint32_t* ostage = (uint32_t*)(smem + (RING_WORDS + 4) * 256);   // [16][OST]
     uint8_t* curve = (uint8_t*)(ostage + 16 * OST);    // 96 bytes reserved
-    uint8_t* needtab = curve + 96;                     // [C][8] most ring words a block of 16 symbols can take, over the wave's 64 frames
-    uint8_t* cipher_lds = needtab + 128;               // [n_cipher][256] (jobs with up to 16 cipher tables)
+    uint8_t* needtab = curve + 96;                     // [C][8] most ring words a block of 16 symbols can take over the wave's 64 frames; bit 7: no code of the block has more than four bits
+    uint8_t* lut = needtab + 128;                      // [8][16] symbol values of the prefix codes (build_symbol_lut)
+    uint8_t* nstab = lut + 128;                        // [16] short-code count by T
+    uint8_t* cipher_lds = nstab + 16;                  // [n_cipher][256] (jobs with up to 16 cipher tables)
+    build_symbol_lut(lut, nstab, lane);
     for (uint32_t i = lane; i < 66; i += 64) curve[i] = HCA_CURVE_TO_RES[i];
     if (!IDENTITY && CT_LDS) for (uint32_t i = lane; i < a.n_cipher * 64; i += 64) ((uint32_t*)cipher_lds)[i] = ((const uint32_t*)a.cipher_tables)[i];
 
@@ -320,6 +382,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint8_t* rec = tile_rec + (uint64_t)lane * F.record_bytes;
     uint8_t* recq = tile_rec + (uint64_t)(lane >> 2) * F.record_bytes + (lane & 3) * 16;
     const uint32_t rb16 = 16 * F.record_bytes;
+    uint8_t* qc_tile = a.scratch + a.qc_offset + (uint64_t)tile * HCA_QC_TILE(C);
     const uint32_t nvalid = a.frames - tile * 64 < 64 ? a.frames - tile * 64 : 64;
     int status = 0;
     // every lane parses (frames that fail sync / checksum parse to ignored output; the padding lanes of the last tile read zeros)
@@ -369,7 +432,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         const uint32_t expected = (1u << db) - 1;
         // scalefactors + resolutions in blocks of 16 bands (the last block is padded with zeros)
         for (uint32_t blk = 0; blk < 8; blk++) {
-            feed_land<IDENTITY, CT_LDS>(fd); feed_request(fd, bb); pend.run(ostage, recq, rb16, nvalid, lane);
+            feed_land<IDENTITY, CT_LDS>(fd); feed_request(fd, bb); pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
             uint32_t sfw[4] = {0, 0, 0, 0};
             uint32_t mw[4] = {0, 0, 0, 0};
             // far from the frame end (always, in a well-formed frame) the reader's end-of-frame rules cannot apply
@@ -414,7 +477,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 #pragma unroll
                 for (uint32_t k = 0; k < 16; k++) {
                     const bool live = blk * 16 + k < coded && ((sfw[k >> 2] >> (8 * (k & 3))) & 0xFF) != 0;
-                    const bool coded_res = ((mw[k >> 2] >> (8 * (k & 3))) & 0xFF) != 0;      // band_meta(0) == 0
+                    const bool coded_res = ((mw[k >> 2] >> (8 * (k & 3))) & 0xFF) != 0;      // band_meta(0) == 0 (no bits, resolution 0)
                     n_noise += live && !coded_res ? 1u : 0u; n_valid += live && coded_res ? 1u : 0u;
                 }
             }
@@ -430,7 +493,11 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 for (uint32_t q = 0; q < 4; q++) sb = __builtin_amdgcn_sad_u8(mw[q] & 0x0F0F0F0Fu, 0u, sb);
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)sb, o); sb = t > sb ? t : sb; }
-                if (lane == 0) needtab[c * 8 + blk] = (uint8_t)((sb + 55) >> 5);
+                uint32_t longc = 0;                              // a code of more than four bits (resolution >= 8)?
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) longc |= ((mw[q] & 0x0F0F0F0Fu) + 0x0B0B0B0Bu) & 0x10101010u;
+                const bool lut_ok = !__any(longc != 0);
+                if (lane == 0) needtab[c * 8 + blk] = (uint8_t)(((sb + 55) >> 5) | (lut_ok ? 0x80u : 0u));
             }
 #pragma unroll
             for (uint32_t q = 0; q < 4; q++) ostage[((blk & 3) * 4 + q) * OST + lane] = sfw[q];
@@ -451,7 +518,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             }
         }
         if (extra) {                                              // v3.0: scalefactors[127 - i] = scalefactors[cs - i]
-            pend.run(ostage, recq, rb16, nvalid, lane);
+            pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
             __syncthreads();                                      // (global data written by other lanes: drain the stores)
             if (valid) for (uint32_t i = 0; i < extra; i++) {
                 const uint32_t srci = cs - i;
@@ -507,7 +574,22 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     //      (channels without coded bands -- a secondary channel of a format with base_band_count 0 -- have no blocks)
     uint32_t first_c = 0;
     while (first_c + 1 < C && F.coded(first_c) == 0) first_c++;
-    uint4 mv_next = metag[first_c * 8 * 64];
+    // (c, blk) -> the block parsed after it: the next block of the channel, else block 0 of the next channel that has blocks
+    auto block_after = [&](uint32_t c, uint32_t blk, uint32_t& nc, uint32_t& nb) {
+        nb = blk + 1; nc = c;
+        if (nb >= ((F.coded(c) + 15) >> 4)) {
+            nb = 0;
+            do { nc = nc + 1 == C ? 0 : nc + 1; } while (F.coded(nc) == 0 && nc != c);
+        }
+    };
+    // code descriptions travel two blocks ahead of their use: the records a wave streams out keep the memory system busy enough
+    // that a load asked for one block ahead arrives late more often than not
+    uint4 mv_next = metag[first_c * 8 * 64], mv_next2;
+    {
+        uint32_t nc, nb;
+        block_after(first_c, 0, nc, nb);
+        mv_next2 = metag[(nc * 8 + nb) * 64];
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): nothing is pending when the loop is entered, so the
                                                                   // waits the compiler places inside it stay exact counts
     wave_lds_sync();                                              // (needtab)
@@ -516,28 +598,58 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t nblk = (F.coded(c) + 15) >> 4;
             for (uint32_t blk = 0; blk < nblk; blk++) {
-                uint32_t nb = blk + 1, nc = c;
-                if (nb >= nblk) {                              // the next channel that has blocks (this one again, if it is the only one)
-                    nb = 0;
-                    do { nc = nc + 1 == C ? 0 : nc + 1; } while (F.coded(nc) == 0 && nc != c);
-                }
-                const uint32_t thresh = (uint32_t)needtab[c * 8 + blk] + (uint32_t)needtab[nc * 8 + nb] + 2;
+                uint32_t nb, nc, nb2, nc2;
+                block_after(c, blk, nc, nb);
+                block_after(nc, nb, nc2, nb2);
+                const uint32_t nt = needtab[c * 8 + blk];
+                const uint32_t thresh = (nt & 0x7F) + ((uint32_t)needtab[nc * 8 + nb] & 0x7F) + 2;
                 if (ck == HCA_FEED_LAND || __any(fd.nfl > 0 && fd.wr - bb.rd < thresh)) feed_land<IDENTITY, CT_LDS>(fd);
                 if (ck == HCA_FEED_LAND && sf == 0 && c == first_c && blk == 0) ck = 0;      // (and it is the first eager one)
                 const uint4 mv = mv_next;
-                mv_next = metag[(nc * 8 + nb) * 64];
-                feed_request(fd, bb, ck == 0, thresh); pend.run(ostage, recq, rb16, nvalid, lane);
+                mv_next = mv_next2;
+#ifdef HCA_ABL_NOMETA
+                mv_next2 = make_uint4(0x82828282u + nc2, 0x82828282u, 0x82828282u, 0x82828282u + nb2);   // (timing experiment: no code-description loads)
+#else
+                mv_next2 = metag[(nc2 * 8 + nb2) * 64];
+#endif
+                feed_request(fd, bb, ck == 0, thresh); pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
                 ck = ck + 1 == HCA_FEED_SYNC ? 0 : ck + 1;
                 const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
+                if (fast && narrow && (nt & 0x80)) {
+                    // every code of the block has at most four bits, in all 64 frames.  Length of a symbol = bits - (next four
+                    // bits < T): shift, compare, add-with-carry is all the next symbol waits for; the value byte comes from
+                    // the table whenever it comes.  The window needs a refill only every four symbols (<= 16 bits).
+                    const uint32_t off0 = bb.off, rd0 = bb.rd;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) {
+                        bb_refill(bb, ring);
+                        const uint64_t win = ((uint64_t)bb.hi << 32) | bb.lo;
+                        uint32_t e[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            const uint32_t idx = (uint32_t)((win << bb.off) >> 60);                   // the next four bits
+                            const uint32_t t = __builtin_amdgcn_ubfe(mw[q], 8 * j + 4, 4), bits = __builtin_amdgcn_ubfe(mw[q], 8 * j, 4);
+                            e[j] = lut[(t << 3) + idx];
+                            bb.off += bits - (idx < t ? 1u : 0u);
+                        }
+                        // the four line bytes, first band in the low byte
+                        const uint32_t lo2 = __builtin_amdgcn_perm(e[1], e[0], 0x0c0c0400u), hi2 = __builtin_amdgcn_perm(e[3], e[2], 0x04000c0cu);
+                        ostage[((blk & 3) * 4 + q) * OST + lane] = lo2 | hi2;
+                    }
+                    bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
+                    if ((blk & 3) == 3 || blk + 1 == nblk)
+                        pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 2) * HCA_QC_QUARTER, 4 * ((blk & 3) + 1));
+                    continue;
+                }
                 uint32_t words[8];
                 if (fast) {
                     const uint32_t off0 = bb.off, rd0 = bb.rd;
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
                         pair_refill(bb, ring);
-                        const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
-                        const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
+                        const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF, nstab);
+                        const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF, nstab);
                         words[k] = pair_negated(v0, v1);
                     }
                     bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
@@ -545,8 +657,8 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
                         pair_refill(bb, ring);
-                        const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF);
-                        const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF);
+                        const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF, nstab);
+                        const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF, nstab);
                         words[k] = pair_negated(v0, v1);
                     }
                 }
@@ -554,17 +666,17 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) ostage[((blk & 3) * 4 + k) * OST + lane] = pairs_to_i8(words[2 * k], words[2 * k + 1]);
                     if ((blk & 3) == 3 || blk + 1 == nblk)
-                        pend.set(HCA_REC_QC(C, sf, c) + (blk >> 2) * 64, 4 * ((blk & 3) + 1));
+                        pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 2) * HCA_QC_QUARTER, 4 * ((blk & 3) + 1));
                 } else {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * OST + lane] = pair_to_i16(words[k]);
                     if ((blk & 1) || blk + 1 == nblk)
-                        pend.set(HCA_REC_QC(C, sf, c) + (blk >> 1) * 64, (blk & 1) ? 16 : 8);
+                        pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 1) * HCA_QC_QUARTER, (blk & 1) ? 16 : 8);
                 }
             }
         }
     }
-    pend.run(ostage, recq, rb16, nvalid, lane);
+    pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
     // whatever the parse left of the frame still goes through the checksum (the ring is no longer read: its room is its size)
     while (__any(fd.nfl > 0 || fd.bytes_left > 0)) {
         feed_land<IDENTITY, CT_LDS>(fd);
@@ -686,13 +798,19 @@ __device__ __forceinline__ void frame_gains(const TransformCtx& X, const uint8_t
     }
 }
 
+// quantised lines of a frame (cri_types.h): the frame's 64-byte column of its tile, quarter 0 of row (0, 0); g = the frame's
+// number within its format group
+__device__ __forceinline__ const uint8_t* qc_frame(const HcaDecArgs& a, uint32_t C, uint32_t g) {
+    return a.scratch + a.qc_offset + (uint64_t)(g >> 6) * HCA_QC_TILE(C) + (g & 63) * 64;
+}
+
 // spectra of subframe sf of one frame into S: dequantise, HFR, intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
 // `rnd` is the generator state before this subframe's first draw; it is advanced past the subframe's draws.
-__device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8_t* rec, uint32_t sf, const uint8_t* inten /* [C][8] resolved */, uint32_t& rnd) {
+__device__ __forceinline__ void frame_spectra(const TransformCtx& X, const uint8_t* rec, const uint8_t* qcf, uint32_t sf, const uint8_t* inten /* [C][8] resolved */, uint32_t& rnd) {
     const Fmt& F = *X.F;
     const uint32_t C = X.C, lane = X.lane;
     for (uint32_t c = 0; c < C; c++) {
-        const uint32_t q2 = ((const uint32_t*)(rec + HCA_REC_QC(C, sf, c)))[lane];
+        const uint32_t q2 = *(const uint32_t*)(qcf + HCA_QC_ROW(C, sf, c) + (lane >> 4) * HCA_QC_QUARTER + (lane & 15) * 4);     // int16 lines 2*lane, 2*lane+1
         const uint32_t i0 = 2 * lane;
         float q0 = (float)(int)(int16_t)(q2 & 0xFFFF), q1 = (float)(int)(int16_t)(q2 >> 16);
         X.S[c * 128 + i0] = i0 < F.coded(c) ? X.G[c * 128 + i0] * q0 : 0.0f;
@@ -853,7 +971,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
             rnd = lcg_jump(1, ((const uint32_t*)(prec + HCA_REC_TAIL(C)))[3] + 7 * per_sf);
         }
         wave_lds_sync();
-        frame_spectra(X, prec, 7, inten, rnd);
+        frame_spectra(X, prec, qc_frame(a, C, g - 1), 7, inten, rnd);
         dct_rows(1);
     }
     resolve_intensity(F, rec0, f, C, lane, inten);
@@ -866,7 +984,7 @@ __global__ __launch_bounds__(64) void k_hca_transform_generic(HcaDecArgs a) {
     const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
     uint8_t* dst = a.out + st.dst_offset;
     for (uint32_t sf = 0; sf < 8; sf++) {
-        frame_spectra(X, rec, sf, inten, rnd);
+        frame_spectra(X, rec, qc_frame(a, C, g), sf, inten, rnd);
         const uint32_t set = sf & 1;
         dct_rows(set);
         const bool have_prev = !(f == 0 && sf == 0);
@@ -1073,9 +1191,9 @@ __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, con
 // reconstruction and intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
 struct TrFetch { uint4 q; };         // quantised lines of (sf, c) for this lane's 8 bands
 template <bool PLAIN, int C>
-__device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* rec, uint32_t sf, uint32_t c, uint32_t l16) {
+__device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* qcf, uint32_t sf, uint32_t c, uint32_t l16) {
     TrFetch t;
-    t.q = *(const uint4*)(rec + (HCA_REC_QC(C, sf, c) + l16 * 16));
+    t.q = *(const uint4*)(qcf + (HCA_QC_ROW(C, sf, c) + (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16));    // int16 lines l16*8 .. +7
     return t;
 }
 template <bool PLAIN, int C>
@@ -1234,7 +1352,8 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
     const uint32_t f_first = has_halo ? f0 - 1 : f0;
     const uint8_t* rec = rec0 + (uint64_t)f_first * F.record_bytes;         // record of the step's frame
     FramePre<C> pre = tr_prefetch_frame<PLAIN, C>(rec, lane);
-    TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, rec, 7, slot < (uint32_t)C ? slot : 0, l16) : tr_fetch<PLAIN, C>(F, rec, slot / C, slot % C, l16);
+    const uint32_t g0 = st.first_frame;                      // group frame number of the stream's frame 0
+    TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f_first), 7, slot < (uint32_t)C ? slot : 0, l16) : tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f_first), slot / C, slot % C, l16);
     uint32_t f = f_first, pass = has_halo ? PASSES : 0;    // pass >= PASSES marks the halo steps (four channels each)
     uint32_t ring = RING;                                   // ring position of a normal step's slot 0
     const uint32_t f_end = f0 + nf;
@@ -1257,8 +1376,8 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
         {   // next step's lines: same frame's next step, or the next frame's first pass
             if (!last) {
                 const uint32_t tn = halo ? 7 * C + (hc + 4 < (uint32_t)C ? hc + 4 : 0) : t + 4;
-                ft = tr_fetch<PLAIN, C>(F, rec, tn / C, tn % C, l16);
-            } else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, rec + F.record_bytes, slot / C, slot % C, l16);
+                ft = tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f), tn / C, tn % C, l16);
+            } else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f + 1), slot / C, slot % C, l16);
         }
         f2 x[4];
         tr_load_spectra<PLAIN, C>(F, T, cur, sf, c, slot, l16, nproc, x);
@@ -1467,15 +1586,17 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
         wave_lds_sync();
         return true;
     };
-    // row 0 of this lane's unit's quantised lines in the frame of step s (subframe sf is sf*C*256 bytes on), and where this
-    // lane's bands l16*8 .. +7 sit in a row: 16 bytes of int16 or 8 bytes of int8
-    // (as a 32-bit offset from the record before the run's first one: the run's records and its halo's are within 9 records of it)
-    const uint8_t* rec_run = rec0 + ((uint64_t)f0 - (f0 > 0 ? 1 : 0)) * F.record_bytes;
+    // row (0, c) of this lane's unit's quantised lines in the frame of step s (subframe sf is sf * C * 4 quarters on), and where
+    // this lane's bands l16*8 .. +7 sit in a row: 16 bytes of int16 (quarter l16 / 4) or 8 bytes of int8 (quarter l16 / 8)
+    // (as a 32-bit offset from the tile of the frame before the run's first one: the run and its halo span at most two tiles)
+    const uint32_t g_run = st.first_frame + f0 - (f0 > 0 ? 1 : 0);
+    const uint8_t* rec_run = a.scratch + a.qc_offset + (uint64_t)(g_run >> 6) * HCA_QC_TILE(C);
     auto row0 = [&](int s) {
         bool live; const uint32_t f = unit_frame(u, s, live);
-        return (f - (f0 - (f0 > 0 ? 1 : 0))) * F.record_bytes + HCA_REC_QC(C, 0, c);
+        const uint32_t g = st.first_frame + f;
+        return ((g >> 6) - (g_run >> 6)) * HCA_QC_TILE(C) + (g & 63) * 64 + HCA_QC_ROW(C, 0, c);
     };
-    auto lane_off = [&](bool narrow) { return narrow ? l16 * 8 : l16 * 16; };
+    auto lane_off = [&](bool narrow) { return narrow ? (l16 >> 3) * HCA_QC_QUARTER + (l16 & 7) * 8 : (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16; };
     // (step_narrow: all four units' frames are int8 -- wave-uniform; mine: this lane's is)
     auto dct_pass = [&](const uint4& q, bool step_narrow, bool mine, f2 x[4]) {
         const float4 g0 = *(const float4*)(G + u * 128 + l16 * 8), g1 = *(const float4*)(G + u * 128 + l16 * 8 + 4);
@@ -1503,7 +1624,7 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
     uint32_t rows = row0(-1);                              // rows of the current step's frame
     uint4 q = make_uint4(0, 0, 0, 0);
     {   // (the one load of a run that waits for a flag first)
-        const uint8_t* p = rec_run + (rows + 7 * C * 256 + lane_off(my_narrow(pre)));
+        const uint8_t* p = rec_run + (rows + HCA_QC_ROW(C, 7, 0) + lane_off(my_narrow(pre)));
         if (NW && all_narrow(pre)) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
     }
     const uint32_t last_count = unit_count(3);             // frames of the last group: steps below it have every group at work
@@ -1528,7 +1649,7 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
             // out by that frame's own flag, which came with `pre` seven passes ago)
             {   // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
                 const uint8_t* p; bool ld8;
-                if (sf < 7) { p = rec_run + (rows + (sf + 1) * (C * 256) + loff); ld8 = NW && step_narrow; }
+                if (sf < 7) { p = rec_run + (rows + HCA_QC_ROW(C, sf + 1, 0) + loff); ld8 = NW && step_narrow; }
                 else {                                     // the next step's first row, laid out by that frame's own flag (it came with `pre` seven passes ago)
                     const bool more = s + 1 < (int)h;
                     p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);

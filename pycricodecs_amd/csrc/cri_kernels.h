@@ -9,7 +9,7 @@ namespace cri {
 struct HcaDecArgs {
     const uint8_t* in;             // input blob (device)
     uint8_t* out;                  // output blob (device)
-    uint8_t* scratch;              // frame records
+    uint8_t* scratch;              // frame records, quantised lines, band code descriptions
     int32_t* status;               // per item, may be null
     const HcaFormat* formats;
     const HcaStream* streams;      // sorted by format
@@ -29,6 +29,7 @@ struct HcaDecArgs {
     uint32_t narrow;               // 1: k_hca_transform_plain reads this format's records: int8 lines where the values allow it
     uint32_t pad1;
     uint64_t in_bytes;             // size of the input blob (the intake's 16-byte loads stop there)
+    uint64_t qc_offset;            // scratch byte offset of this group's quantised lines (tile-major, cri_types.h)
     uint64_t resg_offset;          // scratch byte offset of this group's band code descriptions: [tile][C][8 blocks][64 lanes] uint4 (16 bands x 1 byte)
     float* float_out;              // validation runs only (cri_job_run_floats), else null: every frame's samples before the int16
                                    // conversion (hca.cpp:1987-1992 wave[][]), [frame][1024][C] floats from HcaStream::float_offset on

@@ -43,18 +43,30 @@ struct HcaStream {
     uint32_t pad3;
 };
 
-// Layout of one decoded-frame record in scratch (written by hca_unpack, read by hca_transform):
-//   int16 qc[8][C][128]  | uint8 scalefactors[C][128] | uint8 intensity[C][8] | uint32 tail[4]
-//   tail = { packed_noise_level, status (0 or CRI_ERR_HCA_FRAME), flags (bit c: channel c reuses intensity[1..7]), bits_read }
-// (an odd number of 128-byte lines: k_hca_parse stores the same 64 B of 16 consecutive records per instruction, and with an
-//  even line stride those would land on a quarter of the L2 channels)
-static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels * (2048u + 128u + 8u) + 16u) + 127u) >> 7) | 1u) << 7; }
-#define HCA_REC_QC(C, sf, c) ((((sf) * (C)) + (c)) * 256u)
-#define HCA_REC_SF(C, c) ((C) * 2048u + (c) * 128u)
-#define HCA_REC_INT(C, c) ((C) * 2176u + (c) * 8u)
-#define HCA_REC_TAIL(C) ((C) * 2184u)
-#define HCA_REC_NARROW 0x40000000u   // tail flags: the frame's quantised lines are int8 and NEGATED, 128 B per (subframe, channel) row at the row's int16 place
-                                     // (formats with HcaDecArgs::narrow only: k_hca_parse -> k_hca_transform_plain)
+// Between k_hca_parse and the transform kernels a frame's unpacked state travels through scratch in two places.
+//
+// 1. Frame record (per frame, consecutive in frame order within a format group; HcaStream::scratch_offset = the stream's first):
+//      uint8 scalefactors[C][128] | uint8 intensity[C][8] | uint32 tail[4]
+//      tail = { packed_noise_level, status (0 or CRI_ERR_HCA_FRAME), flags (bit c: channel c reuses intensity[1..7];
+//               HCA_REC_NARROW), generator draws (v3.0 noise fill; k_hca_noise_scan turns it into a prefix) }
+//    (an odd number of 64-byte lines: k_hca_parse stores the same 64 B of 16 consecutive records per instruction, and with an
+//     even line stride those would land on a fraction of the L2 channels)
+static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels * (128u + 8u) + 16u) + 63u) >> 6) | 1u) << 6; }
+#define HCA_REC_SF(C, c) ((c) * 128u)
+#define HCA_REC_INT(C, c) ((C) * 128u + (c) * 8u)
+#define HCA_REC_TAIL(C) ((C) * 136u)
+#define HCA_REC_NARROW 0x40000000u   // tail flags: the frame's quantised lines are int8 and NEGATED (formats with HcaDecArgs::narrow
+                                     // only: k_hca_parse -> k_hca_transform_plain)
+//
+// 2. Quantised lines, tile-major (a tile = the 64 consecutive frames one parse wave owns; HcaDecArgs::qc_offset = the group's
+//    first tile):  [tile][subframe 8][channel C][quarter 4][frame 64][64 B]
+//    A row of 128 lines is 256 B of int16 (four quarters of 32 lines) or, for HCA_REC_NARROW frames, 128 B of int8 (quarters 0
+//    and 1, 64 lines each; 2 and 3 unused).  What a parse wave has ready at a flush -- the same 64 B of a row for each of its
+//    64 frames -- is therefore 4 KB of contiguous memory (four fully coalesced 1 KB stores) instead of 64 pieces a record apart,
+//    and a transform lane still finds its 8 lines in one 8- or 16-byte piece.
+#define HCA_QC_QUARTER 4096u                                          /* 64 frames x 64 B */
+#define HCA_QC_ROW(C, sf, c) ((((sf) * (C)) + (c)) * (4u * HCA_QC_QUARTER))   /* row (sf, c), quarter 0, frame 0, inside a tile */
+#define HCA_QC_TILE(C) (8u * (C) * 4u * HCA_QC_QUARTER)              /* bytes of a tile: 2 KB per frame and channel */
 
 // ---- ADX ---------------------------------------------------------------------------------------------------
 struct AdxStream {
