@@ -355,16 +355,21 @@ void launch_adx_encode(const AdxArgs& a, hipStream_t s) {
 // walks its recurrence sample by sample with v_readlane broadcasts, identically in every lane of a half, the decoder hands
 // a frame's products through LDS to registers (see k_adx_decode_wpf).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t half_min(int32_t v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { const int32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+// min / max over the 32 lanes of a half, the result in every lane: xor 1, 2 as quad permutes, xor 4 and 8 as the mirrors of 8 and
+// 16 lanes (lanes of a reduced group already agree), xor 16 through the swizzle crossbar -- DPP modifiers on the min / max
+// themselves, so the five steps cost five dependent VALU instructions and one crossbar hop instead of five LDS round trips
+template <bool MAX>
+__device__ __forceinline__ int32_t half_reduce(int32_t v) {
+    auto op = [](int32_t a, int32_t b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));       // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));      // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));      // row_mirror
+    v = op(v, __builtin_amdgcn_ds_swizzle(v, 0x401F));                        // lane ^ 16 (bit mode: and 0x1F, xor 0x10)
     return v;
 }
-__device__ __forceinline__ int32_t half_max(int32_t v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { const int32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
+__device__ __forceinline__ int32_t half_min(int32_t v) { return half_reduce<false>(v); }
+__device__ __forceinline__ int32_t half_max(int32_t v) { return half_reduce<true>(v); }
 
 // Decode.  A wave per file runs alone on its SIMD, so every dependent instruction and every memory round trip is paid in
 // full; the kernel is organised around that:
@@ -563,10 +568,14 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
     for (uint64_t i = (uint64_t)done * 32 * C + lane; i < (uint64_t)S.samples * C; i += 64) ((int16_t*)out)[i] = 0;
 }
 
+// (an instance per channel count, both launched over all streams: a block whose stream has the other count leaves at once)
+template <int C>
 __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
     __shared__ uint8_t blk_img[40];
+    __shared__ __attribute__((aligned(16))) int32_t xl[64];   // a frame's (sample << 12), by lane
     const AdxStream S = a.streams[blockIdx.x];
-    const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
+    if (S.channels != (uint32_t)C) return;
+    const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31;
     const bool act = half < C;
     const uint32_t chain = S.first_chain + (act ? half : 0);
     int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
@@ -594,12 +603,12 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
             if (fr >= S.frames) break;
             const int32_t x = xr[t];
             // pass A (adx.cpp:221-230): residual against the two previous RAW samples; lanes 0/1 of a block see the carried history
-            int32_t p1 = __shfl_up(x, 1, 32), p2 = __shfl_up(x, 2, 32);
+            // (the previous lanes' samples: wave_shr:1 twice; what the first two lanes of a half receive is replaced just below)
+            int32_t p1 = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, false), p2 = __builtin_amdgcn_update_dpp(0, p1, 0x138, 0xF, 0xF, false);
             if (s == 0) { p1 = h1; p2 = h2; } else if (s == 1) p2 = h1;
             const int32_t r = ((int32_t)((uint32_t)x << 12) - c0 * p1 - c1 * p2) >> 12;
             int32_t mn = half_min(r < 0 ? r : 0), mx = half_max(r > 0 ? r : 0);
             const bool silent = !mn && !mx;                                            // adx.cpp:231-234
-            const int32_t raw1 = __shfl(x, (int)(half * 32 + 31)), raw2 = __shfl(x, (int)(half * 32 + 30));
             const int32_t qa = mx / 7, qb = (int32_t)((uint32_t)(-mn) >> 3);           // Maximum/Limit, Minimum/~Limit with Limit = 7
             uint32_t scale = (uint32_t)(qa > qb ? qa : qb) & 0xFFFF;
             if (scale > 0x1000) scale = 0x1000;
@@ -611,30 +620,45 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
             } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
             else word = scale;
             if (!scale) scale = 1;
-            // pass B (adx.cpp:254-271) is one serial chain of 32 steps per block, so its length in dependent instructions
-            // is what the kernel's time is made of.  delta / scale (C division, then a clamp to [-8, 7]) only needs the
-            // quotient up to 9: |delta| is capped at 9 * scale (< 2^24, exact in fp32) and floor((n + 0.5) / scale) comes
-            // out of one fma and a truncation -- the 0.5 keeps every exact quotient 0.5 / scale >= 1.2e-4 away from an
-            // integer, against a relative error of 2^-23.  Everything else is 24-bit multiplies and selects.
-            const float rcp = 1.0f / (float)scale, half_rcp = 0.5f * rcp;
-            const int32_t hs = (int32_t)(scale >> 1), cap = 9 * (int32_t)scale, iscale = (int32_t)scale;
+            // pass B (adx.cpp:254-271) is one serial chain of 32 steps per block, so its length in dependent instructions is
+            // what the kernel's time is made of.  The quantiser -- delta +- scale/2, C division by scale, clamp to [-8, 7] -- is
+            // a monotone step function of delta with 15 steps, so the code is a COUNT: lanes 0..14 of a half hold the
+            // thresholds  delta >= -(j*scale - hs) + 1 (j = 8..1: code > -j)  and  delta >= j*scale - hs (j = 1..7: code >= j),
+            // scaled by 4096 so that they apply to (x << 12) - prediction before its shift, and
+            //     code = popcount(compare mask of the half) - 8.
+            // The simulated sample is code * scale + (prediction >> 12) exactly ((code * scale) << 12 has no low bits).  Per
+            // step the next one waits for: multiply-add, subtract, compare, popcount (scalar), select, multiply-add, clamp.
+            const int32_t hs = (int32_t)(scale >> 1), iscale = (int32_t)scale;
+            int32_t thr;
+            {
+                const int32_t j = (int32_t)s;
+                const int32_t t = j < 8 ? 1 - ((8 - j) * iscale - hs) : (j - 7) * iscale - hs;
+                thr = j < 15 ? t * 4096 : 0x7FFFFFFF;
+            }
+            // (a lone wave issues an instruction every four cycles whatever it is, so the instruction count per step matters as
+            //  much as the chain: the sample of step k comes to the half's lanes through one crossbar read, the two halves'
+            //  counts through one vector popcount each)
+            // (x << 12) of the half's 32 samples in every lane, gathered before the chain starts: one LDS store per lane, eight
+            // 16-byte broadcast reads
+            int32_t xs[32];
+            wave_lds_sync();
+            xl[lane] = (int32_t)((uint32_t)x << 12);
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 32; k += 4) { const int4 q = *(const int4*)&xl[half * 32 + k]; xs[k] = q.x; xs[k + 1] = q.y; xs[k + 2] = q.z; xs[k + 3] = q.w; }
+            const int32_t raw1 = xs[31] >> 12, raw2 = xs[30] >> 12;                   // the half's last two raw samples
+            __builtin_amdgcn_sched_barrier(0);                                         // (keep the gather out of the chain: there every read would be waited for)
             int32_t g1 = h1, g2 = h2, mine = 0;
             int32_t c1g2 = __mul24(c1, g2);
 #pragma unroll
             for (int k = 0; k < 32; k++) {
-                const int32_t x0 = __builtin_amdgcn_readlane(x, k), x1 = __builtin_amdgcn_readlane(x, 32 + k);
-                const int32_t xs = (int32_t)((uint32_t)(half ? x1 : x0) << 12);
                 const int32_t pred = __mul24(c0, g1) + c1g2;
-                const int32_t d = (xs - pred) >> 12;
-                const int32_t ad = d < 0 ? -d : d;
-                int32_t an = ad + hs;
-                an = an < cap ? an : cap;
-                int32_t q = (int32_t)__builtin_fmaf((float)an, rcp, half_rcp);
-                const bool neg = d < 0;
-                const int32_t qmax = neg ? 8 : 7;
-                q = q < qmax ? q : qmax;
-                const int32_t code = neg ? -q : q;
-                int32_t sim = (int32_t)(((uint32_t)__mul24(code, iscale) << 12) + (uint32_t)pred) >> 12;
+                const uint64_t m = __ballot((xs[k] - pred) >= thr);
+                // code = popcount(the half's compare bits) - 8 (v_bcnt_u32_b32 adds its second operand)
+                const uint32_t mh = (C == 1 || !half) ? (uint32_t)m : (uint32_t)(m >> 32);
+                const int32_t code = (int32_t)__builtin_popcount(mh) + (-8);
+                int32_t sim;                                                           // code * scale + (pred >> 12): 24-bit operands
+                asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(sim) : "v"(code), "v"(iscale), "v"(pred >> 12));
                 sim = clamp_sym(sim, 0x7FFF);
                 c1g2 = __mul24(c1, g1);
                 g2 = g1; g1 = sim;
@@ -660,7 +684,9 @@ void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s) 
     if (n_streams) hipLaunchKernelGGL(k_adx_decode_wpf, dim3(n_streams), dim3(64), 0, s, a);
 }
 void launch_adx_encode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s) {
-    if (n_streams) hipLaunchKernelGGL(k_adx_encode_wpf, dim3(n_streams), dim3(64), 0, s, a);
+    if (!n_streams) return;
+    hipLaunchKernelGGL(k_adx_encode_wpf<2>, dim3(n_streams), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_adx_encode_wpf<1>, dim3(n_streams), dim3(64), 0, s, a);
 }
 
 }  // namespace cri
