@@ -344,7 +344,9 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.noise_fill = F.min_res == 0 ? 1 : 0;
         if (a.noise_fill) a.plain = 0;                                 // noise reconstruction lives in the general variant of the transform
-        a.narrow = (a.plain && a.channels <= 2) ? 1 : 0;          // (k_hca_transform_plain<1>, <2> are the instances that read int8 lines)
+        // int8 lines are read by the mono / stereo instances: k_hca_transform_plain<1>, <2> and (joint stereo / HFR formats)
+        // k_hca_transform<false, 1>, <false, 2>; v3.0 noise fill and the wider layouts keep int16
+        a.narrow = (a.channels <= 2 && !a.noise_fill) ? 1 : 0;
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
         j->hca_dec.push_back(a);
@@ -381,15 +383,19 @@ extern "C" int cri_job_create_hca_decode_items(const cri_items* items, const uin
 }
 
 
-// Mapping choice: wave-per-file fills the chip with ~1 k files but spends 62 of 64 lanes idle in the
-// serial section; lane-per-chain is 16x cheaper per sample but needs tens of thousands of chains.  CRICODECS_ADX_MAPPING
-// = "chain" | "file" overrides the heuristic (tests use it to cover both kernels).
-static bool adx_pick_wave_per_file(bool all_std, size_t n_streams) {
+// Mapping choice: wave-per-file fills the chip with ~1 k files but spends most lanes idle in the serial
+// section; lane-per-chain is cheaper per sample but one wave of 64 chains per SIMD needs 65 536 chains just to occupy the chip
+// once.  Measured on 1 s stereo files (tools/debug/adx_chain_sweep.py, profiles/r02_adx_chain_sweep.jsonl): the lane-per-chain
+// kernels take the same 7.5 ms (decode) / 17 ms (encode) for anything up to 32 768 chains and scale linearly beyond; the
+// wave-per-file kernels saturate at 4.5 G (decode) / 3.1 G (encode) blocks/s from ~4 000 files.  Decode crosses over between
+// 8 192 and 16 384 files (5.6 vs 7.5 ms, 10.9 vs 7.7 ms); encode between 32 768 and 100 000 (31.7 vs 35.0 ms; 3.1 vs 3.4 G blocks/s).
+// CRICODECS_ADX_MAPPING = "chain" | "file" overrides the choice (tests use it to cover both kernels).
+static bool adx_pick_wave_per_file(bool all_std, size_t n_streams, bool encode) {
     if (!all_std || n_streams == 0) return false;
     const char* e = getenv("CRICODECS_ADX_MAPPING");
     if (e && !strcmp(e, "chain")) return false;
     if (e && !strcmp(e, "file")) return true;
-    return n_streams <= 8192;
+    return n_streams <= (encode ? 65536u : 12288u);
 }
 
 // LDS plan of the lane-per-chain ADX kernels.  A wave stages, for each of its files, T rows of blocks and of PCM in LDS
@@ -478,7 +484,7 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
     j->adx.chains = (uint32_t)chain_stream.size();
     plan.finish(j->adx);
     j->adx_streams = (uint32_t)streams.size();
-    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size());
+    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), false);
     if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
@@ -882,7 +888,7 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     j->adx.chains = (uint32_t)chain_stream.size();
     plan.finish(j->adx);
     j->adx_streams = (uint32_t)streams.size();
-    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size());
+    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), true);
     if (j->adx_wave_per_file) j->dominant = "k_adx_encode_wpf";
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }

@@ -1104,7 +1104,7 @@ __device__ __forceinline__ FramePre<C> tr_prefetch_frame(const uint8_t* rec, uin
 // Table lookups go to LDS copies and are unconditional (selects instead of branches around loads).
 template <bool PLAIN, int C>
 __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, const uint8_t* rec0, uint32_t f, uint32_t lane, int nproc,
-                                               const FramePre<C>& pre, uint32_t ath2) {
+                                               const FramePre<C>& pre, uint32_t ath2, bool narrow) {
     const uint32_t packed = __builtin_amdgcn_readfirstlane(pre.packed);
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, con
             res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
             res = v > 0 ? res : 0u;
             const float gain = T.scale[v & 63] * T.range[res & 15];
-            g[h] = i < coded ? gain : 0.0f;
+            g[h] = i < coded ? (narrow ? -gain : gain) : 0.0f;      // (int8 lines are stored negated: negated gains, which is exact)
         }
         *(float2*)(T.G + c * 128 + 2 * lane) = make_float2(g[0], g[1]);
     }
@@ -1191,13 +1191,16 @@ __device__ __forceinline__ void tr_setup_frame(const Fmt& F, const TrLds& T, con
 // reconstruction and intensity stereo (hca.cpp:1566, 1638-1683, 1696-1714)
 struct TrFetch { uint4 q; };         // quantised lines of (sf, c) for this lane's 8 bands
 template <bool PLAIN, int C>
-__device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* qcf, uint32_t sf, uint32_t c, uint32_t l16) {
+__device__ __forceinline__ TrFetch tr_fetch(const Fmt& F, const uint8_t* qcf, uint32_t sf, uint32_t c, uint32_t l16, bool narrow) {
     TrFetch t;
-    t.q = *(const uint4*)(qcf + (HCA_QC_ROW(C, sf, c) + (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16));    // int16 lines l16*8 .. +7
+    if (narrow) {                                                                                         // int8 lines l16*8 .. +7 (wave-uniform)
+        const uint2 h = *(const uint2*)(qcf + (HCA_QC_ROW(C, sf, c) + (l16 >> 3) * HCA_QC_QUARTER + (l16 & 7) * 8));
+        t.q = make_uint4(h.x, h.y, 0, 0);
+    } else t.q = *(const uint4*)(qcf + (HCA_QC_ROW(C, sf, c) + (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16));    // int16 lines l16*8 .. +7
     return t;
 }
 template <bool PLAIN, int C>
-__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t slot, uint32_t l16, int nproc, f2 x[4]) {
+__device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, const TrFetch& ft, uint32_t sf, uint32_t c, uint32_t slot, uint32_t l16, int nproc, f2 x[4], bool narrow) {
     const bool secondary = F.type(c) == CRI_CH_SECONDARY;
     const uint32_t qw[4] = {ft.q.x, ft.q.y, ft.q.z, ft.q.w};
     if (PLAIN) {
@@ -1218,7 +1221,8 @@ __device__ __forceinline__ void tr_load_spectra(const Fmt& F, const TrLds& T, co
     const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
     float own[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) own[r] = g[r] * (float)(int)(int16_t)(qw[r >> 1] >> (16 * (r & 1)));   // gain is 0 past the coded bands
+    for (int r = 0; r < 8; r++)                                                                         // gain is 0 past the coded bands
+        own[r] = g[r] * (narrow ? (float)(int)(int8_t)(qw[r >> 2] >> (8 * (r & 3))) : (float)(int)(int16_t)(qw[r >> 1] >> (16 * (r & 1))));
     float* srow = T.S + slot * 128;
     *(float4*)(srow + l16 * 8) = make_float4(own[0], own[1], own[2], own[3]);
     *(float4*)(srow + l16 * 8 + 4) = make_float4(own[4], own[5], own[6], own[7]);
@@ -1353,7 +1357,13 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
     const uint8_t* rec = rec0 + (uint64_t)f_first * F.record_bytes;         // record of the step's frame
     FramePre<C> pre = tr_prefetch_frame<PLAIN, C>(rec, lane);
     const uint32_t g0 = st.first_frame;                      // group frame number of the stream's frame 0
-    TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f_first), 7, slot < (uint32_t)C ? slot : 0, l16) : tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f_first), slot / C, slot % C, l16);
+    // int8 (HCA_REC_NARROW) lines: the mono and stereo instances of the joint-stereo / HFR formats take them too (frames whose tile
+    // allows it, see k_hca_parse); a frame's flag arrives with its setup inputs
+    constexpr bool NWG = !PLAIN && C <= 2;
+    bool ft_narrow = NWG && (__builtin_amdgcn_readfirstlane(pre.flags) & HCA_REC_NARROW) != 0;      // form of the lines in `ft`
+    TrFetch ft = has_halo ? tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f_first), 7, slot < (uint32_t)C ? slot : 0, l16, ft_narrow)
+                          : tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f_first), slot / C, slot % C, l16, ft_narrow);
+    bool cur_narrow = ft_narrow;
     uint32_t f = f_first, pass = has_halo ? PASSES : 0;    // pass >= PASSES marks the halo steps (four channels each)
     uint32_t ring = RING;                                   // ring position of a normal step's slot 0
     const uint32_t f_end = f0 + nf;
@@ -1368,7 +1378,8 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
             const int32_t status = __builtin_amdgcn_readfirstlane(cur_pre.status);
             if (status != 0) { if (!halo && lane == 0 && a.status) atomicMin(a.status + st.item, status); return; }
             if (f + 1 < f_end) pre = tr_prefetch_frame<PLAIN, C>(rec + F.record_bytes, lane);
-            tr_setup_frame<PLAIN, C>(F, T, rec0, f, lane, nproc, cur_pre, ath2);
+            cur_narrow = NWG && (__builtin_amdgcn_readfirstlane(cur_pre.flags) & HCA_REC_NARROW) != 0;
+            tr_setup_frame<PLAIN, C>(F, T, rec0, f, lane, nproc, cur_pre, ath2, cur_narrow);
         }
         const uint32_t t = halo ? 7 * C + (hact ? hc : 0) : pass * 4 + slot, sf = t / C, c = t % C;
         const TrFetch cur = ft;
@@ -1376,11 +1387,14 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
         {   // next step's lines: same frame's next step, or the next frame's first pass
             if (!last) {
                 const uint32_t tn = halo ? 7 * C + (hc + 4 < (uint32_t)C ? hc + 4 : 0) : t + 4;
-                ft = tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f), tn / C, tn % C, l16);
-            } else if (f + 1 < f_end) ft = tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f + 1), slot / C, slot % C, l16);
+                ft = tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f), tn / C, tn % C, l16, cur_narrow);
+            } else if (f + 1 < f_end) {
+                ft_narrow = NWG && (__builtin_amdgcn_readfirstlane(pre.flags) & HCA_REC_NARROW) != 0;
+                ft = tr_fetch<PLAIN, C>(F, qc_frame(a, C, g0 + f + 1), slot / C, slot % C, l16, ft_narrow);
+            }
         }
         f2 x[4];
-        tr_load_spectra<PLAIN, C>(F, T, cur, sf, c, slot, l16, nproc, x);
+        tr_load_spectra<PLAIN, C>(F, T, cur, sf, c, slot, l16, nproc, x, cur_narrow);
         dct4_inplace(x, L);
         const uint32_t dslot = halo ? ring - C + hc : ring + slot;
         float* d = T.D + (dslot & (RING - 1)) * TR_DSTRIDE;
