@@ -33,12 +33,39 @@ template <int X, int K> __device__ __forceinline__ void sumdiff_cross(f2 p[4], c
 #pragma unroll
     for (int k = 0; k < 4; k++) p[k] = __builtin_elementwise_fma(p[k], sg, lane16_xor2<X>(p[k]));   // a+b in the `a` lane, a-b in the `b` lane
 }
+// partner(v) * (NEG ? -c : c) in ONE instruction where the exchange is a DPP pattern (lane16 ^ 1, 2, 8): v_mul_f32 takes the
+// permuted operand itself, so the v_mov_b32_dpp that would feed a packed multiply disappears (a packed multiply cannot carry
+// DPP).  The product is the same single IEEE multiply.
+template <int X, bool NEG> __device__ __forceinline__ float mul_partner(float v, float c) {
+    float r;
+    if (X == 1) {
+        if (NEG) asm("v_mul_f32_dpp %0, %1, -%2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));
+        else asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));
+    } else if (X == 2) {
+        if (NEG) asm("v_mul_f32_dpp %0, %1, -%2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));
+        else asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));
+    } else {
+        if (NEG) asm("v_mul_f32_dpp %0, %1, -%2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));
+        else asm("v_mul_f32_dpp %0, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));
+    }
+    return r;
+}
 template <int X, int ST> __device__ __forceinline__ void rotate_cross(f2 p[4], const DctLane& L) {
     const f2 sn = {L.s[ST], L.s[ST]};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const f2 p1 = p[k] * sn;
-        const f2 p2 = lane16_xor2<X>(p[k]) * DCT_SIGNED2(L.c[ST], ST, k);          // -b*cos in the `a` lane, +a*cos in the `b` lane
+        f2 p2;                                                                     // -b*cos in the `a` lane, +a*cos in the `b` lane
+#if defined(CRI_XOR8_SWIZZLE) || defined(CRI_DCT_NO_DPP_MUL)
+        p2 = lane16_xor2<X>(p[k]) * DCT_SIGNED2(L.c[ST], ST, k);
+#else
+        if (X == 4) p2 = lane16_xor2<X>(p[k]) * DCT_SIGNED2(L.c[ST], ST, k);       // lane16 ^ 4 goes through the swizzle crossbar
+        else {
+            // (the register's sign is a constant once the loop is unrolled)
+            p2.x = HCA_DCT_REGSIGN(ST, 2 * k) ? mul_partner<X, true>(p[k].x, L.c[ST]) : mul_partner<X, false>(p[k].x, L.c[ST]);
+            p2.y = HCA_DCT_REGSIGN(ST, 2 * k + 1) ? mul_partner<X, true>(p[k].y, L.c[ST]) : mul_partner<X, false>(p[k].y, L.c[ST]);
+        }
+#endif
         p[k] = p1 + p2;
     }
 }

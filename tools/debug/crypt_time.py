@@ -6,7 +6,7 @@ import oracle_lib as O
 from pycricodecs_amd import synth
 from pycricodecs_amd.batch import Job
 KEY = 0xCF222F1FE0748978
-uniq = [O.hca_encode(synth.wav(i, 480000, 2, 48000), 1) for i in range(4)]
+uniq = [O.hca_encode(synth.wav(i, 480000, 2, 48000), 1) for i in range(4)]  # 10 s stereo
 items = [uniq[i % 4] for i in range(1000)]
 job = Job.hca_crypt(items, 1, 56, keys=[KEY] * len(items))
 bufs = job.alloc("cuda:0")
