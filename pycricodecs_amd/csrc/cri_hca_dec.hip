@@ -1,14 +1,12 @@
 // cri_hca_dec.hip -- HCA decode kernels for gfx950 (MI355X, wave64).
 //
 // Reference functions replaced (/root/reference/CriCodecs/hca.cpp):
-//   k_hca_prepare    sync word + crc16_checksum (186-211) + cipher_decrypt (491-497): the head of
-//                    clHCA_DecodeBlock_unpack (1159-1169).  One wave per tile of 64 frames: coalesced loads,
-//                    LDS transpose, one LANE per frame for the (serial) CRC, coalesced store of the deciphered
-//                    frames as big-endian words in a lane-interleaved tile [row][64 frames].
-//   k_hca_parse      the rest of clHCA_DecodeBlock_unpack (1172-1204): unpack_scalefactors (1290-1358),
-//                    unpack_intensity (1361-1441), calculate_resolution (1444-1494) and the bit parse of
-//                    dequantize_coefficients (1540-1571).  The variable-length parse is a serial chain per frame,
-//                    so it runs one LANE per frame (64 frames per wave) on a register bit buffer fed from the tile.
+//   k_hca_parse      all of clHCA_DecodeBlock_unpack (1159-1204): sync word + crc16_checksum (186-211) + cipher_decrypt (491-497)
+//                    as the frame's bytes enter the kernel's bit feed, then unpack_scalefactors (1290-1358), unpack_intensity
+//                    (1361-1441), calculate_resolution (1444-1494) and the bit parse of dequantize_coefficients (1540-1571).
+//                    The variable-length parse is a serial chain per frame, so it runs one LANE per frame (64 frames per wave)
+//                    on a sliding window fed from the lane's LDS ring; results leave as small frame records plus tile-major
+//                    quantised lines (cri_types.h).
 //   k_hca_transform<PLAIN, C>  calculate_gain (1498-1507), the float half of dequantize (1566),
 //                    reconstruct_high_frequency (1638-1683), apply_intensity_stereo (1696-1714), imdct_transform
 //                    (1898-2019), clHCA_ReadSamples16 (339-360) and HcaDecode's delay/trim (3401-3452).  One WAVE per run of
