@@ -344,11 +344,13 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
         a.noise_fill = F.min_res == 0 ? 1 : 0;
         if (a.noise_fill) a.plain = 0;                                 // noise reconstruction lives in the general variant of the transform
-        // int8 lines are read by the mono / stereo instances: k_hca_transform_plain<1>, <2> and (joint stereo / HFR formats)
-        // k_hca_transform<false, 1>, <false, 2>; v3.0 noise fill and the wider layouts keep int16
-        a.narrow = (a.channels <= 2 && !a.noise_fill) ? 1 : 0;
+        // int8 lines are read by k_hca_transform_plain<1>, <2>, <4> and (joint stereo / HFR formats) k_hca_transform<false, 1>,
+        // <false, 2>; v3.0 noise fill and the wider layouts keep int16
+        a.narrow = (!a.noise_fill && (a.channels <= 2 || (a.channels == 4 && a.plain))) ? 1 : 0;
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
+        a.inlane = (!a.plain && !a.noise_fill && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) ? 1 : 0;
+        if (a.channels == 4 && a.inlane && !a.noise_fill) a.narrow = 1;
         j->hca_dec.push_back(a);
         j->hca_group_first_record.push_back(streams[b].scratch_offset);
         b = e;

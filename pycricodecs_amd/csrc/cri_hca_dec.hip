@@ -1486,17 +1486,19 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
 // eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of HCA_RUN
 // frames, but its 4 slots ("units") are 4/C groups x C channels: each group takes a contiguous part of the run and walks
 // it frame by frame, subframe by subframe, after one halo pass (the subframe before its first one).
-struct PlainPre { uint2 ps; uint32_t fl; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
+struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
 #ifndef CRI_PLAIN_WAVES
 #define CRI_PLAIN_WAVES 4
 #endif
-template <int C, bool FLT>
-__global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
+// JOINT: the format has high-frequency reconstruction and / or intensity stereo (a stereo pair is an even channel and the next one,
+// i.e. two neighbouring units of one group): each pass stages the units' dequantised lines in LDS, a reconstructed band reads its
+// source band there, a secondary reads its primary's row.
+template <int C, bool FLT, bool JOINT>
+__global__ __launch_bounds__(64, JOINT ? 3 : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
-    constexpr bool NW = C <= 2;                            // int8 lines (HCA_REC_NARROW) are read by the mono and stereo instances: the
-                                                           // four-channel one is at its register limit without that and spills with it
+    constexpr bool NW = true;                              // int8 lines (HCA_REC_NARROW) are read by all three instances
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
     float* G = (float*)smem;                               // [4][128] gains of each unit's frame
@@ -1529,6 +1531,60 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
     scale[lane] = HCA_DEQ_SCALE[lane];
     if (lane < 16) range[lane] = HCA_DEQ_RANGE[lane];
     curve[lane] = HCA_CURVE_TO_RES[lane]; if (lane < 2) curve[64 + lane] = HCA_CURVE_TO_RES[64 + lane];
+    // JOINT only: S[4][128] the pass's dequantised lines, hconv[4][128] HFR scale of a reconstructed band (per unit's frame),
+    // conv[128], iratio[16], zero[4], ratio[4][8] intensity ratio of the unit's pair per subframe, sfb[4][128] scalefactor bytes,
+    // hlow[128] / hgrp[128] source band and HFR group of a reconstructed band (format constants)
+    float* S = (float*)(curve + 80 + 2048 + 1024); float* hconv = S + 512; float* conv = hconv + 512; float* iratio = conv + 128;
+    float* ratio = iratio + 16; float* zero = ratio + 32; uint8_t* sfb = (uint8_t*)(zero + 4); uint8_t* hlow = sfb + 512; uint8_t* hgrp = hlow + 128;
+    constexpr uint32_t ZERO_IDX = 512 + 512 + 128 + 16 + 32;            // (index of `zero` from S)
+    int nproc = 0;                                         // bands reconstructed by HFR (hca.cpp:1650-1676), as in k_hca_transform
+    if (JOINT) {
+        conv[lane] = HCA_SCALE_CONV[lane]; conv[lane + 64] = HCA_SCALE_CONV[lane + 64];
+        if (lane < 16) iratio[lane] = HCA_INTENSITY_RATIO[lane];
+        hlow[lane] = 0; hlow[lane + 64] = 0; hgrp[lane] = 0; hgrp[lane + 64] = 0;
+        for (uint32_t i = lane; i < 512; i += 64) hconv[i] = 1.0f;       // (1: a band that is not reconstructed is taken as it is)
+        if (lane < 4) zero[lane] = 0.0f;                                 // the line every band without a source reads
+        wave_lds_sync();
+        if (F.bands_per_hfr_group > 0) {
+            const int start = (int)(F.stereo_bands + F.base_bands), bpg = (int)F.bands_per_hfr_group, groups = (int)F.hfr_group_count;
+            const int limit = F.version <= 0x0200 ? groups : (groups >> 1);
+            nproc = groups * bpg;
+            if (nproc > (int)F.total_bands - start) nproc = (int)F.total_bands - start;
+            if (nproc < 0) nproc = 0;
+            if (limit * bpg > start - 1 && nproc > start) nproc = start;
+            for (int k = (int)lane; k < nproc; k += 64) {
+                const int dec = k < limit * bpg ? k : limit * bpg;
+                hlow[start + k] = (uint8_t)(start - 1 - dec);
+                hgrp[start + k] = (uint8_t)(k / bpg);
+            }
+        }
+        wave_lds_sync();
+    }
+    // JOINT: where each of this lane's eight lines comes from -- format constants (tr_load_spectra states the same rules line by
+    // line): its own coded line; for a secondary in the bands it shares, the primary's (hca.cpp:1707-1711); for a reconstructed
+    // band the source band of the row it reads (hca.cpp:1638-1683; the last one is cleared, 1681); nothing.  The value is then
+    // S[src] * hconv[unit][band] (1 unless reconstructed) * (the pair's ratio in the shared bands, else 1).
+    uint32_t src_off[8];                                   // byte offsets into S
+    uint32_t ratio_mask = 0;                               // bit r: line r takes the pair's ratio
+    if (JOINT) {
+        const uint32_t tc = F.type(c);
+        const bool secondary = tc == CRI_CH_SECONDARY && c > 0, stereo = F.stereo_bands > 0, hfr = F.bands_per_hfr_group > 0;
+        const int start = (int)(F.stereo_bands + F.base_bands);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t bnd = l16 * 8 + r;
+            const bool shared = stereo && bnd >= F.base_bands && bnd < F.total_bands;
+            const bool from_prev = secondary && shared;
+            const uint32_t us = from_prev ? u - 1 : u, cs = from_prev ? c - 1 : c;
+            const bool cs_hfr = hfr && F.type(cs) != CRI_CH_SECONDARY;
+            uint32_t idx = ZERO_IDX;
+            if (cs_hfr && (int)bnd == start + nproc - 1) idx = ZERO_IDX;                   // hca.cpp:1681 (with nothing reconstructed this is a coded band)
+            else if (bnd < F.coded(cs)) idx = us * 128 + bnd;
+            else if (cs_hfr && (int)bnd >= start && (int)bnd < start + nproc) idx = us * 128 + hlow[bnd];
+            src_off[r] = idx * 4;
+            if (shared && (from_prev || tc == CRI_CH_PRIMARY)) ratio_mask |= 1u << r;
+        }
+    }
     const uint32_t ath2 = ((const uint16_t*)(a.ath_tables + F.ath_index * 128))[lane];
     const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
     uint8_t* dst = a.out + st.dst_offset;
@@ -1551,6 +1607,12 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
             p.ps = *(const uint2*)tail; p.fl = NW ? tail[2] : 0u;
             p.ps.y = live ? p.ps.y : 0u;
         }
+        p.ib = 0;
+        if (JOINT) {                                       // lane < 32: intensity byte (lane & 7) of unit lane >> 3's pair (its secondary's entry)
+            const uint32_t v = (lane >> 3) & 3, cv = v % C, cs = (F.type(cv) == CRI_CH_SECONDARY || cv + 1 >= (uint32_t)C) ? cv : cv + 1;
+            bool live; const uint32_t f = unit_frame(v, s, live);
+            p.ib = rec0[(uint64_t)f * F.record_bytes + HCA_REC_INT(C, cs) + (lane & 7)];
+        }
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
             bool live; const uint32_t f = unit_frame(v, s, live);
@@ -1569,7 +1631,7 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
         return (__builtin_amdgcn_readlane(p.fl, 0) & __builtin_amdgcn_readlane(p.fl, 1) & __builtin_amdgcn_readlane(p.fl, 2) & __builtin_amdgcn_readlane(p.fl, 3) & HCA_REC_NARROW) != 0;
     };
     // gains of the four units' frames (hca.cpp:1444-1507), two bands per lane; false if one of the frames is bad
-    auto setup = [&](const PlainPre& p) {
+    auto setup = [&](const PlainPre& p, int cur_step) {
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
             const int32_t status = (int32_t)__builtin_amdgcn_readlane(p.ps.y, v);
@@ -1594,8 +1656,39 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
                 gn[hh] = i < coded ? (neg ? -gain : gain) : 0.0f;
             }
             *(float2*)(G + v * 128 + 2 * lane) = make_float2(gn[0], gn[1]);
+            if (JOINT) ((uint16_t*)sfb)[v * 64 + lane] = (uint16_t)sf2;
         }
         wave_lds_sync();
+        if (JOINT) {
+            if (F.bands_per_hfr_group > 0) {               // HFR scale of every reconstructed band (hca.cpp:1638-1683), as tr_setup_frame
+                const int start = (int)(F.stereo_bands + F.base_bands), groups = (int)F.hfr_group_count;
+#pragma unroll
+                for (uint32_t v = 0; v < 4; v++) {
+                    if (F.type(v % C) == CRI_CH_SECONDARY) continue;
+                    const bool pair = v % C + 1 < (uint32_t)C && F.type(v % C + 1) == CRI_CH_SECONDARY;      // the next unit takes these bands from this one
+                    const uint8_t* sb = sfb + v * 128;
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) {
+                        const int k = (int)lane + 64 * hh, b = (start + k) & 127;
+                        int sc = (int)sb[(128 - groups + hgrp[b]) & 127] - (int)sb[hlow[b]] + 63;
+                        sc = sc & ~(sc >> 31);
+                        if (k < nproc) {
+                            const float hc = conv[sc & 127];
+                            hconv[v * 128 + b] = hc;
+                            if (pair && F.stereo_bands > 0 && (uint32_t)b < F.total_bands) hconv[(v + 1) * 128 + b] = hc;
+                        }
+                    }
+                }
+            }
+            if (lane < 32) {                               // intensity ratio per (unit, subframe): hca.cpp:1361-1441, 1696-1714
+                const uint32_t v = lane >> 3, cv = v % C, tv = F.type(cv);
+                const uint32_t cs = (tv == CRI_CH_SECONDARY || cv + 1 >= (uint32_t)C) ? cv : cv + 1;
+                bool live; const uint32_t f = unit_frame(v, cur_step, live);
+                const uint8_t iv = intensity_walk_back(F, rec0, f, C, cs, lane & 7, (uint8_t)p.ib);
+                ratio[lane] = (F.stereo_bands > 0 && (tv == CRI_CH_SECONDARY || tv == CRI_CH_PRIMARY)) ? iratio[iv & 15] : 1.0f;
+            }
+            wave_lds_sync();
+        }
         return true;
     };
     // row (0, c) of this lane's unit's quantised lines in the frame of step s (subframe sf is sf * C * 4 quarters on), and where
@@ -1610,7 +1703,7 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
     };
     auto lane_off = [&](bool narrow) { return narrow ? (l16 >> 3) * HCA_QC_QUARTER + (l16 & 7) * 8 : (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16; };
     // (step_narrow: all four units' frames are int8 -- wave-uniform; mine: this lane's is)
-    auto dct_pass = [&](const uint4& q, bool step_narrow, bool mine, f2 x[4]) {
+    auto dct_pass = [&](const uint4& q, bool step_narrow, bool mine, uint32_t sf, f2 x[4]) {
         const float4 g0 = *(const float4*)(G + u * 128 + l16 * 8), g1 = *(const float4*)(G + u * 128 + l16 * 8 + 4);
         const f2 gg[4] = {f2{g0.x, g0.y}, f2{g0.z, g0.w}, f2{g1.x, g1.y}, f2{g1.z, g1.w}};
         const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
@@ -1626,6 +1719,22 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
                 const uint32_t w = qw[k >> 1] >> (16 * (k & 1));
                 const int a0 = NW && mine ? (int)(int8_t)(w & 0xFF) : (int)(int16_t)(qw[k] & 0xFFFF), a1 = NW && mine ? (int)(int8_t)((w >> 8) & 0xFF) : ((int)qw[k] >> 16);
                 x[k] = gg[k] * f2{(float)a0, (float)a1};
+            }
+        }
+        if (JOINT) {
+            float* srow = S + u * 128;
+            *(float4*)(srow + l16 * 8) = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+            *(float4*)(srow + l16 * 8 + 4) = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+            wave_lds_sync();
+            const float rl = ratio[u * 8 + sf];
+            const float rm = (F.type(c) == CRI_CH_SECONDARY) ? 2.0f - rl : rl;
+            const float4 h0 = *(const float4*)(hconv + u * 128 + l16 * 8), h1 = *(const float4*)(hconv + u * 128 + l16 * 8 + 4);
+            const f2 hm[4] = {f2{h0.x, h0.y}, f2{h0.z, h0.w}, f2{h1.x, h1.y}, f2{h1.z, h1.w}};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const f2 sv = {*(const float*)((const uint8_t*)S + src_off[2 * k]), *(const float*)((const uint8_t*)S + src_off[2 * k + 1])};
+                const f2 mr = {(ratio_mask >> (2 * k)) & 1u ? rm : 1.0f, (ratio_mask >> (2 * k + 1)) & 1u ? rm : 1.0f};
+                x[k] = (sv * hm[k]) * mr;
             }
         }
         dct4_inplace(x, L);
@@ -1651,12 +1760,12 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
             step_narrow = all_narrow(cur); mine = my_narrow(cur); loff = lane_off(mine);
             if (s + 1 < (int)h) pre = load_pre(s + 1);
             wave_lds_sync();                               // (the previous pass has read G)
-            if (!setup(cur)) return;                       // (a group's halo frame is one of the run's own, except the first group's)
+            if (!setup(cur, s)) return;                     // (a group's halo frame is one of the run's own, except the first group's)
         }
 #pragma unroll 1
         for (uint32_t sf = s < 0 ? 7 : 0; sf < 8; sf++) {
             f2 x[4];
-            dct_pass(q, step_narrow, mine, x);
+            dct_pass(q, step_narrow, mine, sf, x);
             // the next pass's lines, requested as soon as this pass's are in registers as floats (the next step's first row is laid
             // out by that frame's own flag, which came with `pre` seven passes ago)
             {   // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
@@ -1754,6 +1863,7 @@ __global__ __launch_bounds__(64, CRI_PLAIN_WAVES) void k_hca_transform_plain(Hca
 }
 
 #define HCA_PLAIN_LDS (2048 + 1024 + 256 + 64 + 80 + 2048 + 1024)
+#define HCA_PLAIN_JOINT_LDS (HCA_PLAIN_LDS + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
     return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + ((C * 8 + 15) & ~15) + (C * 4 + 4) * 4 + 2 * C * 128 + 64;
@@ -1768,19 +1878,24 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
         const bool flt = a.float_out != nullptr;
 #define CRI_LAUNCH_TR(P, CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform<P, CH, true>), dim3(a.runs), dim3(64), lds, s, a); \
                                   else hipLaunchKernelGGL((k_hca_transform<P, CH, false>), dim3(a.runs), dim3(64), lds, s, a); } while (0)
-#define CRI_LAUNCH_PL(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); \
-                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
+#define CRI_LAUNCH_PL(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, false>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); \
+                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, false>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
+#define CRI_LAUNCH_PJ(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true>), dim3(a.runs), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); \
+                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true>), dim3(a.runs), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); } while (0)
         if (a.plain) switch (a.channels) {
             case 1: CRI_LAUNCH_PL(1); break;
             case 2: CRI_LAUNCH_PL(2); break;
             case 4: CRI_LAUNCH_PL(4); break;
             case 6: CRI_LAUNCH_TR(true, 6); break; default: CRI_LAUNCH_TR(true, 8); break;
+        } else if (a.inlane && !getenv("CRI_NO_INLANE")) switch (a.channels) {
+            case 1: CRI_LAUNCH_PJ(1); break; case 2: CRI_LAUNCH_PJ(2); break; default: CRI_LAUNCH_PJ(4); break;
         } else switch (a.channels) {
             case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;
             case 6: CRI_LAUNCH_TR(false, 6); break; default: CRI_LAUNCH_TR(false, 8); break;
         }
 #undef CRI_LAUNCH_TR
 #undef CRI_LAUNCH_PL
+#undef CRI_LAUNCH_PJ
     } else {
         size_t lds = (size_t)a.channels * (2 * 128 + 2 * TR_DSTRIDE) * 4 + a.channels * 256 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);

@@ -270,9 +270,9 @@ def test_hca_header_with_wrapped_hfr_group_count(cc):
         cc.HcaDecode(bad, int.from_bytes(bad[6:8], "big"), 0, 0)
 
 
-@pytest.mark.parametrize("ch", [1, 2])
+@pytest.mark.parametrize("ch", [1, 2, 4])
 def test_hca_int8_and_int16_records_mixed(cc, ch):
-    """Mono and stereo plain formats keep a frame's quantised lines as int8 when no band of its 64-frame tile can exceed 8 bits, as
+    """Mono, stereo and four-channel plain formats keep a frame's quantised lines as int8 when no band of its 64-frame tile can exceed 8 bits, as
     int16 otherwise.  Streams whose later tiles (or single frames, in a batch that shares tiles) carry random high-resolution
     frames put both record forms next to each other: in one run of 8 frames, in one transform step, in one tile."""
     from pycricodecs_amd.batch import Job
