@@ -1491,11 +1491,14 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t sf2[4]; };   // s
 #ifndef CRI_PLAIN_WAVES
 #define CRI_PLAIN_WAVES 4
 #endif
+#ifndef CRI_JOINT_WAVES
+#define CRI_JOINT_WAVES 3
+#endif
 // JOINT: the format has high-frequency reconstruction and / or intensity stereo (a stereo pair is an even channel and the next one,
 // i.e. two neighbouring units of one group): each pass stages the units' dequantised lines in LDS, a reconstructed band reads its
 // source band there, a secondary reads its primary's row.
 template <int C, bool FLT, bool JOINT>
-__global__ __launch_bounds__(64, JOINT ? 3 : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
+__global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
     constexpr bool NW = true;                              // int8 lines (HCA_REC_NARROW) are read by all three instances
