@@ -137,10 +137,21 @@ __device__ __forceinline__ uint4 load_chunk_guarded(const uint8_t* p, const uint
 // counts loads and stores together and in order, so the wait at the next checkpoint covers those stores too -- by then
 // they have had a whole block of parsing to complete.
 template <bool IDENTITY, bool CT_LDS>
-__device__ __forceinline__ void feed_land_chunk(BitFeed& f, const uint4& c, uint32_t k, uint32_t nb) {
+__device__ __forceinline__ void feed_land_chunk(BitFeed& f, const uint4& c, uint32_t k, uint32_t nbs) {
     const bool on = k < f.nfl;
     uint32_t* slot = f.ring + (on ? ((f.wr + 4 * k) & (RING_WORDS - 1)) : (uint32_t)RING_WORDS) * 64;
-    const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    const uint32_t nb = nbs & 0xFF, sh = nbs >> 8;             // sh: feed_issue_wave loaded this chunk from sh bytes before its place
+    uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    if (__any(on && sh != 0)) {                                // (only the last chunks of the input blob)
+        const uint64_t lo = ((uint64_t)w[1] << 32) | w[0], hi = ((uint64_t)w[3] << 32) | w[2];
+        const uint32_t bs = 8 * sh;                            // 0 .. 128 bits down; what comes in from past the blob's end is 0
+        uint64_t nlo, nhi;
+        if (bs == 0) { nlo = lo; nhi = hi; }
+        else if (bs < 64) { nlo = (lo >> bs) | (hi << (64 - bs)); nhi = hi >> bs; }
+        else if (bs < 128) { nlo = hi >> (bs - 64); nhi = 0; }
+        else { nlo = 0; nhi = 0; }
+        w[0] = (uint32_t)nlo; w[1] = (uint32_t)(nlo >> 32); w[2] = (uint32_t)nhi; w[3] = (uint32_t)(nhi >> 32);
+    }
     uint32_t o[4] = {0, 0, 0, 0};
     if (__all(!on || nb == 16)) {                              // whole chunks (the usual case): 32 bits per checksum step
         if (on) {
@@ -162,34 +173,63 @@ __device__ __forceinline__ void feed_land_chunk(BitFeed& f, const uint4& c, uint
     }
     slot[0] = o[0]; slot[64] = o[1]; slot[128] = o[2]; slot[192] = o[3];
 }
+// (c0, c1: the registers the chunks in flight were loaded into -- BitFeed's own pair, or a pair that only lives inside one
+//  iteration of the spectra loop, see there)
 template <bool IDENTITY, bool CT_LDS>
-__device__ __forceinline__ void feed_land(BitFeed& f) {
-    if (__any(f.nfl > 0)) feed_land_chunk<IDENTITY, CT_LDS>(f, f.fl0, 0, f.nb0);
-    if (__any(f.nfl > 1)) feed_land_chunk<IDENTITY, CT_LDS>(f, f.fl1, 1, f.nb1);
+__device__ __forceinline__ void feed_land(BitFeed& f, const uint4& c0, const uint4& c1) {
+    if (__any(f.nfl > 0)) feed_land_chunk<IDENTITY, CT_LDS>(f, c0, 0, f.nb0);
+    if (__any(f.nfl > 1)) feed_land_chunk<IDENTITY, CT_LDS>(f, c1, 1, f.nb1);
     f.wr += 4 * f.nfl;
     f.nfl = 0;
 }
+template <bool IDENTITY, bool CT_LDS>
+__device__ __forceinline__ void feed_land(BitFeed& f) { feed_land<IDENTITY, CT_LDS>(f, f.fl0, f.fl1); }
 // asks for n (0..2) chunks; a lane with `ask` false keeps what it has in flight
-__device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask = true) {
+__device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask, uint4& c0, uint4& c1) {
     const int left = f.bytes_left;
     const uint32_t nb0 = (uint32_t)(left > 16 ? 16 : left), nb1 = (uint32_t)(left > 32 ? 16 : (left > 16 ? left - 16 : 0));
     const bool want0 = ask && n > 0 && nb0 > 0, want1 = ask && n > 1 && nb1 > 0;
     if (__any((want0 && f.next + 16 > f.in_end) || (want1 && f.next + 32 > f.in_end))) {     // the blob's very last frame
-        if (want0) f.fl0 = load_chunk_guarded(f.next, f.in_end);
-        if (want1) f.fl1 = load_chunk_guarded(f.next + 16, f.in_end);
+        if (want0) c0 = load_chunk_guarded(f.next, f.in_end);
+        if (want1) c1 = load_chunk_guarded(f.next + 16, f.in_end);
     } else {
 #ifdef HCA_ABL_NOLOAD
-        if (want0) f.fl0 = make_uint4((uint32_t)(uintptr_t)f.next, 1, 2, 3);                       // (timing experiment: no input loads)
-        if (want1) f.fl1 = make_uint4((uint32_t)(uintptr_t)f.next, 5, 6, 7);
+        if (want0) c0 = make_uint4((uint32_t)(uintptr_t)f.next, 1, 2, 3);                       // (timing experiment: no input loads)
+        if (want1) c1 = make_uint4((uint32_t)(uintptr_t)f.next, 5, 6, 7);
 #else
-        if (want0) f.fl0 = ld_u128_unaligned(f.next);
-        if (__any(want1)) { if (want1) f.fl1 = ld_u128_unaligned(f.next + 16); }
+        if (want0) c0 = ld_u128_unaligned(f.next);
+        if (__any(want1)) { if (want1) c1 = ld_u128_unaligned(f.next + 16); }
 #endif
     }
     if (ask) {
         const int adv = (int)(n > 1 ? nb0 + nb1 : (n > 0 ? nb0 : 0u));
         f.next += adv; f.bytes_left = left - adv;
         f.nb0 = nb0; f.nb1 = nb1; f.nfl = n;
+    }
+}
+__device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask = true) { feed_issue(f, n, ask, f.fl0, f.fl1); }
+// The spectra loop's form: when any lane asks, every lane loads (no lane-masked definition of c0 / c1 for the compiler to keep
+// copies of -- the registers are plain results of one load each), from an address pulled back inside the blob when the 16 bytes
+// would reach past its end (the landing step shifts those down again: nb0 / nb1 carry the distance in their second byte).
+__device__ __forceinline__ void feed_issue_wave(BitFeed& f, uint32_t n, bool ask, uint4& c0, uint4& c1) {
+    const int left = f.bytes_left;
+    const uint32_t nb0 = (uint32_t)(left > 16 ? 16 : left), nb1 = (uint32_t)(left > 32 ? 16 : (left > 16 ? left - 16 : 0));
+    const bool want0 = ask && n > 0 && nb0 > 0, want1 = ask && n > 1 && nb1 > 0;
+    const uint8_t* lim = f.in_end - 16;
+    const uint8_t* p0 = f.next;
+    const uint8_t* p1 = f.next + 16;
+    const uint32_t sh0 = p0 > lim ? (uint32_t)(p0 - lim) : 0u, sh1 = p1 > lim ? (uint32_t)(p1 - lim) : 0u;
+#ifdef HCA_ABL_NOLOAD
+    if (__any(want0)) c0 = make_uint4((uint32_t)(uintptr_t)f.next, 1, 2, 3);
+    if (__any(want1)) c1 = make_uint4((uint32_t)(uintptr_t)f.next, 5, 6, 7);
+#else
+    if (__any(want0)) c0 = ld_u128_unaligned(p0 > lim ? lim : p0);
+    if (__any(want1)) c1 = ld_u128_unaligned(p1 > lim ? lim : p1);
+#endif
+    if (ask) {
+        const int adv = (int)(n > 1 ? nb0 + nb1 : (n > 0 ? nb0 : 0u));
+        f.next += adv; f.bytes_left = left - adv;
+        f.nb0 = nb0 | ((sh0 > 16 ? 16u : sh0) << 8); f.nb1 = nb1 | ((sh1 > 16 ? 16u : sh1) << 8); f.nfl = n;
     }
 }
 // `eager`: ask whenever there is room (always safe: see the invariant above).  Otherwise only a lane whose ring could run dry
@@ -204,11 +244,12 @@ __device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask = tr
 #ifndef HCA_FEED_LAND
 #define HCA_FEED_LAND 2
 #endif
-__device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b, bool eager = true, uint32_t thresh = 0) {
+__device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b, bool eager, uint32_t thresh, uint4& c0, uint4& c1) {
     const uint32_t h = f.wr - b.rd, room = RING_WORDS - h;
     const bool ask = f.nfl == 0 && (eager || h < thresh);
-    feed_issue(f, room >> 2 > 2 ? 2u : room >> 2, ask);
+    feed_issue_wave(f, room >> 2 > 2 ? 2u : room >> 2, ask, c0, c1);
 }
+__device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b, bool eager = true, uint32_t thresh = 0) { feed_request(f, b, eager, thresh, f.fl0, f.fl1); }
 // one refill opportunity per symbol; branch-free, the LDS read issued here is consumed by the NEXT call
 __device__ __forceinline__ void bb_refill(BitBuf& b, const uint32_t* ring) {
     const bool need = b.off >= 32;                   // the window's first word is used up: slide by one word
@@ -580,37 +621,38 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
             do { nc = nc + 1 == C ? 0 : nc + 1; } while (F.coded(nc) == 0 && nc != c);
         }
     };
-    // code descriptions travel two blocks ahead of their use: the records a wave streams out keep the memory system busy enough
-    // that a load asked for one block ahead arrives late more often than not
-    uint4 mv_next = metag[first_c * 8 * 64], mv_next2;
-    {
-        uint32_t nc, nb;
-        block_after(first_c, 0, nc, nb);
-        mv_next2 = metag[(nc * 8 + nb) * 64];
-    }
+    // One iteration = one block of 16 symbols:
+    //   top     everything that goes to memory: the previous block's finished lines are stored, the code descriptions of the NEXT
+    //           block are asked for, and the lanes' next chunks (together every HCA_FEED_SYNC-th block; in between only when a
+    //           lane could run dry);
+    //   middle  the block's symbols;
+    //   bottom  the chunks land in the ring: the one place the iteration waits for memory, for operations a whole block old.
+    // The chunk registers live inside one iteration on purpose: as loop-carried values the compiler kept copying them at the
+    // back edge, which made every iteration wait for everything it had just issued, stores included (s_waitcnt vmcnt(0)).
+    feed_land<IDENTITY, CT_LDS>(fd);                              // what the scalefactor pass left in flight
+    pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
+    uint4 mv_next = metag[first_c * 8 * 64];
     __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): nothing is pending when the loop is entered, so the
                                                                   // waits the compiler places inside it stay exact counts
     wave_lds_sync();                                              // (needtab)
-    uint32_t ck = HCA_FEED_LAND;                                  // the first checkpoint lands what the scalefactor pass left in flight
+    uint32_t ck = 0;
     for (uint32_t sf = 0; sf < 8; sf++) {
         for (uint32_t c = 0; c < C; c++) {
             const uint32_t nblk = (F.coded(c) + 15) >> 4;
             for (uint32_t blk = 0; blk < nblk; blk++) {
-                uint32_t nb, nc, nb2, nc2;
+                uint32_t nb, nc;
                 block_after(c, blk, nc, nb);
-                block_after(nc, nb, nc2, nb2);
                 const uint32_t nt = needtab[c * 8 + blk];
                 const uint32_t thresh = (nt & 0x7F) + ((uint32_t)needtab[nc * 8 + nb] & 0x7F) + 2;
-                if (ck == HCA_FEED_LAND || __any(fd.nfl > 0 && fd.wr - bb.rd < thresh)) feed_land<IDENTITY, CT_LDS>(fd);
-                if (ck == HCA_FEED_LAND && sf == 0 && c == first_c && blk == 0) ck = 0;      // (and it is the first eager one)
                 const uint4 mv = mv_next;
-                mv_next = mv_next2;
+                pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);      // the previous block's lines
 #ifdef HCA_ABL_NOMETA
-                mv_next2 = make_uint4(0x82828282u + nc2, 0x82828282u, 0x82828282u, 0x82828282u + nb2);   // (timing experiment: no code-description loads)
+                mv_next = make_uint4(0x82828282u + nc, 0x82828282u, 0x82828282u, 0x82828282u + nb);   // (timing experiment: no code-description loads)
 #else
-                mv_next2 = metag[(nc2 * 8 + nb2) * 64];
+                mv_next = metag[(nc * 8 + nb) * 64];
 #endif
-                feed_request(fd, bb, ck == 0, thresh); pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
+                uint4 c0, c1;
+                feed_request(fd, bb, ck == 0, thresh, c0, c1);
                 ck = ck + 1 == HCA_FEED_SYNC ? 0 : ck + 1;
                 const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
@@ -638,39 +680,40 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                     bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
                     if ((blk & 3) == 3 || blk + 1 == nblk)
                         pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 2) * HCA_QC_QUARTER, 4 * ((blk & 3) + 1));
-                    continue;
-                }
-                uint32_t words[8];
-                if (fast) {
-                    const uint32_t off0 = bb.off, rd0 = bb.rd;
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) {
-                        pair_refill(bb, ring);
-                        const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF, nstab);
-                        const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF, nstab);
-                        words[k] = pair_negated(v0, v1);
-                    }
-                    bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
                 } else {
+                    uint32_t words[8];
+                    if (fast) {
+                        const uint32_t off0 = bb.off, rd0 = bb.rd;
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) {
-                        pair_refill(bb, ring);
-                        const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF, nstab);
-                        const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF, nstab);
-                        words[k] = pair_negated(v0, v1);
+                        for (uint32_t k = 0; k < 8; k++) {
+                            pair_refill(bb, ring);
+                            const int v0 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF, nstab);
+                            const int v1 = parse_symbol<false>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF, nstab);
+                            words[k] = pair_negated(v0, v1);
+                        }
+                        bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; k++) {
+                            pair_refill(bb, ring);
+                            const int v0 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1))) & 0xFF, nstab);
+                            const int v1 = parse_symbol<true>(bb, (mw[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF, nstab);
+                            words[k] = pair_negated(v0, v1);
+                        }
+                    }
+                    if (narrow) {                              // (tile-uniform) int8 lines: 16 bytes per block, 64 B of a frame per four blocks
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) ostage[((blk & 3) * 4 + k) * OST + lane] = pairs_to_i8(words[2 * k], words[2 * k + 1]);
+                        if ((blk & 3) == 3 || blk + 1 == nblk)
+                            pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 2) * HCA_QC_QUARTER, 4 * ((blk & 3) + 1));
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * OST + lane] = pair_to_i16(words[k]);
+                        if ((blk & 1) || blk + 1 == nblk)
+                            pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 1) * HCA_QC_QUARTER, (blk & 1) ? 16 : 8);
                     }
                 }
-                if (narrow) {                                  // (tile-uniform) int8 lines: 16 bytes per block, 64 B of a frame per four blocks
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; k++) ostage[((blk & 3) * 4 + k) * OST + lane] = pairs_to_i8(words[2 * k], words[2 * k + 1]);
-                    if ((blk & 3) == 3 || blk + 1 == nblk)
-                        pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 2) * HCA_QC_QUARTER, 4 * ((blk & 3) + 1));
-                } else {
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) ostage[((blk & 1) * 8 + k) * OST + lane] = pair_to_i16(words[k]);
-                    if ((blk & 1) || blk + 1 == nblk)
-                        pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 1) * HCA_QC_QUARTER, (blk & 1) ? 16 : 8);
-                }
+                feed_land<IDENTITY, CT_LDS>(fd, c0, c1);
             }
         }
     }
