@@ -379,8 +379,12 @@ __device__ __forceinline__ void flush16_qc(const uint32_t* ostage, uint8_t* qc_t
 #ifdef HCA_ABL_NOSTORE
         if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
 #endif
-        if (all) *dst = v;
-        else if (fr < nvalid && wq < nwords) *dst = v;
+        // (streaming stores: nobody reads the lines before the transform kernel, and the wave waits for its stores at the bottom
+        //  of the next block together with its loads -- 9.17 -> 8.80 ms for the kernel)
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        const u4v vv = {v.x, v.y, v.z, v.w};
+        if (all) __builtin_nontemporal_store(vv, (u4v*)dst);
+        else if (fr < nvalid && wq < nwords) __builtin_nontemporal_store(vv, (u4v*)dst);
     }
     wave_lds_sync();
 }
@@ -1821,7 +1825,14 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                     const bool more = s + 1 < (int)h;
                     p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);
                 }
+#ifdef HCA_NT_LOAD
+                typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                if (ld8) { const u2v t = __builtin_nontemporal_load((const u2v*)p); q.x = t.x; q.y = t.y; }
+                else { const u4v t = __builtin_nontemporal_load((const u4v*)p); q = make_uint4(t.x, t.y, t.z, t.w); }
+#else
                 if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
+#endif
             }
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
