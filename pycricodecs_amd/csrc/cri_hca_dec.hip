@@ -475,7 +475,10 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         const uint32_t expected = (1u << db) - 1;
         // scalefactors + resolutions in blocks of 16 bands (the last block is padded with zeros)
         for (uint32_t blk = 0; blk < 8; blk++) {
-            feed_land<IDENTITY, CT_LDS>(fd); feed_request(fd, bb); pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
+            // (as in the spectra loop below: stores and loads are issued here, the chunks land at the bottom of the iteration)
+            pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
+            uint4 c0, c1;
+            feed_request(fd, bb, true, 0, c0, c1);
             uint32_t sfw[4] = {0, 0, 0, 0};
             uint32_t mw[4] = {0, 0, 0, 0};
             // far from the frame end (always, in a well-formed frame) the reader's end-of-frame rules cannot apply
@@ -528,7 +531,6 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 #pragma unroll
                 for (uint32_t q = 0; q < 4; q++) wide_bits |= ((mw[q] & 0x0F0F0F0Fu) + 0x07070707u) & 0x10101010u;
             }
-            metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
             {   // bits the block's 16 symbols can take (the low nibbles), the most over the wave, as ring words: a refill slides the
                 // window by one word, and the window may already be up to 55 bits in when the block starts
                 uint32_t sb = 0;
@@ -559,6 +561,8 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 }
                 pend.set(HCA_REC_SF(C, c) + (blk >> 2) * 64, 16);
             }
+            feed_land<IDENTITY, CT_LDS>(fd, c0, c1);
+            metag[(c * 8 + blk) * 64] = make_uint4(mw[0], mw[1], mw[2], mw[3]);      // (after the wait, not before it)
         }
         if (extra) {                                              // v3.0: scalefactors[127 - i] = scalefactors[cs - i]
             pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);
@@ -1825,14 +1829,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                     const bool more = s + 1 < (int)h;
                     p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);
                 }
-#ifdef HCA_NT_LOAD
-                typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-                typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                if (ld8) { const u2v t = __builtin_nontemporal_load((const u2v*)p); q.x = t.x; q.y = t.y; }
-                else { const u4v t = __builtin_nontemporal_load((const u4v*)p); q = make_uint4(t.x, t.y, t.z, t.w); }
-#else
                 if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
-#endif
             }
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
