@@ -89,14 +89,14 @@ template <int ST> __device__ __forceinline__ void rotate_within(f2 p[4], const D
         const float sn = L.s[7 + k], cs = fneg_if(L.c[7 + k], HCA_DCT_REGSIGN(ST, 2 * k));
         const f2 u = p[k] * f2{sn, sn};                    // (a*sin, b*sin)
         const f2 w = p[k].yx * f2{cs, cs};                 // (b*cos, a*cos)
-        p[k] = u + f2{-w.x, w.y};                          // (a*sin - b*cos, b*sin + a*cos)
+        p[k] = pk_add_neg_lo(u, w);                        // (a*sin - b*cos, b*sin + a*cos)
     }
 }
 
 __device__ __forceinline__ void dct4_inplace(f2 p[4], const DctLane& L) {
     // sum/difference stages 0..2: register bits 0, 1, 2
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const f2 a = p[k].xx, b = p[k].yy; p[k] = a + f2{b.x, -b.y}; }
+    for (int k = 0; k < 4; k++) p[k] = pk_sum_diff(p[k]);
     { const f2 a0 = p[0], a2 = p[2]; p[0] = a0 + p[1]; p[1] = a0 - p[1]; p[2] = a2 + p[3]; p[3] = a2 - p[3]; }
     { const f2 a0 = p[0], a1 = p[1]; p[0] = a0 + p[2]; p[2] = a0 - p[2]; p[1] = a1 + p[3]; p[3] = a1 - p[3]; }
     sumdiff_cross<1, 0>(p, L); sumdiff_cross<2, 1>(p, L); sumdiff_cross<4, 2>(p, L); sumdiff_cross<8, 3>(p, L);   // stages 3..6

@@ -25,6 +25,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// packed adds whose second operand is negated in one half only: the modifier does it inside the instruction (the compiler builds
+// {b.x, -b.y} with a packed negate and a move first -- two more instructions per use, 24 per pass of four transforms)
+__device__ __forceinline__ f2 pk_add_neg_hi(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }   // {a.x + b.x, a.y - b.y}
+__device__ __forceinline__ f2 pk_add_neg_lo(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }   // {a.x - b.x, a.y + b.y}
+__device__ __forceinline__ f2 pk_sum_diff(f2 p) { f2 r; asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(p)); return r; }   // {p.x + p.y, p.x - p.y}
+
 // packed fp32 pair (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 operate on these)
 // value of the lane whose lane16 differs in bit X (X = 1, 2, 4, 8), via DPP
 template <int X> __device__ __forceinline__ float lane16_xor(float v) {

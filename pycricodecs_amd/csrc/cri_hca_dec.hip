@@ -1849,7 +1849,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                 const float dy = x[j].y, pv = prev[j];
                 const f2 t = f2{wa[j], wb[j]} * f2{dy, dy};          // w[63-k]*d[127-k], w[64+k]*d[127-k]
                 const f2 r = f2{wb[j], wa[j]} * f2{pv, pv};          // w[64+k]*prev[k],  w[63-k]*prev[k]
-                const f2 wv = t + f2{r.x, -r.y};                   // wave[sf][63 - k], wave[sf][64 + k]
+                const f2 wv = pk_add_neg_hi(t, r);                 // wave[sf][63 - k], wave[sf][64 + k]
                 o[j] = wv * f2{32768.0f, 32768.0f};
                 if (FLT) {
                     bool live; const uint32_t ff = unit_frame(u, s, live);

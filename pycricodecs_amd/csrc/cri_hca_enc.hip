@@ -123,7 +123,7 @@ __device__ __forceinline__ int enc_maxbits(int res) { return res > 7 ? res - 3 :
 __device__ __forceinline__ f2 enc_rot(f2 u, float sn, float cs) {
     const f2 p = u.xx * f2{cs, sn};
     const f2 q = u.yy * f2{sn, cs};
-    return p + f2{q.x, -q.y};
+    return pk_add_neg_hi(p, q);
 }
 
 struct EncLds {
