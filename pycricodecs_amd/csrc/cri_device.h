@@ -25,6 +25,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// (float)(int8_t)(w >> 8*B) in one instruction (the compiler finds the SDWA form for some of a dword's bytes only)
+template <int B> __device__ __forceinline__ float cvt_f32_i8(uint32_t w) {
+    float r;
+    if (B == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(w));
+    else if (B == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(r) : "v"(w));
+    else if (B == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(w));
+    else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(r) : "v"(w));
+    return r;
+}
+
+// LDS address of a pointer into shared memory, and 16-bit stores through such an address (no base to add per access)
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p; }
+
 // packed adds whose second operand is negated in one half only: the modifier does it inside the instruction (the compiler builds
 // {b.x, -b.y} with a packed negate and a move first -- two more instructions per use, 24 per pass of four transforms)
 __device__ __forceinline__ f2 pk_add_neg_hi(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }   // {a.x + b.x, a.y - b.y}

@@ -1571,24 +1571,23 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     dct_lane_init(L, l16, HCA_DCT_LANE_SIN, HCA_DCT_LANE_COS);
     const uint2 dlogp = *(const uint2*)(HCA_DCT_LOGICAL + l16 * 8);
     // per-lane constants kept in LDS (12 registers otherwise): {w[63-k], w[64+k]} x 4 and the staging index of out[64+k] x 4
-    // (out[63-k] sits at po_sum - that; byte offsets)
+    // (as final LDS addresses: an offset would cost an add per store)
     float* wtab = (float*)(curve + 80) + lane * 8;         // [64][8]
-    uint32_t* potab = (uint32_t*)(curve + 80 + 2048) + lane * 4;   // [64][4]
+    uint32_t* potab = (uint32_t*)(curve + 80 + 2048) + lane * 8;   // [64][8]: LDS addresses of out[64+k] x 4, of out[63-k] x 4
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t k = ((j < 2 ? dlogp.x : dlogp.y) >> (16 * (j & 1))) & 0xFF;      // register 2j: k < 64 (register 2j+1: 127 - k)
         wtab[2 * j] = HCA_WINDOW[63 - k]; wtab[2 * j + 1] = HCA_WINDOW[64 + k];
-        potab[j] = ((g * 128 + 64 + k) * C + c) * 2;       // byte offsets
+        const uint32_t po = ((g * 128 + 64 + k) * C + c) * 2;
+        potab[j] = lds_address((uint8_t*)pcm + po); potab[4 + j] = lds_address((uint8_t*)pcm + (((2 * g * 128 + 127) * C + 2 * c) * 2 - po));
     }
-    const uint32_t po_sum = ((2 * g * 128 + 127) * C + 2 * c) * 2;
-    uint8_t* pcmb = (uint8_t*)pcm;
     scale[lane] = HCA_DEQ_SCALE[lane];
     if (lane < 16) range[lane] = HCA_DEQ_RANGE[lane];
     curve[lane] = HCA_CURVE_TO_RES[lane]; if (lane < 2) curve[64 + lane] = HCA_CURVE_TO_RES[64 + lane];
     // JOINT only: S[4][128] the pass's dequantised lines, hconv[4][128] HFR scale of a reconstructed band (per unit's frame),
     // conv[128], iratio[16], zero[4], ratio[4][8] intensity ratio of the unit's pair per subframe, sfb[4][128] scalefactor bytes,
     // hlow[128] / hgrp[128] source band and HFR group of a reconstructed band (format constants)
-    float* S = (float*)(curve + 80 + 2048 + 1024); float* hconv = S + 512; float* conv = hconv + 512; float* iratio = conv + 128;
+    float* S = (float*)(curve + 80 + 2048 + 2048); float* hconv = S + 512; float* conv = hconv + 512; float* iratio = conv + 128;
     float* ratio = iratio + 16; float* zero = ratio + 32; uint8_t* sfb = (uint8_t*)(zero + 4); uint8_t* hlow = sfb + 512; uint8_t* hgrp = hlow + 128;
     constexpr uint32_t ZERO_IDX = 512 + 512 + 128 + 16 + 32;            // (index of `zero` from S)
     int nproc = 0;                                         // bands reconstructed by HFR (hca.cpp:1650-1676), as in k_hca_transform
@@ -1763,10 +1762,8 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
         if (NW && __builtin_expect(step_narrow, 1)) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t w = qw[k >> 1] >> (16 * (k & 1));
-                x[k] = gg[k] * f2{(float)(int)(int8_t)(w & 0xFF), (float)(int)(int8_t)((w >> 8) & 0xFF)};   // gains are 0 past the coded bands
-            }
+            for (int k = 0; k < 4; k++)                        // gains are 0 past the coded bands
+                x[k] = gg[k] * (k & 1 ? f2{cvt_f32_i8<2>(qw[k >> 1]), cvt_f32_i8<3>(qw[k >> 1])} : f2{cvt_f32_i8<0>(qw[k >> 1]), cvt_f32_i8<1>(qw[k >> 1])});
         } else {                                           // a frame with wide lines among the four (rare): either form per lane
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1842,8 +1839,8 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             float big = 0.0f;
             const float4 w0 = *(const float4*)wtab, w1 = *(const float4*)(wtab + 4);
             const float wa[4] = {w0.x, w0.z, w1.x, w1.z}, wb[4] = {w0.y, w0.w, w1.y, w1.w};
-            const uint4 pov = *(const uint4*)potab;
-            const uint32_t po[4] = {pov.x, pov.y, pov.z, pov.w};
+            const uint4 pov = *(const uint4*)potab, prv = *(const uint4*)(potab + 4);
+            const uint32_t po[4] = {pov.x, pov.y, pov.z, pov.w}, pr[4] = {prv.x, prv.y, prv.z, prv.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float dy = x[j].y, pv = prev[j];
@@ -1871,16 +1868,16 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                     int32_t q0 = cvt_trunc_x86(ox), q1 = cvt_trunc_x86(oy);
                     q0 = q0 > 32767 ? 32767 : (q0 < -32768 ? -32768 : q0);
                     q1 = q1 > 32767 ? 32767 : (q1 < -32768 ? -32768 : q1);
-                    *(uint16_t*)(pcmb + (po_sum - po[j])) = (uint16_t)(int16_t)q0;
-                    *(uint16_t*)(pcmb + po[j]) = (uint16_t)(int16_t)q1;
+                    *(lds_u16*)(uintptr_t)pr[j] = (uint16_t)(int16_t)q0;
+                    *(lds_u16*)(uintptr_t)po[j] = (uint16_t)(int16_t)q1;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     typedef short s2 __attribute__((ext_vector_type(2)));
                     const s2 pk = __builtin_amdgcn_cvt_pk_i16((int32_t)o[j].x, (int32_t)o[j].y);     // saturating
-                    *(uint16_t*)(pcmb + (po_sum - po[j])) = (uint16_t)pk.x;
-                    *(uint16_t*)(pcmb + po[j]) = (uint16_t)pk.y;
+                    *(lds_u16*)(uintptr_t)pr[j] = (uint16_t)pk.x;
+                    *(lds_u16*)(uintptr_t)po[j] = (uint16_t)pk.y;
                 }
             }
             wave_lds_sync();
@@ -1916,7 +1913,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     }
 }
 
-#define HCA_PLAIN_LDS (2048 + 1024 + 256 + 64 + 80 + 2048 + 1024)
+#define HCA_PLAIN_LDS (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
 #define HCA_PLAIN_JOINT_LDS (HCA_PLAIN_LDS + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
