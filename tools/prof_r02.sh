@@ -3,28 +3,34 @@
 #   1. the default bench line (headline + secondaries + CPU baseline) and the other workloads' lines
 #   2. rocprofv3 --kernel-trace --stats of the headline-only run and of the hca_encode / adx_roundtrip / awb_mixed / crypt runs
 #   3. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, no tracing domains) of the same commands
-# Compact summaries land in gpurun_out/$TAG; raw rocprofv3 output is deleted.
+# Compact summaries land in gpurun_out/$TAG; raw rocprofv3 output is deleted.  Every profiler pass runs under `timeout`: one
+# counter pass of the full-size batch once sat for 39 minutes without finishing (SKIP_BENCH=1 skips step 1).
 export TMPDIR=/tmp
 TAG=${TAG:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 RAW=/tmp/prof_raw
 rm -rf $RAW; mkdir -p $OUT $RAW
 cd $GRAFT_REPO_ROOT
+if [ -z "$SKIP_BENCH" ]; then
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -1 $OUT/bench.err
 python bench.py --workload hca_encode --steps 3 --warmup 1 > $OUT/bench_hca_encode.json 2> $OUT/bench_hca_encode.err
 python bench.py --workload adx_roundtrip > $OUT/bench_adx_roundtrip.json 2> $OUT/bench_adx_roundtrip.err
 python bench.py --workload awb_mixed > $OUT/bench_awb_mixed.json 2> $OUT/bench_awb_mixed.err
+fi
 declare -A CMDS
 CMDS[hca_decode]="python bench.py --no-cpu --no-secondary --no-verify --steps 5 --warmup 2"
 CMDS[hca_encode]="python bench.py --workload hca_encode --no-cpu --no-verify --steps 3 --warmup 1"
 CMDS[adx_roundtrip]="python bench.py --workload adx_roundtrip --no-cpu --no-verify"
 CMDS[awb_mixed]="python bench.py --workload awb_mixed --no-verify"
 CMDS[hca_crypt]="python tools/debug/crypt_time.py"
+# (the counter passes of the full-size decode use three dispatches: with seven the FETCH_SIZE pass did not finish, twice)
+PMC_hca_decode="python bench.py --no-cpu --no-secondary --no-verify --steps 2 --warmup 1"
 for w in hca_decode hca_encode adx_roundtrip awb_mixed hca_crypt; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/t_$w -o t -- ${CMDS[$w]} > $OUT/trace_$w.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/t_$w -o t -- ${CMDS[$w]} > $OUT/trace_$w.log 2>&1
   find $RAW/t_$w -name "*kernel_stats.csv" -exec cp {} $OUT/${w}_kernel_stats.csv \;
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/f_$w -o f -- ${CMDS[$w]} > $OUT/fetch_$w.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/w_$w -o w -- ${CMDS[$w]} > $OUT/write_$w.log 2>&1
+  PC=${CMDS[$w]}; if [ $w = hca_decode ]; then PC=$PMC_hca_decode; fi
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/f_$w -o f -- $PC > $OUT/fetch_$w.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/w_$w -o w -- $PC > $OUT/write_$w.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections, os, json
