@@ -270,13 +270,13 @@ def test_hca_header_with_wrapped_hfr_group_count(cc):
         cc.HcaDecode(bad, int.from_bytes(bad[6:8], "big"), 0, 0)
 
 
-@pytest.mark.parametrize("ch", [1, 2, 4])
-def test_hca_int8_and_int16_records_mixed(cc, ch):
-    """Mono, stereo and four-channel plain formats keep a frame's quantised lines as int8 when no band of its 64-frame tile can exceed 8 bits, as
+@pytest.mark.parametrize("ch,q", [(1, 1), (2, 1), (4, 1), (2, 2), (2, 3), (1, 3), (4, 3), (2, 4)])
+def test_hca_int8_and_int16_records_mixed(cc, ch, q):
+    """Mono, stereo and four-channel formats (plain, and with intensity stereo / high-frequency reconstruction: q >= 2) keep a frame's quantised lines as int8 when no band of its 64-frame tile can exceed 8 bits, as
     int16 otherwise.  Streams whose later tiles (or single frames, in a batch that shares tiles) carry random high-resolution
     frames put both record forms next to each other: in one run of 8 frames, in one transform step, in one tile."""
     from pycricodecs_amd.batch import Job
-    base = O.hca_encode(synth.wav(91, 90000, ch, 48000), 1)             # 88 frames: tiles 0 and 1
+    base = O.hca_encode(synth.wav(91, 90000, ch, 48000), q)             # 88 frames: tiles 0 and 1
     hs, fs = int.from_bytes(base[6:8], "big"), int.from_bytes(base[28:30], "big")
     nfr = int.from_bytes(base[16:20], "big")
 
@@ -296,7 +296,7 @@ def test_hca_int8_and_int16_records_mixed(cc, ch):
     for v in variants:
         assert diff(cc.HcaDecode(v, hs, 0, 0), O.hca_decode(v)) is None
     # one batch: short plain streams around them, so that tiles mix streams of both kinds
-    short = [O.hca_encode(synth.wav(300 + i, 2000 + 700 * i, ch, 48000), 1) for i in range(6)]
+    short = [O.hca_encode(synth.wav(300 + i, 2000 + 700 * i, ch, 48000), q) for i in range(6)]
     items = [short[0], variants[1], short[1], short[2], variants[2], short[3], variants[0], short[4], variants[4], short[5]]
     outs, st = Job.hca_decode(items).run_host()
     for i, (o, h, code) in enumerate(zip(outs, items, st)):
