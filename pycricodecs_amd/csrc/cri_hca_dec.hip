@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 mv_next = metag[(nc * 8 + nb) * 64];
 #endif
                 uint4 c0, c1;
-                feed_request(fd, bb, ck == 0, thresh, c0, c1);
+                if (ck == 0 || __any(fd.wr - bb.rd < thresh)) feed_request(fd, bb, ck == 0, thresh, c0, c1);   // (most blocks: nothing to ask for)
                 ck = ck + 1 == HCA_FEED_SYNC ? 0 : ck + 1;
                 const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
