@@ -1756,7 +1756,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     };
     auto lane_off = [&](bool narrow) { return narrow ? (l16 >> 3) * HCA_QC_QUARTER + (l16 & 7) * 8 : (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16; };
     // (step_narrow: all four units' frames are int8 -- wave-uniform; mine: this lane's is)
-    auto dct_pass = [&](const uint4& q, bool step_narrow, bool mine, uint32_t sf, f2 x[4]) {
+    auto lines_to_spectra = [&](const uint4& q, bool step_narrow, bool mine, uint32_t sf, f2 x[4]) {
         const float4 g0 = *(const float4*)(G + u * 128 + l16 * 8), g1 = *(const float4*)(G + u * 128 + l16 * 8 + 4);
         const f2 gg[4] = {f2{g0.x, g0.y}, f2{g0.z, g0.w}, f2{g1.x, g1.y}, f2{g1.z, g1.w}};
         const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
@@ -1788,7 +1788,6 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                 x[k] = (sv * hm[k]) * mr;
             }
         }
-        dct4_inplace(x, L);
     };
 
     float prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};              // hca.cpp:962: the overlap tail starts as zeros
@@ -1816,9 +1815,9 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
 #pragma unroll 1
         for (uint32_t sf = s < 0 ? 7 : 0; sf < 8; sf++) {
             f2 x[4];
-            dct_pass(q, step_narrow, mine, sf, x);
-            // the next pass's lines, requested as soon as this pass's are in registers as floats (the next step's first row is laid
-            // out by that frame's own flag, which came with `pre` seven passes ago)
+            lines_to_spectra(q, step_narrow, mine, sf, x);
+            // the next pass's lines, requested as soon as this pass's are in registers as floats, i.e. a whole DCT ahead of their use
+            // (the next step's first row is laid out by that frame's own flag, which came with `pre` seven passes ago)
             {   // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
                 const uint8_t* p; bool ld8;
                 if (sf < 7) { p = rec_run + (rows + HCA_QC_ROW(C, sf + 1, 0) + loff); ld8 = NW && step_narrow; }
@@ -1826,8 +1825,14 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                     const bool more = s + 1 < (int)h;
                     p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);
                 }
+#ifdef HCA_ABL_NOLINES
+                q.x = (uint32_t)(uintptr_t)p & 0x03030303u; q.y = 0x01010101u;      // (timing experiment: no line loads)
+#else
                 if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
+#endif
             }
+            __builtin_amdgcn_sched_barrier(0);             // (keep the load here: the compiler would sink it behind most of the DCT)
+            dct4_inplace(x, L);
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
 #pragma unroll
@@ -1884,9 +1889,15 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             // 256*C contiguous bytes per group; delay / length trim of hca.cpp:3392-3425
             const uint32_t n00 = (f0 + (uint32_t)s) * 1024 + sf * 128;   // first sample (per channel) of group 0's subframe
             if (dword_ok && (uint32_t)s < last_count && n00 >= st.delay && n00 + (NG - 1) * h * 1024 + 128 - st.delay <= st.samples) {
-                uint32_t* q0 = (uint32_t*)(dst + (uint64_t)(n00 - st.delay) * C * 2) + lane;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++) q0[(k / C) * group_dwords + (k % C) * 64] = ((const uint32_t*)pcm)[k * 64 + lane];
+                // one 16-byte store per lane: the staging area is the groups' 256*C-byte pieces back to back (the output address is only
+                // dword-aligned: the WAV header is 44 bytes)
+                typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+                const uint32_t gk = lane / (16 * C), wi = 4 * lane - gk * 64 * C;
+                const uint4 v = ((const uint4*)pcm)[lane];
+#ifdef HCA_ABL_NOPCM
+                if (v.x == 0x12345678u && v.y == 0x9abcdef0u)                      // (timing experiment: the stores practically never happen)
+#endif
+                *(u4u*)((uint32_t*)(dst + (uint64_t)(n00 - st.delay) * C * 2) + gk * group_dwords + wi) = u4u{v.x, v.y, v.z, v.w};
             } else {
 #pragma unroll 1
                 for (uint32_t k = 0; k < 4; k++) {
