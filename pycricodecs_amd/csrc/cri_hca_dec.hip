@@ -1799,7 +1799,20 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         if (NW && all_narrow(pre)) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
     }
     const uint32_t last_count = unit_count(3);             // frames of the last group: steps below it have every group at work
-    const uint32_t group_dwords = h * 512 * C;             // output dwords between the frames of consecutive groups
+    // A pass's PCM leaves one pass late: its 16-byte store is issued right BEFORE the next pass's line load, so that the wait for
+    // those lines (the counter retires in order) finds a store that has had a whole DCT to complete, not one issued just before it.
+    uint32_t pend_n00 = 0xFFFFFFFFu;                       // first sample of the staged pass's group-0 subframe (wave-uniform), or none
+    auto flush_pcm = [&]() {
+        if (pend_n00 == 0xFFFFFFFFu) return;
+        typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t gk = lane / (16 * C), wi = 4 * lane - gk * 64 * C;
+        const uint4 v = ((const uint4*)pcm)[lane];
+#ifdef HCA_ABL_NOPCM
+        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)      // (timing experiment: the stores practically never happen)
+#endif
+        *(u4u*)((uint32_t*)(dst + (uint64_t)(pend_n00 - st.delay) * C * 2) + gk * h * 512 * C + wi) = u4u{v.x, v.y, v.z, v.w};
+        pend_n00 = 0xFFFFFFFFu;
+    };
     // step -1 is the halo: the subframe before each group's first one (its frame's subframe 7) only feeds the overlap state
 #pragma unroll 1
     for (int s = -1; s < (int)h; s++) {
@@ -1810,7 +1823,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             step_narrow = all_narrow(cur); mine = my_narrow(cur); loff = lane_off(mine);
             if (s + 1 < (int)h) pre = load_pre(s + 1);
             wave_lds_sync();                               // (the previous pass has read G)
-            if (!setup(cur, s)) return;                     // (a group's halo frame is one of the run's own, except the first group's)
+            if (!setup(cur, s)) { flush_pcm(); return; }                   // (a group's halo frame is one of the run's own, except the first group's)
         }
 #pragma unroll 1
         for (uint32_t sf = s < 0 ? 7 : 0; sf < 8; sf++) {
@@ -1818,6 +1831,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             lines_to_spectra(q, step_narrow, mine, sf, x);
             // the next pass's lines, requested as soon as this pass's are in registers as floats, i.e. a whole DCT ahead of their use
             // (the next step's first row is laid out by that frame's own flag, which came with `pre` seven passes ago)
+            flush_pcm();                                   // the previous pass's PCM (staged in LDS since)
             {   // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
                 const uint8_t* p; bool ld8;
                 if (sf < 7) { p = rec_run + (rows + HCA_QC_ROW(C, sf + 1, 0) + loff); ld8 = NW && step_narrow; }
@@ -1889,15 +1903,9 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             // 256*C contiguous bytes per group; delay / length trim of hca.cpp:3392-3425
             const uint32_t n00 = (f0 + (uint32_t)s) * 1024 + sf * 128;   // first sample (per channel) of group 0's subframe
             if (dword_ok && (uint32_t)s < last_count && n00 >= st.delay && n00 + (NG - 1) * h * 1024 + 128 - st.delay <= st.samples) {
-                // one 16-byte store per lane: the staging area is the groups' 256*C-byte pieces back to back (the output address is only
-                // dword-aligned: the WAV header is 44 bytes)
-                typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
-                const uint32_t gk = lane / (16 * C), wi = 4 * lane - gk * 64 * C;
-                const uint4 v = ((const uint4*)pcm)[lane];
-#ifdef HCA_ABL_NOPCM
-                if (v.x == 0x12345678u && v.y == 0x9abcdef0u)                      // (timing experiment: the stores practically never happen)
-#endif
-                *(u4u*)((uint32_t*)(dst + (uint64_t)(n00 - st.delay) * C * 2) + gk * group_dwords + wi) = u4u{v.x, v.y, v.z, v.w};
+                // one 16-byte store per lane, issued by the next pass (flush_pcm): the staging area is the groups' 256*C-byte pieces back
+                // to back (the output address is only dword-aligned: the WAV header is 44 bytes)
+                pend_n00 = n00;
             } else {
 #pragma unroll 1
                 for (uint32_t k = 0; k < 4; k++) {
@@ -1922,6 +1930,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         }
         rows = next_rows;
     }
+    flush_pcm();
 }
 
 #define HCA_PLAIN_LDS (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
