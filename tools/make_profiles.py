@@ -54,7 +54,7 @@ def main(tag):
         for k, v in raw.get(w, {}).items():
             if "k_fill" in k or "scatter" in k:
                 continue
-            others.setdefault(w, {})[k.replace("void cri::", "").replace("cri::", "")] = {"FETCH_SIZE_KB": round(v["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(v["WRITE_SIZE"], 1)}
+            others.setdefault(w, {})[k.replace("void cri::", "").replace("cri::", "")] = {c + "_KB": (round(v[c], 1) if c in v else None) for c in ("FETCH_SIZE", "WRITE_SIZE")}   # None: that counter pass did not finish (timeout)
     out["other_workloads_raw_counters_per_dispatch"] = others
     with open(os.path.join(dst, "%s_traffic.json" % tag), "w") as f:
         json.dump(out, f, indent=1)
