@@ -24,6 +24,7 @@ SYMBOLS = [
     "cri_job_create_hca_decode_items", "cri_job_create_adx_decode_items", "cri_job_create_adx_encode_items",
     "cri_job_create_hca_encode_items", "cri_job_create_hca_crypt_items", "cri_job_input_offsets", "cri_device_count", "cri_set_device", "cri_get_device", "cri_job_device", "cri_job_run_floats", "cri_job_float_count", "cri_job_float_offsets",
     "cri_usm_audio_mask", "cri_usm_index", "cri_job_create_usm_audio_demux", "cri_job_create_sfa_pack", "cri_job_item_tags", "cri_job_item_sizes",
+    "cri_job_hca_groups",
 ]
 
 
