@@ -236,10 +236,16 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
     else { atomicOr(&words[w], v >> (-shift)); atomicOr(&words[w + 1], v << (32 + shift)); }
 }
 
-#define ENC_WAVES 4     // most frames (waves) per workgroup; they share the LDS tables and are otherwise independent
+#ifndef ENC_WAVES
+#define ENC_WAVES 2     // most frames (waves) per workgroup; they share the LDS tables and are otherwise independent (measured, stereo
+                        // High, ms per 469 k frames: 1 wave -, 2: 6.68, 3: 6.72-6.80, 4: 6.91-6.96, 7: 9.4; at 4 waves per SIMD it spills: 7.5)
+#endif
+#ifndef ENC_MIN_WAVES
+#define ENC_MIN_WAVES 1
+#endif
 // CT = 1, 2, 4, 6, 8: channel count known at compile time, the rate loop keeps the lane's bands in registers; CT = 0: any count
 template <int CT>
-__global__ __launch_bounds__(64 * ENC_WAVES) void k_hca_encode(HcaEncArgs a) {
+__global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     const EncTab T = enc_tables_to_lds(smem_all, threadIdx.x, blockDim.x, a.crc_mul);
     __syncthreads();                                       // the only workgroup barrier: tables are read-only from here on
