@@ -697,13 +697,12 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
     ENC_MARK(5);
     // spectra: QuantizeSpectra (hca.cpp:2878-2892) + WriteSpectra (2920-2936)
     if constexpr (CT > 0) {
-        // bands lane and lane + 64 of each channel; per-band constants hoisted out of the subframe loop;
-        // one packed DPP scan (two 16-bit sums) places both halves of the spectrum
+        // bands 2*lane and 2*lane + 1 of each channel (neighbours in the bit stream: their two codes go out as one write);
+        // per-band constants hoisted out of the subframe loop
         int rb[NB], downb[NB]; float invb[NB], upb[NB]; uint32_t mbb[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            const int i = (int)lane + 64 * (b & 1);
-            rb[b] = inr[b] ? enc_resolution(T, sfr[b], i < eval_boundary ? noise_level - 1 : noise_level) : 0;
+            rb[b] = L.res[(b >> 1) * 128 + 2 * lane + (b & 1)];           // 0 past the coded bands
             invb[b] = T.inv[rb[b]]; upb[b] = invb[b] + 1; downb[b] = (int)((double)invb[b] + 0.5);
             mbb[b] = rb[b] >= 8 ? (uint32_t)enc_maxbits(rb[b]) - 1 : 1u;
         }
@@ -712,10 +711,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
 #pragma unroll
             for (int c = 0; c < CT; c++) {
                 uint32_t code[2], len[2];
+                const float2 xv = *(const float2*)(L.sc + (c * 8 + sf) * 128 + 2 * lane);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int b = 2 * c + h, r = rb[b];
-                    const int q = (int)(L.sc[(c * 8 + sf) * 128 + lane + 64 * h] * invb[b] + upb[b]) - downb[b];
+                    const int q = (int)((h ? xv.y : xv.x) * invb[b] + upb[b]) - downb[b];
                     const uint32_t ti = (uint32_t)r * 16 + ((uint32_t)(q + 8) & 15);
                     const uint32_t lt = T.clen[ti & 127], ct = T.code[ti & 127];
                     const uint32_t mag = (uint32_t)(q < 0 ? -q : q) & ((1u << mbb[b]) - 1);
@@ -723,13 +723,13 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                     len[h] = r == 0 ? 0u : (r < 8 ? lt : lb);
                     code[h] = r == 0 ? 0u : (r < 8 ? ct : cb);
                 }
-                const uint32_t v = len[0] | (len[1] << 16);
-                const uint32_t incl = wave_incl_scan_dpp(v), excl = incl - v;
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), tot0 = tot & 0xFFFF;
+                const uint32_t tl = len[0] + len[1];                       // at most 13 + 13 bits
+                const uint32_t both = (code[0] << len[1]) | code[1];
+                const uint32_t incl = wave_incl_scan_dpp(tl);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 // BitWriter drops writes that do not fit (IO.cpp:131-134); the rate loop guarantees they do
-                put_bits(L.words, pos + (excl & 0xFFFF), code[0], len[0]);
-                put_bits(L.words, pos + tot0 + (excl >> 16), code[1], len[1]);
-                pos += tot0 + (tot >> 16);
+                put_bits(L.words, pos + (incl - tl), both, tl);
+                pos += tot;
             }
         }
     } else {
