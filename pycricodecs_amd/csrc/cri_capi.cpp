@@ -1049,8 +1049,8 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
         a.channels = F.channels; a.frame_size = F.frame_size; a.crc_chunk = (F.frame_size - 2 + 63) / 64;
         j->hca_enc_crc_off.push_back((uint32_t)crcmul.size());
-        for (uint32_t k = 0; k < 6; k++) {
-            uint32_t v = crc_xpow_bytes(a.crc_chunk << k);
+        for (uint32_t l = 0; l < 64; l++) {
+            uint32_t v = crc_xpow_bytes(a.crc_chunk * (63 - l));
             for (uint32_t bit = 0; bit < 16; bit++) { crcmul.push_back((uint16_t)v); v = ((v << 1) ^ ((v & 0x8000) ? 0x8005u : 0u)) & 0xFFFF; }
         }
         if (hca_encode_lds_bytes(F.channels, F.frame_size) > 160 * 1024) {
@@ -1062,7 +1062,7 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
     }
     if (formats.empty()) { HcaFormat F; memset(&F, 0, sizeof F); formats.push_back(F); }
     if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
-    if (crcmul.empty()) crcmul.assign(96, 0);
+    if (crcmul.empty()) crcmul.assign(1024, 0);
     int rc = 0;
     if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     *out = j;

@@ -40,12 +40,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v);
 __device__ __forceinline__ int wave_sum(int v) {          // total of the 64 lanes, wave-uniform (SGPR)
     return __builtin_amdgcn_readlane((int)wave_incl_scan_dpp((uint32_t)v), 63);
 }
-__device__ __forceinline__ int wave_excl_scan(int v, uint32_t lane) {
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
-    return inc - v;
-}
+__device__ __forceinline__ int wave_excl_scan(int v, uint32_t) { return (int)wave_incl_scan_dpp((uint32_t)v) - v; }
 // inclusive prefix sum over the 64 lanes with DPP adds: row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast 15 / 31
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
@@ -65,7 +60,7 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
 // encoder's bottleneck: ~940 dependent loads per frame)
 struct EncTab {
     const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64] [8][64] [64] [64] [16] [16] [16]
-    const uint16_t* crcmul;                                                 // [6][16] per launch (HcaEncArgs::crc_mul)
+    const uint16_t* crcmul;                                                 // (unused slot)
     const uint8_t* sfbase;                                                  // [32] entries of deq[0..62] that are <= 2^(j - 25)
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
     const uint32_t* bnd;                                                    // [16] per resolution: fewest | most << 16 bits one spectrum can take
@@ -78,7 +73,7 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
     uint16_t* cm = (uint16_t*)(shuf + 128);
     uint8_t* sfb = (uint8_t*)(cm + 96);
     uint32_t* bnd = (uint32_t*)(sfb + 32);
-    for (uint32_t i = tid; i < 96; i += nthreads) cm[i] = crc_mul[i];
+    (void)crc_mul;                                                          // (read by the checksum step itself, a row per lane)
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
     for (uint32_t i = tid; i < 64; i += nthreads) { escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
@@ -674,7 +669,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             int d0 = 0, d1 = 0;
             if (b0 < coded) { if (b0 == 0) len0 = 6; else { d0 = (int)sf[b0] - (int)sf[b0 - 1]; len0 = (d0 < 0 ? -d0 : d0) > maxd ? db + 6 : db; } }
             if (b1 < coded) { d1 = (int)sf[b1] - (int)sf[b1 - 1]; len1 = (d1 < 0 ? -d1 : d1) > maxd ? db + 6 : db; }
-            const int off = wave_excl_scan(len0 + len1, lane);
+            const uint32_t incl01 = wave_incl_scan_dpp((uint32_t)(len0 + len1));
+            const int off = (int)incl01 - (len0 + len1);
             if (b0 < coded) {
                 if (b0 == 0) put_bits(L.words, pos + off, sf[0], 6);
                 else if (len0 > db) { put_bits(L.words, pos + off, (uint32_t)esc, (uint32_t)db); put_bits(L.words, pos + off + db, sf[b0], 6); }
@@ -684,7 +680,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                 if (len1 > db) { put_bits(L.words, pos + off + len0, (uint32_t)esc, (uint32_t)db); put_bits(L.words, pos + off + len0 + db, sf[b1], 6); }
                 else put_bits(L.words, pos + off + len0, (uint32_t)(maxd + d1), (uint32_t)db);
             }
-            pos += (uint32_t)wave_sum(len0 + len1);
+            pos += (uint32_t)__builtin_amdgcn_readlane((int)incl01, 63);
         }
         if (F.type(c) == CRI_CH_SECONDARY) {
             if (lane < 8) put_bits(L.words, pos + 4 * lane, L.inten[c * 8 + lane], 4);
@@ -764,10 +760,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
     wave_lds_sync();
 
     ENC_MARK(6);
-    // ---- CRC16 over frame_size-2 bytes (hca.cpp:2961-2962), chunk per lane + log-step combine.
+    // ---- CRC16 over frame_size-2 bytes (hca.cpp:2961-2962), chunk per lane, then one multiply per lane and an xor across the wave.
     // The message is front-padded with zero bytes to 64*m bytes (leading zeros do not change a zero-init CRC).
     {
         const uint32_t n = F.frame_size - 2, m = a.crc_chunk, pad = 64 * m - n;
+        const uint4 cw0 = ((const uint4*)(a.crc_mul + lane * 16))[0], cw1 = ((const uint4*)(a.crc_mul + lane * 16))[1];
         uint32_t crc = 0;
         for (uint32_t k = 0; k < m; k++) {
             const uint32_t j = lane * m + k;
@@ -775,14 +772,22 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             if (j >= pad) { const uint32_t q = j - pad; b = (L.words[q >> 2] >> (24 - 8 * (q & 3))) & 0xFF; }
             crc = crc16_step_enc(crc, b);
         }
-        for (uint32_t k = 0; k < 6; k++) {
-            const uint32_t partner = (uint32_t)__shfl_down((int)crc, 1 << k);
-            uint32_t mul = 0;                                           // crc * x^(8*m*2^k) mod P
+        // lane l's chunk stands 8*m*(63 - l) bits above the end of the message: multiply by x^that (mod P) -- the launch's table holds
+        // x^bit * x^(8*m*(63 - l)) for the 16 bits of the chunk's remainder, a 32-byte row per lane -- and xor the 64 products together
+        {
+            const uint32_t wr[8] = {cw0.x, cw0.y, cw0.z, cw0.w, cw1.x, cw1.y, cw1.z, cw1.w};
+            uint32_t acc = 0;
 #pragma unroll
-            for (uint32_t bit = 0; bit < 16; bit++) mul ^= (0u - ((crc >> bit) & 1u)) & T.crcmul[k * 16 + bit];
-            if ((lane & ((2u << k) - 1)) == 0) crc = mul ^ partner;
+            for (uint32_t bit = 0; bit < 16; bit++) acc ^= (0u - ((crc >> bit) & 1u)) & (wr[bit >> 1] >> (16 * (bit & 1)));
+            acc &= 0xFFFFu;
+            acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xF, 0xF, true);      // the scan's pattern, with xor
+            acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x112, 0xF, 0xF, true);
+            acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x114, 0xF, 0xF, true);
+            acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x118, 0xF, 0xF, true);
+            acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x142, 0xA, 0xF, false);
+            acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x143, 0xC, 0xF, false);
+            crc = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63);
         }
-        crc = (uint32_t)__shfl((int)crc, 0);
         if (lane == 0) put_bits(L.words, (F.frame_size - 2) * 8, crc & 0xFFFF, 16);
     }
     wave_lds_sync();

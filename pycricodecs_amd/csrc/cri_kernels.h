@@ -43,7 +43,7 @@ struct HcaEncArgs {
     const uint8_t* scratch;        // converted PCM16 (HcaStream::pad0 != 0 -> src_offset is relative to scratch)
     const HcaFormat* formats;
     const HcaStream* streams;      // sorted by format; src_offset = first PCM byte, dst_offset = first frame byte
-    const uint16_t* crc_mul;       // [6][16]: (x^bit * x^(8 * crc_chunk * 2^k)) mod P, for the log-step CRC combine
+    const uint16_t* crc_mul;       // [64][16]: (x^bit * x^(8 * crc_chunk * (63 - lane))) mod P: a lane's chunk remainder times its place in the frame
     uint32_t format, stream_begin, stream_end, frames, channels, frame_size;
     uint32_t crc_chunk;            // bytes of the (front-padded) frame each lane checksums
     uint32_t lds_per_wave;         // LDS bytes of one frame's working set (set by launch_hca_encode)
