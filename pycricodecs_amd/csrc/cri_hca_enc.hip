@@ -663,23 +663,25 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             pos += 6 * coded;
         } else if (db != 0) {                                          // WriteScalesFactors, hca.cpp:2894-2918
             const int maxd = (1 << (db - 1)) - 1, esc = (1 << db) - 1;
-            // bands 2*lane, 2*lane+1 per lane so that the prefix sum runs in band order
+            // bands 2*lane, 2*lane+1 per lane so that the prefix sum runs in band order; their codes (a delta, or the escape value
+            // followed by the 6-bit scalefactor; band 0 is always the plain 6 bits) leave as one write of at most 22 bits
             int len0 = 0, len1 = 0;
+            uint32_t c0 = 0, c1 = 0;
             const int b0 = 2 * (int)lane, b1 = b0 + 1;
-            int d0 = 0, d1 = 0;
-            if (b0 < coded) { if (b0 == 0) len0 = 6; else { d0 = (int)sf[b0] - (int)sf[b0 - 1]; len0 = (d0 < 0 ? -d0 : d0) > maxd ? db + 6 : db; } }
-            if (b1 < coded) { d1 = (int)sf[b1] - (int)sf[b1 - 1]; len1 = (d1 < 0 ? -d1 : d1) > maxd ? db + 6 : db; }
-            const uint32_t incl01 = wave_incl_scan_dpp((uint32_t)(len0 + len1));
-            const int off = (int)incl01 - (len0 + len1);
             if (b0 < coded) {
-                if (b0 == 0) put_bits(L.words, pos + off, sf[0], 6);
-                else if (len0 > db) { put_bits(L.words, pos + off, (uint32_t)esc, (uint32_t)db); put_bits(L.words, pos + off + db, sf[b0], 6); }
-                else put_bits(L.words, pos + off, (uint32_t)(maxd + d0), (uint32_t)db);
+                const int d0 = b0 == 0 ? 0 : (int)sf[b0] - (int)sf[b0 - 1];
+                const bool e0 = (d0 < 0 ? -d0 : d0) > maxd;
+                len0 = b0 == 0 ? 6 : (e0 ? db + 6 : db);
+                c0 = b0 == 0 ? (uint32_t)sf[0] : (e0 ? (((uint32_t)esc << 6) | sf[b0]) : (uint32_t)(maxd + d0));
             }
             if (b1 < coded) {
-                if (len1 > db) { put_bits(L.words, pos + off + len0, (uint32_t)esc, (uint32_t)db); put_bits(L.words, pos + off + len0 + db, sf[b1], 6); }
-                else put_bits(L.words, pos + off + len0, (uint32_t)(maxd + d1), (uint32_t)db);
+                const int d1 = (int)sf[b1] - (int)sf[b1 - 1];
+                const bool e1 = (d1 < 0 ? -d1 : d1) > maxd;
+                len1 = e1 ? db + 6 : db;
+                c1 = e1 ? (((uint32_t)esc << 6) | sf[b1]) : (uint32_t)(maxd + d1);
             }
+            const uint32_t incl01 = wave_incl_scan_dpp((uint32_t)(len0 + len1));
+            put_bits(L.words, pos + (incl01 - (uint32_t)(len0 + len1)), (c0 << len1) | c1, (uint32_t)(len0 + len1));
             pos += (uint32_t)__builtin_amdgcn_readlane((int)incl01, 63);
         }
         if (F.type(c) == CRI_CH_SECONDARY) {
