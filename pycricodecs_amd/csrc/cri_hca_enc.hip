@@ -179,19 +179,25 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const EncLds&
 }
 
 // bits of the 8 spectra of one band at one resolution (the inner part of CalculateUsedBits, hca.cpp:2771-2786)
-__device__ __forceinline__ int enc_band_bits(const EncTab& T, const float x[8], int res) {
+// (the spectra as four pairs: the multiply and the add of the quantiser are packed operations, the same two roundings per value)
+__device__ __forceinline__ int enc_band_bits(const EncTab& T, const f2 x[4], int res) {
     int part = 0;
     if (res >= 8) {
         const int bits = enc_maxbits(res) - 1;
         const float dz = T.dead[res];
+        part = 8 * bits;
 #pragma unroll
-        for (int j = 0; j < 8; j++) part += bits + (fabsf(x[j]) >= dz ? 1 : 0);
+        for (int j = 0; j < 4; j++) part += (fabsf(x[j].x) >= dz ? 1 : 0) + (fabsf(x[j].y) >= dz ? 1 : 0);
     } else {
         const float inv = T.inv[res], up = inv + 1;
         const int down = (int)((double)inv + 0.5 - 8);
         const uint8_t* row = T.clen + res * 16;
+        const f2 invv = {inv, inv}, upv = {up, up};
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const int q = (int)(x[j] * inv + up) - down; part += row[q & 15]; }
+        for (int j = 0; j < 4; j++) {
+            const f2 t = x[j] * invv + upv;
+            part += row[((int)t.x - down) & 15] + row[((int)t.y - down) & 15];
+        }
     }
     return part;
 }
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
     // With a compile-time channel count the lane's bands (i = lane, lane + 64 of every channel) sit in registers: their 8
     // scaled spectra, scalefactor and "is coded" flag.
     constexpr int NB = CT > 0 ? 2 * CT : 1;
-    float xr[NB][8]; int sfr[NB]; bool inr[NB];
+    f2 xr[NB][4]; int sfr[NB]; bool inr[NB];
     auto load_bands = [&]() {
         if constexpr (CT > 0) {
 #pragma unroll
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                 inr[b] = i < F.coded(c);
                 sfr[b] = L.sfac[c * 128 + i];
 #pragma unroll
-                for (int j = 0; j < 8; j++) xr[b][j] = L.sc[(c * 8 + j) * 128 + i];
+                for (int j = 0; j < 4; j++) xr[b][j] = f2{L.sc[(c * 8 + 2 * j) * 128 + i], L.sc[(c * 8 + 2 * j + 1) * 128 + i]};
             }
         }
     };
