@@ -59,7 +59,8 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
 // Workgroup-shared LDS copies of every table the per-frame code indexes with data (global-memory lookups were the
 // encoder's bottleneck: ~940 dependent loads per frame)
 struct EncTab {
-    const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64] [8][64] [64] [64] [16] [16] [16]
+    const float *win, *esin, *ecos, *deq, *escale, *dead, *inv, *ibounds;   // [128] [8][64][2] = etw (esin..ecos) [64] [64] [16] [16] [16]
+    const f2* etw;                                                          // [8][64] {cos, sin}
     const uint16_t* crcmul;                                                 // (unused slot)
     const uint8_t* sfbase;                                                  // [32] entries of deq[0..62] that are <= 2^(j - 25)
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
@@ -75,7 +76,7 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
     uint32_t* bnd = (uint32_t*)(sfb + 32);
     (void)crc_mul;                                                          // (read by the checksum step itself, a row per lane)
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
-    for (uint32_t i = tid; i < 512; i += nthreads) { esin[i] = HCA_ENC_SIN[i >> 6][i & 63]; ecos[i] = HCA_ENC_COS[i >> 6][i & 63]; }
+    for (uint32_t i = tid; i < 512; i += nthreads) { esin[2 * i] = HCA_ENC_COS[i >> 6][i & 63]; esin[2 * i + 1] = HCA_ENC_SIN[i >> 6][i & 63]; }   // etw[i] = {cos, sin}: a twiddle is one register pair
     for (uint32_t i = tid; i < 64; i += nthreads) { escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
     for (uint32_t i = tid; i < 72; i += nthreads) deq[i] = i < 63 ? HCA_DEQ_SCALE[i] : __uint_as_float(0x7FC00000u);   // NaN padding never compares <=
     for (uint32_t j = tid; j < 32; j += nthreads) {
@@ -91,7 +92,7 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
         else { lo = i ? 15 : 0; hi = 0; for (uint32_t q = 8 - i; q <= 8 + i; q++) { const uint32_t l = HCA_ENC_CODE_LEN[i][q]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; } }
         bnd[i] = lo | (hi << 16);                          // per spectrum; a band has 8
     }
-    EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
+    EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.etw = (const f2*)esin; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
     T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb; T.bnd = bnd;
     return T;
 }
@@ -114,10 +115,13 @@ __device__ __forceinline__ int enc_resolution(const EncTab& T, int sf, int noise
 }
 __device__ __forceinline__ int enc_maxbits(int res) { return res > 7 ? res - 3 : (int)((0x44443320u >> (res * 4)) & 15); }
 
-// (u.x*c + u.y*s, u.x*s - u.y*c): the rotation of hca.cpp:2515-2520 / 2493-2496 as three packed operations
-__device__ __forceinline__ f2 enc_rot(f2 u, float sn, float cs) {
-    const f2 p = u.xx * f2{cs, sn};
-    const f2 q = u.yy * f2{sn, cs};
+// (u.x*c + u.y*s, u.x*s - u.y*c): the rotation of hca.cpp:2515-2520 / 2493-2496 as three packed operations.  The twiddle is one
+// register pair tw = {c, s}, and the operand selects of the packed multiplies pick u.x / u.y and c / s -- written out as
+// instructions because the compiler builds the broadcast operands with moves first (68 of a pass's 274 instructions)
+__device__ __forceinline__ f2 enc_rot(f2 u, f2 tw) {
+    f2 p, q;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p) : "v"(u), "v"(tw));      // {u.x*c, u.x*s}
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(u), "v"(tw));      // {u.y*s, u.y*c}
     return pk_add_neg_hi(p, q);
 }
 
@@ -389,34 +393,34 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             }
             f2 z[4];
             {
-                const float4 s7 = *(const float4*)(T.esin + 7 * 64 + 4 * l16), c7 = *(const float4*)(T.ecos + 7 * 64 + 4 * l16);
-                const float sn[4] = {s7.x, s7.y, s7.z, s7.w}, cs[4] = {c7.x, c7.y, c7.z, c7.w};
+                const float4 ta = *(const float4*)(T.etw + 7 * 64 + 4 * l16), tb = *(const float4*)(T.etw + 7 * 64 + 4 * l16 + 2);
+                const f2 tw[4] = {f2{ta.x, ta.y}, f2{ta.z, ta.w}, f2{tb.x, tb.y}, f2{tb.z, tb.w}};
 #pragma unroll
-                for (int r = 0; r < 4; r++) z[r] = enc_rot(f2{in[r], in[4 + r]}, sn[r], cs[r]);
+                for (int r = 0; r < 4; r++) z[r] = enc_rot(f2{in[r], in[4 + r]}, tw[r]);
             }
 #define ENC_CROSS(X, HB, SG) { \
                 const uint32_t ti = HB * 64 + ((l16 & (X - 1)) << 2); \
-                const float4 s4 = *(const float4*)(T.esin + ti), c4 = *(const float4*)(T.ecos + ti); \
-                const float sn[4] = {s4.x, s4.y, s4.z, s4.w}, cs[4] = {c4.x, c4.y, c4.z, c4.w}; \
+                const float4 ta = *(const float4*)(T.etw + ti), tb = *(const float4*)(T.etw + ti + 2); \
+                const f2 tw[4] = {f2{ta.x, ta.y}, f2{ta.z, ta.w}, f2{tb.x, tb.y}, f2{tb.z, tb.w}}; \
                 const bool hi = (l16 & X) != 0; \
                 _Pragma("unroll") for (int r = 0; r < 4; r++) { \
                     const f2 u = __builtin_elementwise_fma(z[r], f2{SG, SG}, lane16_xor2<X>(z[r])); \
-                    const f2 w = enc_rot(u, sn[r], cs[r]); \
+                    const f2 w = enc_rot(u, tw[r]); \
                     z[r] = f2{hi ? w.x : u.x, hi ? w.y : u.y}; \
                 } }
             ENC_CROSS(8, 5, sg8) ENC_CROSS(4, 4, sg4) ENC_CROSS(2, 3, sg2) ENC_CROSS(1, 2, sg1)
 #undef ENC_CROSS
             {   // bit 1 of j: (z0, z2) with twiddle [1][0], (z1, z3) with [1][1]
-                const float2 s1 = *(const float2*)(T.esin + 64), c1 = *(const float2*)(T.ecos + 64);
+                const float4 t1 = *(const float4*)(T.etw + 64);
                 const f2 d0 = z[0] - z[2], d1 = z[1] - z[3];
                 z[0] = z[0] + z[2]; z[1] = z[1] + z[3];
-                z[2] = enc_rot(d0, s1.x, c1.x); z[3] = enc_rot(d1, s1.y, c1.y);
+                z[2] = enc_rot(d0, f2{t1.x, t1.y}); z[3] = enc_rot(d1, f2{t1.z, t1.w});
             }
             {   // bit 0 of j: (z0, z1), (z2, z3) with twiddle [0][0]
-                const float s0 = T.esin[0], c0 = T.ecos[0];
+                const f2 t0 = T.etw[0];
                 const f2 d0 = z[0] - z[1], d1 = z[2] - z[3];
                 z[0] = z[0] + z[1]; z[2] = z[2] + z[3];
-                z[1] = enc_rot(d0, s0, c0); z[3] = enc_rot(d1, s0, c0);
+                z[1] = enc_rot(d0, t0); z[3] = enc_rot(d1, t0);
             }
             float* out = L.sp + (c * 8 + sf) * 128;
 #pragma unroll
