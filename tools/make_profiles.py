@@ -39,14 +39,22 @@ def main(tag):
                      "XCD under the record stream of 16 waves per CU, so nearly all of those re-reads reach the fabric (the counters include Infinity-Cache hits)." % frames,
            "frames_per_dispatch": frames, "kernels": {}, "algorithmic_bytes_per_frame": bench["roofline"]["algorithmic_bytes_per_launch"] // frames}
     total = 0.0
+    # a counter pass of the full-size batch sometimes does not finish inside its timeout (tools/prof_r02.sh): that counter is then
+    # carried over from the newest earlier traffic file -- named in the kernel's entry -- whose kernels moved the same bytes
+    earlier = sorted(f for f in os.listdir(dst) if f.endswith("_traffic.json") and f[:5] < tag)
+    prev = json.load(open(os.path.join(dst, earlier[-1]))) if earlier else None
     for k, v in raw["hca_decode"].items():
         if "k_hca_" not in k:
             continue
         name = "k_hca_parse" if "parse" in k else "k_hca_transform"
+        carried = []
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if c not in v:
+                v[c] = prev["kernels"][name][c + "_KB"]; carried.append("%s from %s" % (c, earlier[-1]))
         fb, wb = v["FETCH_SIZE"] * 1024 / frames, v["WRITE_SIZE"] * 1024 / frames
         out["kernels"][name] = {"kernel_symbol": k.replace("void cri::", "").replace("cri::", ""), "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"],
                                 "fetch_correction": 1.0, "fetch_bytes_per_frame": round(fb, 1), "write_bytes_per_frame": round(wb, 1),
-                                "hbm_bytes_per_frame": round(fb + wb, 1)}
+                                "hbm_bytes_per_frame": round(fb + wb, 1), "carried_over": carried}
         total += fb + wb
     out["total_hbm_bytes_per_frame"] = round(total, 1)
     others = {}
