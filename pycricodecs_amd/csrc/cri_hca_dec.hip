@@ -79,8 +79,8 @@ __device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; 
 // 16-band block, written once by the scalefactor pass and re-read (coalesced, L2-resident) by each of the 8 subframes.
 //
 // Bit feed.  HBM latency under load is microseconds and the parse is an in-order serial chain, so words travel
-//   input blob (global) --16-byte chunk requested at a checkpoint--> VGPRs --checksummed, deciphered and landed at the NEXT
-//   checkpoint--> per-lane LDS ring --one word prefetched per symbol--> 64-bit shift register.
+//   input blob (global) --16-byte chunk requested at a checkpoint--> VGPRs --checksummed, deciphered and landed one block of
+//   parsing later--> per-lane LDS ring --one word prefetched per symbol--> 64-bit shift register.
 // Checkpoints sit every 16 symbols (at most 16*12 bits = 6 words consumed in between).  A checkpoint asks for as many whole
 // chunks (16 bytes of the lane's frame) as the ring has room for, at most two: with h words in the ring after landing,
 // r = min(8, 4*floor((16-h)/4)) are requested and c <= 6 consumed before they land, so h' = h - c + r >= 7 whenever
@@ -235,14 +235,10 @@ __device__ __forceinline__ void feed_issue_wave(BitFeed& f, uint32_t n, bool ask
 // `eager`: ask whenever there is room (always safe: see the invariant above).  Otherwise only a lane whose ring could run dry
 // asks: `thresh` = the most words the block about to be parsed and the one after it can take, + 2 (the bounds are exact
 // per block, see `needtab` in k_hca_parse; chunks asked for now land before the second of those blocks starts).
-// In the spectra loop the lanes top up together every HCA_FEED_SYNC-th checkpoint and those chunks are only landed
-// HCA_FEED_LAND checkpoints later -- a wave load of 64 lanes' chunks touches 64 cache lines in as many frames and completes
-// with the slowest of them, so it gets two blocks of parsing to do so -- unless a lane would run dry before that.
+// In the spectra loop the lanes top up together every HCA_FEED_SYNC-th block (a landing step then serves most of the wave at
+// once); in between only when a lane would run dry.  A chunk asked for at the top of a block's iteration lands at its bottom.
 #ifndef HCA_FEED_SYNC
-#define HCA_FEED_SYNC 3
-#endif
-#ifndef HCA_FEED_LAND
-#define HCA_FEED_LAND 2
+#define HCA_FEED_SYNC 3     // (measured, parse of 4.69 M frames: 1: 9.68 ms, 2: 9.38, 3: 9.07, 4: 9.00, 5: 9.33)
 #endif
 __device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b, bool eager, uint32_t thresh, uint4& c0, uint4& c1) {
     const uint32_t h = f.wr - b.rd, room = RING_WORDS - h;
