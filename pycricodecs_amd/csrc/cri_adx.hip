@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
     __shared__ __attribute__((aligned(16))) int32_t dl[R][2][32];      // [frame][half][sample] code * scale
     __shared__ __attribute__((aligned(16))) int32_t ol[R][2][32];      // [frame][half][sample] decoded samples
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][K * 36];
-    const AdxStream S = a.streams[blockIdx.x];
+    const AdxStream S = a.streams[a.wpf_order ? a.wpf_order[blockIdx.x] : blockIdx.x];
     const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
     const bool act = half < C;
     const uint32_t chain = S.first_chain + (act ? half : 0);
@@ -573,7 +573,7 @@ template <int C>
 __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
     __shared__ uint8_t blk_img[40];
     __shared__ __attribute__((aligned(16))) int32_t xl[64];   // a frame's (sample << 12), by lane
-    const AdxStream S = a.streams[blockIdx.x];
+    const AdxStream S = a.streams[a.wpf_order ? a.wpf_order[blockIdx.x] : blockIdx.x];
     if (S.channels != (uint32_t)C) return;
     const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31;
     const bool act = half < C;

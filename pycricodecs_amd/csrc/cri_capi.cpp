@@ -50,7 +50,7 @@ struct cri_job {
     std::string dominant;
     // device metadata
     DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
-        d_frame_sizes, d_first_frame, d_adx_streams, d_convert;
+        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_convert;
     std::vector<ConvertItem> convert;            // WAV items whose samples are converted to PCM16 in scratch before encoding
     uint64_t convert_total = 0;
     // registers item data for conversion; returns the scratch offset its PCM16 will be at
@@ -407,6 +407,17 @@ static bool adx_pick_wave_per_file(bool all_std, size_t n_streams, bool encode) 
 // the wave's rows would pass ADX_LDS_ROW_LIMIT; an item that does not fit a wave on its own is left to the caller
 // (CRI_ERR_UNSUPPORTED for that item alone).  finish() picks T for ~56 KB per wave (occupancy) and the exact maxima.
 static const uint32_t ADX_LDS_ROW_LIMIT = 150 * 1024;
+// wave-per-file kernels: a workgroup is a file and runs as long as the file is -- the longest ones are started first
+static std::vector<uint32_t> adx_longest_first(const std::vector<AdxStream>& streams) {
+    std::vector<uint32_t> order(streams.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    bool same = true;
+    for (size_t i = 1; i < streams.size(); i++) if (streams[i].frames != streams[0].frames) same = false;
+    if (same) return {};                                  // nothing to gain: the kernels take workgroup b = stream b
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return streams[x].frames > streams[y].frames; });
+    return order;
+}
+
 struct AdxWavePlan {
     std::vector<uint32_t> in_row, out_row, files;        // per wave: sum of the files' row bytes (in / out), file count
     bool place(std::vector<uint32_t>& chain_stream, std::vector<int16_t>& history, uint32_t channels, uint32_t in_row_bytes, uint32_t out_row_bytes) {
@@ -488,11 +499,12 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
     j->adx_streams = (uint32_t)streams.size();
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), false);
     if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
+    const std::vector<uint32_t> order = j->adx_wave_per_file ? adx_longest_first(streams) : std::vector<uint32_t>();
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
-        (rc = j->upload_images())) { delete j; return rc; }
+        (!order.empty() && (rc = j->d_adx_order.upload(order))) || (rc = j->upload_images())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -892,11 +904,13 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     j->adx_streams = (uint32_t)streams.size();
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), true);
     if (j->adx_wave_per_file) j->dominant = "k_adx_encode_wpf";
+    const std::vector<uint32_t> order = j->adx_wave_per_file ? adx_longest_first(streams) : std::vector<uint32_t>();
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     if (stale.empty()) stale.push_back(0);
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
+        (!order.empty() && (rc = j->d_adx_order.upload(order))) ||
         (rc = j->d_stale.upload(stale)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     *out = j;
     return 0;
@@ -1109,7 +1123,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
             AdxArgs a = j->adx;
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
             a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
-            a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p;
+            a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p; a.wpf_order = (const uint32_t*)j->d_adx_order.p;
             j->mark(0, true, s);
             if (j->adx_wave_per_file) { if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode_wpf(a, j->adx_streams, s); else launch_adx_encode_wpf(a, j->adx_streams, s); }
             else if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode(a, s); else launch_adx_encode(a, s);

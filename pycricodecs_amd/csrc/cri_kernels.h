@@ -61,6 +61,7 @@ struct AdxArgs {
     uint32_t chains;               // incl. padding entries (chain_stream == 0xFFFFFFFF) that keep a file inside one wave
     uint32_t rows_per_round;       // block rows staged in LDS per round (T)
     uint32_t lds_in_bytes, lds_out_bytes;
+    const uint32_t* wpf_order;     // wave-per-file kernels: stream of workgroup b (longest files first), or null = b
 };
 void launch_adx_decode(const AdxArgs& a, hipStream_t s);
 void launch_adx_encode(const AdxArgs& a, hipStream_t s);
