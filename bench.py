@@ -437,8 +437,16 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True):
     _, ao, ascr, ast = aj.alloc(D.dev, upload=False)
     gathered = {}
 
+    # the two jobs are independent: the ADX one (one wave per file, as long as its longest clip) runs on a stream of its own and the
+    # HCA kernels fill the rest of the chip meanwhile; both are inside the timed region (the main stream waits for the side one)
+    side = torch.cuda.Stream(D.dev)
+
     def step():
-        hj.run(d_in, ho, hscr, hst); aj.run(d_in, ao, ascr, ast)
+        main = torch.cuda.current_stream(D.dev)
+        side.wait_stream(main)
+        aj.run(d_in, ao, ascr, ast, stream=side)
+        hj.run(d_in, ho, hscr, hst)
+        main.wait_stream(side)
         if gather and world > 1:
             gathered["hca"] = shard.gather_bytes_to_root(ho[:hj.output_bytes]); gathered["adx"] = shard.gather_bytes_to_root(ao[:aj.output_bytes])
     dt, _ = run_timed(D, step, max(steps, 1), max(warmup, 1), [])

@@ -68,14 +68,22 @@ class AWB:
         hca_job, adx_job = Job.awb_decode(self.data, key)
         d_in, d_out, d_scr, d_st = hca_job.alloc(device)
         outs = [None] * self.numfiles
-        for job, kind, bufs in ((hca_job, KIND_HCA, (d_out, d_scr, d_st)), (adx_job, KIND_ADX, None)):
+        # the two jobs are independent: the ADX one (one wave per file, as long as its longest clip) goes to a stream of its own and
+        # the HCA kernels fill the rest of the chip meanwhile
+        main, side = torch.cuda.current_stream(device), torch.cuda.Stream(device)
+        ran = []
+        for job, kind, bufs, stream in ((adx_job, KIND_ADX, None, side), (hca_job, KIND_HCA, (d_out, d_scr, d_st), main)):
             if not (self.kinds == kind).any():
                 continue
             if bufs is None:
                 _, o2, s2, st2 = job.alloc(device, upload=False)
                 bufs = (o2, s2, st2)
-            job.run(d_in, *bufs)
-            torch.cuda.synchronize()
+            if stream is side:
+                side.wait_stream(main)                     # (the bank's upload)
+            job.run(d_in, *bufs, stream=stream)
+            ran.append((job, kind, bufs))
+        torch.cuda.synchronize(device)
+        for job, kind, bufs in ran:
             blob = bytes(bufs[0][:max(job.output_bytes, 1)].cpu().numpy())
             status = bufs[2].cpu().numpy()
             items = job.split(blob)
