@@ -420,9 +420,12 @@ static std::vector<uint32_t> adx_longest_first(const std::vector<AdxStream>& str
 
 struct AdxWavePlan {
     std::vector<uint32_t> in_row, out_row, files;        // per wave: sum of the files' row bytes (in / out), file count
+    static bool fits(uint32_t channels, uint32_t in_row_bytes, uint32_t out_row_bytes) {
+        return channels <= 64 && ((in_row_bytes + 3) & ~3u) + ((out_row_bytes + 3) & ~3u) + 8 <= ADX_LDS_ROW_LIMIT;
+    }
     bool place(std::vector<uint32_t>& chain_stream, std::vector<int16_t>& history, uint32_t channels, uint32_t in_row_bytes, uint32_t out_row_bytes) {
         const uint32_t need = ((in_row_bytes + 3) & ~3u) + ((out_row_bytes + 3) & ~3u) + 8;
-        if (channels > 64 || need > ADX_LDS_ROW_LIMIT) return false;
+        if (!fits(channels, in_row_bytes, out_row_bytes)) return false;
         size_t w = chain_stream.size() / 64;
         if (in_row.size() <= w) { in_row.resize(w + 1, 0); out_row.resize(w + 1, 0); files.resize(w + 1, 0); }
         const uint32_t used = ((in_row[w] + 3) & ~3u) + ((out_row[w] + 3) & ~3u) + 8 * files[w] + 8 * 64;
@@ -457,7 +460,7 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_ADX_DECODE, it);
     j->dominant = "k_adx_decode";
-    std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history;
+    std::vector<AdxStream> streams, pend; std::vector<uint32_t> chain_stream; std::vector<int16_t> history, pend_hist;
     AdxWavePlan plan;
     bool all_std = true;
     uint64_t out_pos = 0;
@@ -479,26 +482,39 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
         S.frames = h.blocks; S.channels = h.channels; S.blocksize = h.blocksize; S.bitdepth = h.bitdepth; S.mode = h.mode;
         S.samples_per_block = h.samples_per_block; S.coef0 = h.coef[0]; S.coef1 = h.coef[1]; S.samples = h.sample_count;
         // (more than 64 channels, or one block row that does not fit a wave's LDS: bitdepth 1 with tens of channels)
-        if (!plan.place(chain_stream, history, h.channels, h.channels * h.blocksize, h.channels * h.samples_per_block * 2)) {
+        if (!AdxWavePlan::fits(h.channels, h.channels * h.blocksize, h.channels * h.samples_per_block * 2)) {
             j->host_status[i] = CRI_ERR_UNSUPPORTED; j->images.pop_back(); continue;
         }
-        S.item = i; S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
+        S.item = i;
         if (!(h.blocksize == 18 && h.bitdepth == 4 && h.channels <= 2)) all_std = false;
-        for (uint32_t c = 0; c < h.channels; c++) {
-            chain_stream.push_back((uint32_t)streams.size());
-            history.push_back(h.history[2 * c]); history.push_back(h.history[2 * c + 1]);
-        }
-        streams.push_back(S);
+        pend.push_back(S);
+        for (uint32_t c = 0; c < h.channels; c++) { pend_hist.push_back(h.history[2 * c]); pend_hist.push_back(h.history[2 * c + 1]); }
         out_pos = align_up(out_pos + wh + (uint64_t)h.sample_count * h.channels * 2, 64);
         j->units += h.blocks; j->units2 += (uint64_t)h.blocks * h.channels;
         j->alg_bytes += (uint64_t)h.blocks * h.channels * (h.blocksize + 2ull * h.samples_per_block);
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, pend.size(), false);
+    if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
+    {   // chains are laid out now.  Lane per chain: a wave lasts as long as the longest of its 64 chains, so the files go in by
+        // length (outputs stay where the item order put them); wave per file: item order, and the kernel gets `wpf_order`
+        std::vector<uint32_t> seq(pend.size()), hist_at(pend.size());
+        for (size_t k = 0, hpos = 0; k < pend.size(); k++) { seq[k] = (uint32_t)k; hist_at[k] = (uint32_t)hpos; hpos += 2 * pend[k].channels; }
+        if (!j->adx_wave_per_file) std::stable_sort(seq.begin(), seq.end(), [&](uint32_t x, uint32_t y) { return pend[x].frames > pend[y].frames; });
+        for (uint32_t k : seq) {
+            AdxStream S = pend[k];
+            plan.place(chain_stream, history, S.channels, S.channels * S.blocksize, S.channels * S.samples_per_block * 2);
+            S.first_chain = (uint32_t)chain_stream.size(); S.hist_offset = S.first_chain;
+            for (uint32_t c = 0; c < S.channels; c++) {
+                chain_stream.push_back((uint32_t)streams.size());
+                history.push_back(pend_hist[hist_at[k] + 2 * c]); history.push_back(pend_hist[hist_at[k] + 2 * c + 1]);
+            }
+            streams.push_back(S);
+        }
+    }
     j->adx.chains = (uint32_t)chain_stream.size();
     plan.finish(j->adx);
     j->adx_streams = (uint32_t)streams.size();
-    j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), false);
-    if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
     const std::vector<uint32_t> order = j->adx_wave_per_file ? adx_longest_first(streams) : std::vector<uint32_t>();
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }

@@ -414,3 +414,23 @@ def test_sfa_pack_adx_shorter_than_one_chunk(cc):
         sizes = [int.from_bytes(c[4:8], "big") - 0x18 - int.from_bytes(c[10:12], "big") for c in chunks]
         assert sizes == model_sizes(adx), (n, ch, sr)
         assert chunks[-1].endswith(b"#CONTENTS END   ===============\x00")
+
+
+@pytest.mark.parametrize("mapping", ["chain", "file"])
+def test_adx_decode_many_lengths_both_mappings(cc, mapping, monkeypatch):
+    """The lane-per-chain planner lays the files out by length (a wave lasts as long as its longest chain) and the wave-per-file
+    kernels take them longest first; outputs stay in item order.  A few hundred clips of shuffled lengths, mono and stereo, cross
+    wave boundaries in both."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", mapping)
+    rng = np.random.default_rng(31)
+    uniq = [O.adx_encode(synth.wav(700 + k, 32 * int(rng.integers(1, 60)), 1 + k % 2, 48000)) for k in range(24)]
+    pick = rng.integers(0, len(uniq), 300)
+    items = [uniq[k] for k in pick]
+    job = Job.adx_decode(items)
+    assert job.dominant_kernel == ("k_adx_decode_wpf" if mapping == "file" else "k_adx_decode")
+    outs, st = job.run_host()
+    assert not st.any()
+    refs = [O.adx_decode(u) for u in uniq]
+    for i, k in enumerate(pick):
+        assert bytes(outs[i]) == refs[k], i
