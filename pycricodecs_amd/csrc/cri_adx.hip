@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
 #pragma unroll
                 for (int t = 0; t < R; t++) {
                     const int32_t code = (int32_t)((s & 1 ? b[t] << 28 : b[t] << 24) & 0xF0000000u) >> 28;
-                    dl[t][half][s] = code * ((int32_t)sc[t] + 1);
+                    dl[t][half][s] = (code * ((int32_t)sc[t] + 1)) << 12;      // (|code * scale| < 2^19: shifted here, by all lanes at once, not on the chain)
                 }
                 wave_lds_sync();
                 const int32_t c0 = S.coef0, c1 = S.coef1;
@@ -453,11 +453,13 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
 #pragma unroll
                     for (int k = 0; k < 32; k += 4) { const int4 q = *(const int4*)&dl[t][half][k]; d[k] = q.x; d[k + 1] = q.y; d[k + 2] = q.z; d[k + 3] = q.w; }
                     int32_t v1 = h1, v2 = h2;
-                    int32_t pre = (d[0] + (__mul24(c1, v2) >> 12)) << 12;
+                    // (d + (c1*h2 >> 12)) << 12 = (d << 12) + (c1*h2 with its low 12 bits cleared): five instructions per sample
+                    // (the sum's low 12 bits are the product's: clearing them after the add is the same, and one multiply-add)
+                    int32_t pre = (int32_t)((uint32_t)(__mul24(c1, v2) + d[0]) & 0xFFFFF000u);
 #pragma unroll
                     for (int k = 0; k < 32; k++) {
                         const int32_t v = clamp_sym((__mul24(c0, v1) + pre) >> 12, 0x7FFF);
-                        if (k < 31) pre = (d[k + 1] + (__mul24(c1, v1) >> 12)) << 12;
+                        if (k < 31) pre = (int32_t)((uint32_t)(__mul24(c1, v1) + d[k + 1]) & 0xFFFFF000u);
                         d[k] = v;
                         v2 = v1; v1 = v;
                     }
