@@ -164,6 +164,21 @@ __global__ __launch_bounds__(64) void k_adx_decode(AdxArgs a) {
                     c1 = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
                 } else scale += 1;
                 int16_t* o = fo + (uint64_t)t * spb * C + X.ch;
+                if (std4 && !__any(stopped)) {
+                    // (the usual row: no chain of the wave has ended -- no per-sample selects)
+#pragma unroll
+                    for (uint32_t w = 0; w < 8; w++) {
+                        const uint32_t wd = ((uint32_t)blk[2 + 2 * w] << 8) | blk[3 + 2 * w];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++) {
+                            const int32_t code = (int32_t)(wd << (16 + 4 * k)) >> 28;
+                            const int32_t v = clamp_sym(__mul24(code, scale) + (__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12), 0x7FFF);
+                            h2 = h1; h1 = v;
+                            o[(uint64_t)(4 * w + k) * C] = (int16_t)v;
+                        }
+                    }
+                    continue;
+                }
                 if (std4) {
                     // blocksize 18 / bitdepth 4: 8 big-endian 16-bit words of four codes each; 24-bit multiplies are exact here
                     // (|code| < 2^3, scale < 2^14, |coef| < 2^13, |history| < 2^15)
