@@ -50,7 +50,7 @@ struct cri_job {
     std::string dominant;
     // device metadata
     DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
-        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_convert;
+        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert;
     std::vector<ConvertItem> convert;            // WAV items whose samples are converted to PCM16 in scratch before encoding
     uint64_t convert_total = 0;
     // registers item data for conversion; returns the scratch offset its PCM16 will be at
@@ -942,6 +942,7 @@ extern "C" int cri_job_create_adx_encode_items(const cri_items* items, const cri
 }
 
 // ------------------------------------------------------------------------------------------------ HCA crypt
+static uint16_t crc_xpow_bytes(uint32_t nbytes);
 static int create_hca_crypt(const ItemSrc& it, uint32_t encrypt, uint32_t type, const uint64_t* keys,
                             const uint16_t* subkeys, const uint32_t* header_sizes, cri_job** out) {
     const uint32_t n = it.n;
@@ -992,8 +993,23 @@ static int create_hca_crypt(const ItemSrc& it, uint32_t encrypt, uint32_t type, 
     for (uint32_t fsz : frame_sizes) j->crypt.max_frame_size = std::max(j->crypt.max_frame_size, fsz);
     if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); frame_sizes.push_back(8); }
     if (cipher.empty()) cipher.assign(256, 0);
+    // checksum tables of the wave-per-frame kernel, one per distinct frame size: a lane's chunk remainder times its place in the frame
+    std::vector<uint16_t> crcpos; std::vector<uint32_t> crc_off; std::map<uint32_t, uint32_t> crc_by_size;
+    for (uint32_t fsz : frame_sizes) {
+        auto it2 = crc_by_size.find(fsz);
+        if (it2 == crc_by_size.end()) {
+            it2 = crc_by_size.emplace(fsz, (uint32_t)crcpos.size()).first;
+            const uint32_t m = fsz >= 2 ? (fsz - 2 + 63) / 64 : 0;
+            for (uint32_t l = 0; l < 64; l++) {
+                uint32_t v = crc_xpow_bytes(m * (63 - l));
+                for (uint32_t bit = 0; bit < 16; bit++) { crcpos.push_back((uint16_t)v); v = ((v << 1) ^ ((v & 0x8000) ? 0x8005u : 0u)) & 0xFFFF; }
+            }
+        }
+        crc_off.push_back(it2->second);
+    }
     int rc = 0;
     if ((rc = j->d_streams.upload(streams)) || (rc = j->d_frame_sizes.upload(frame_sizes)) || (rc = j->d_first_frame.upload(first_frame)) ||
+        (rc = j->d_crcmul.upload(crcpos)) || (rc = j->d_crc_off.upload(crc_off)) ||
         (rc = j->d_cipher.upload(cipher)) || (rc = j->upload_images())) { delete j; return rc; }
     *out = j;
     return 0;
@@ -1160,6 +1176,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.streams = (const HcaStream*)j->d_streams.p;
             a.frame_sizes = (const uint32_t*)j->d_frame_sizes.p; a.cipher_tables = (const uint8_t*)j->d_cipher.p;
             a.first_frame = (const uint32_t*)j->d_first_frame.p;
+            a.crc_pos = (const uint16_t*)j->d_crcmul.p; a.crc_pos_off = (const uint32_t*)j->d_crc_off.p;
             j->mark(0, true, s); launch_hca_crypt(a, s); j->mark(0, false, s);
             break;
         }

@@ -77,6 +77,8 @@ struct CryptArgs {
     const uint32_t* first_frame;   // prefix over streams, n_streams + 1
     uint32_t n_streams, frames;
     uint32_t max_frame_size;       // largest frame of the job (sizes the wave-per-frame kernel's LDS image)
+    const uint16_t* crc_pos;       // per distinct frame size [64][16]: (x^bit * x^(8 * m * (63 - lane))) mod P, m = bytes per lane of the checksum
+    const uint32_t* crc_pos_off;   // per stream: its table's first entry
 };
 void launch_hca_crypt(const CryptArgs& a, hipStream_t s);
 

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64) void k_hca_crypt_wpf(CryptArgs a) {
     const uint8_t* src = a.in + st.src_offset + (uint64_t)f * fs;
     uint8_t* dst = a.out + st.dst_offset + (uint64_t)f * fs;
     uint8_t* lut = smem; uint8_t* img = smem + 256;
+    const uint4 cw0 = ((const uint4*)(a.crc_pos + a.crc_pos_off[lo] + lane * 16))[0], cw1 = ((const uint4*)(a.crc_pos + a.crc_pos_off[lo] + lane * 16))[1];
     ((uint32_t*)lut)[lane] = ((const uint32_t*)(a.cipher_tables + st.cipher * 256))[lane];
     wave_lds_sync();
     const uint32_t n = fs - 2;                                  // bytes under the checksum (hca.cpp:3322-3331); fs >= 8
@@ -175,16 +176,22 @@ __global__ __launch_bounds__(64) void k_hca_crypt_wpf(CryptArgs a) {
         const uint32_t j = lane * m + k;
         crc = crc16_step_tf(crc, j >= pad ? (uint32_t)img[j - pad] : 0u);
     }
-    uint32_t xp = 1;                                            // x^(8 m) mod P, wave-uniform
-    for (uint32_t i = 0; i < 8 * m; i++) xp = ((xp << 1) ^ ((xp & 0x8000u) ? 0x8005u : 0u)) & 0xFFFFu;
-#pragma unroll 1
-    for (uint32_t k = 0; k < 6; k++) {
-        const uint32_t partner = (uint32_t)__shfl_down((int)crc, 1 << k);
-        const uint32_t mul = gf16_mulmod(crc, xp);
-        if ((lane & ((2u << k) - 1)) == 0) crc = mul ^ partner;
-        xp = gf16_mulmod(xp, xp);
+    // lane l's chunk stands 8*m*(63 - l) bits above the end of the message: multiply its remainder by x^that (mod P; the job's
+    // table for this frame size holds x^bit * x^(8*m*(63 - l)), a 32-byte row per lane) and xor the 64 products together
+    {
+        const uint32_t wr[8] = {cw0.x, cw0.y, cw0.z, cw0.w, cw1.x, cw1.y, cw1.z, cw1.w};
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t bit = 0; bit < 16; bit++) acc ^= (0u - ((crc >> bit) & 1u)) & (wr[bit >> 1] >> (16 * (bit & 1)));
+        acc &= 0xFFFFu;
+        acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xF, 0xF, true);          // a scan's pattern, with xor
+        acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x112, 0xF, 0xF, true);
+        acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x114, 0xF, 0xF, true);
+        acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x118, 0xF, 0xF, true);
+        acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x142, 0xA, 0xF, false);
+        acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x143, 0xC, 0xF, false);
+        crc = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63);
     }
-    crc = (uint32_t)__shfl((int)crc, 0);
     if (lane == 0) { img[fs - 2] = (uint8_t)(crc >> 8); img[fs - 1] = (uint8_t)crc; }
     wave_lds_sync();
     for (uint32_t d = lane; 4 * d + 4 <= fs; d += 64) { const uint32_t w = ((const uint32_t*)img)[d]; __builtin_memcpy(dst + 4 * d, &w, 4); }
