@@ -560,6 +560,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
         }
     };
     auto header_bits = [&]() { int h = 16 + 16 + 16; for (uint32_t c = 0; c < C; c++) h += L.hbits[c]; return h; };
+    // The noise-level search ends with noise_level = the last level found to fit and noise_level - 1 = the last one found not to;
+    // the boundary search that follows costs every band at exactly those two levels.  The bands' bits of the last exact
+    // evaluation of either kind are kept (`last`, per lane and band), so that they are not quantised again.
+    int fit_bits[NB], over_bits[NB], last[NB];
+    int fit_noise = -1000, over_noise = -1000;             // (wave-uniform) levels the kept bits belong to; -1000: none
     auto used_bits = [&](int noise, int eb) -> int {
         if constexpr (CT > 0) {
             int part = 0;
@@ -567,7 +572,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             for (int b = 0; b < NB; b++) {
                 const int i = (int)lane + 64 * (b & 1);
                 const int bits = enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], i < eb ? noise - 1 : noise));
-                part += inr[b] ? bits : 0;
+                last[b] = inr[b] ? bits : 0;
+                part += last[b];
             }
             return header_bits() + wave_sum(part);
         } else return enc_used_bits(F, L, T, lane, noise, eb);
@@ -595,7 +601,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                     const int hb = header_bits(), least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
                     if (least > avail) over = true;
                     else if (most <= avail) over = false;
-                    else over = used_bits(mid, 0) > avail;
+                    else {
+                        over = used_bits(mid, 0) > avail;
+                        if (over) { over_noise = mid; _Pragma("unroll") for (int b = 0; b < NB; b++) over_bits[b] = last[b]; }
+                        else { fit_noise = mid; _Pragma("unroll") for (int b = 0; b < NB; b++) fit_bits[b] = last[b]; }
+                    }
                 } else over = used_bits(mid, 0) > avail;
                 if (over) low = mid + 1; else high = mid;
             }
@@ -608,6 +618,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             wave_lds_sync();
             enc_header_length(F, L, lane);
             load_bands();
+            fit_noise = over_noise = -1000;                // (the scalefactors changed)
         }
     }
     ENC_MARK(3);
@@ -617,8 +628,10 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
         if constexpr (CT > 0) {
 #pragma unroll
             for (int b = 0; b < NB; b++) {
-                costA[b] = inr[b] ? enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], noise_level)) : 0;
-                costB[b] = inr[b] ? enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], noise_level - 1)) : 0;
+                if (fit_noise == noise_level) costA[b] = fit_bits[b];
+                else costA[b] = inr[b] ? enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], noise_level)) : 0;
+                if (over_noise == noise_level - 1) costB[b] = over_bits[b];
+                else costB[b] = inr[b] ? enc_band_bits(T, xr[b], enc_resolution(T, sfr[b], noise_level - 1)) : 0;
             }
         }
         const int hb = header_bits();
