@@ -89,7 +89,7 @@ __device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; 
 // lane that burned more than 4 words in one block) and sits behind a wave-uniform branch, and so do the frame's last,
 // partial chunk and a chunk that would reach past the end of the input blob.
 #define RING_WORDS 16       // (+ 4 spare rows: the sink of a lane that lands nothing)
-size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
+size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + 256 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
 
 struct BitFeed {
     const uint8_t* next;     // next chunk of this lane's frame in the input blob
@@ -319,7 +319,7 @@ __device__ __forceinline__ uint32_t band_meta(uint32_t res) {
 // a symbol's LENGTH is one compare against T -- the only thing the next symbol waits for -- and its value is a table read
 // that nothing waits for until the bytes are packed.  nstab[T] = nshort for the arithmetic path (parse_symbol).
 #define HCA_LUT_BYTES 128
-__device__ __forceinline__ void build_symbol_lut(uint8_t* lut, uint8_t* nstab, uint32_t lane) {
+__device__ __forceinline__ void build_symbol_lut(uint8_t* lut, uint16_t* lut16, uint8_t* nstab, uint32_t lane) {
 #pragma unroll
     for (uint32_t e = lane; e < 128; e += 64) {
         const uint32_t res = e >> 4, idx = e & 15, bits = band_bits(res), ns = band_nshort(res);
@@ -328,6 +328,7 @@ __device__ __forceinline__ void build_symbol_lut(uint8_t* lut, uint8_t* nstab, u
         const uint32_t sym = is_short ? (code >> 1) : (code - ns);
         const uint32_t negv = (sym >> 1) ^ (uint32_t)__builtin_amdgcn_sbfe(sym, 0, 1);
         lut[(band_meta(res) >> 5) * 16 + idx] = (uint8_t)negv;
+        lut16[(band_meta(res) >> 5) * 16 + idx] = (uint16_t)(0u - negv);      // the value itself, for int16 lines
     }
     if (lane < 16) {
         uint32_t ns = 1;                                      // T = 1: resolutions 8..15
@@ -409,8 +410,9 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     uint8_t* needtab = curve + 96;                     // [C][8] most ring words a block of 16 symbols can take over the wave's 64 frames; bit 7: no code of the block has more than four bits
     uint8_t* lut = needtab + 128;                      // [8][16] symbol values of the prefix codes (build_symbol_lut)
     uint8_t* nstab = lut + 128;                        // [16] short-code count by T
-    uint8_t* cipher_lds = nstab + 16;                  // [n_cipher][256] (jobs with up to 16 cipher tables)
-    build_symbol_lut(lut, nstab, lane);
+    uint16_t* lut16 = (uint16_t*)(nstab + 16);         // [8][16] the same values as int16, not negated (tiles whose lines are int16)
+    uint8_t* cipher_lds = (uint8_t*)(lut16 + 128);     // [n_cipher][256] (jobs with up to 16 cipher tables)
+    build_symbol_lut(lut, lut16, nstab, lane);
     for (uint32_t i = lane; i < 66; i += 64) curve[i] = HCA_CURVE_TO_RES[i];
     if (!IDENTITY && CT_LDS) for (uint32_t i = lane; i < a.n_cipher * 64; i += 64) ((uint32_t*)cipher_lds)[i] = ((const uint32_t*)a.cipher_tables)[i];
 
@@ -660,7 +662,29 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 ck = ck + 1 == HCA_FEED_SYNC ? 0 : ck + 1;
                 const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
                 const bool fast = __all(bb.size - bb.pos >= 16 * 12 + 24);
-                if (fast && narrow && (nt & 0x80)) {
+                if (fast && !narrow && (nt & 0x80)) {
+                    // the same for a tile whose lines are int16 (some other block of some frame has a long code): the table gives
+                    // the 16-bit value, two of them make a line word
+                    const uint32_t off0 = bb.off, rd0 = bb.rd;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) {
+                        bb_refill(bb, ring);
+                        const uint64_t win = ((uint64_t)bb.hi << 32) | bb.lo;
+                        uint32_t e[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            const uint32_t idx = (uint32_t)((win << bb.off) >> 60);
+                            const uint32_t t = __builtin_amdgcn_ubfe(mw[q], 8 * j + 4, 4), bits = __builtin_amdgcn_ubfe(mw[q], 8 * j, 4);
+                            e[j] = lut16[(t << 3) + idx];
+                            bb.off += bits - (idx < t ? 1u : 0u);
+                        }
+                        ostage[((blk & 1) * 8 + 2 * q) * OST + lane] = e[0] | (e[1] << 16);
+                        ostage[((blk & 1) * 8 + 2 * q + 1) * OST + lane] = e[2] | (e[3] << 16);
+                    }
+                    bb.pos += (int)(bb.off - off0) + 32 * (int)(bb.rd - rd0);
+                    if ((blk & 1) || blk + 1 == nblk)
+                        pend.set_qc(HCA_QC_ROW(C, sf, c) + (blk >> 1) * HCA_QC_QUARTER, (blk & 1) ? 16 : 8);
+                } else if (fast && narrow && (nt & 0x80)) {
                     // every code of the block has at most four bits, in all 64 frames.  Length of a symbol = bits - (next four
                     // bits < T): shift, compare, add-with-carry is all the next symbol waits for; the value byte comes from
                     // the table whenever it comes.  The window needs a refill only every four symbols (<= 16 bits).
