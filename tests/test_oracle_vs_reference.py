@@ -292,3 +292,23 @@ def test_adx_bitdepth_1_decode():
     for args in ((255, 1, 2, 3, 1), (255, 1, 24, 2, 2), (160, 1, 8, 2, 3), (255, 1, 40, 1, 4), (18, 4, 2, 5, 5), (10, 2, 3, 4, 6)):
         a = r2.forge_adx_bitdepth(*args)
         assert both(lambda: O.adx_decode(a), lambda: R.adx_decode(a)) is not None, args
+
+
+def test_sfa_adx_golden_is_what_the_reference_generator_writes():
+    """tests/golden/sfa_adx.json (the vectors the GPU test holds sfa_chunks(..., "adx") to) re-derived here from the reference's
+    own generator, usm.py:584-657, driven through the stand-in stream objects of make_golden_sfa_adx.py."""
+    import importlib.util
+    import json
+    import os
+    import golden_util as G
+    spec = importlib.util.spec_from_file_location("make_golden_sfa_adx", os.path.join(G.GOLDEN, "make_golden_sfa_adx.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    with open(os.path.join(G.GOLDEN, "sfa_adx.json")) as f:
+        gold = json.load(f)
+    for c in gold["cases"]:
+        adx = G.load(c["file"])
+        (chunks,) = m.reference_chunks([adx], key=c["key"] if c["key"] else False, encrypt_audio=bool(c["key"]))
+        assert [G.sha(x) for x in chunks] == [y["sha"] for y in c["chunks"]], c["file"]
+    lists = m.reference_chunks([G.load(f) for f in gold["multi"]["files"]])
+    assert [G.sha(b"".join(l)) for l in lists] == gold["multi"]["all_sha"]
