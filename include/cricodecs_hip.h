@@ -116,7 +116,7 @@ typedef struct cri_adx_encode_params {
  * is.  offsets[n+1] places the items in the DEVICE input handed to cri_job_run (item i at offsets[i], offsets[n] = its size;
  * offsets[i+1] - offsets[i] >= lens[i], e.g. the 64-byte aligned output offsets of the job that produced them); NULL =
  * packed back to back.  cri_job_input_offsets() returns the layout either way.  Host data is only read while the job is
- * created (headers); cri_job_run_host* need the blob form. */
+ * created (headers) and by cri_job_run_host_items. */
 typedef struct cri_items { const uint8_t* const* ptrs; const uint64_t* lens; const uint64_t* offsets; uint32_t n; } cri_items;
 
 /* keys / subkeys: per-item arrays, or NULL for all-zero. */
@@ -212,6 +212,9 @@ int cri_job_run_floats(cri_job* job, const void* d_in, void* d_out, void* d_scra
 typedef struct cri_hca_group_info {
     uint32_t channels, frames, record_bytes, flags_offset, narrow_flag, narrow_capable, plain, pad;
     uint64_t first_record_offset;
+    uint64_t lines_offset;        /* the group's quantised lines, tile-major (64 frames per tile) */
+    uint64_t code_desc_offset;    /* the group's band code descriptions: [tile][channel][block 8][frame 64][band 16] bytes, low nibble =
+                                     most bits a symbol of that band can take (0: the band carries no bits) */
 } cri_hca_group_info;
 int cri_job_hca_groups(const cri_job* job, cri_hca_group_info* out, int cap);
 
@@ -227,12 +230,26 @@ int cri_job_event_ms(cri_job* job, float* ms, const char** names, int max_classe
 
 void cri_job_destroy(cri_job* job);
 
-/* Host-buffer convenience wrapper over a job: upload, run, download.  out_blob/out_offsets are malloc'ed
- * (cri_free); status[n] is caller-provided.  kind-specific arguments are passed through `job`. */
+/* Host buffers in, host buffers out: upload, run, download -- what the five single-file entry points do for one item,
+ * for a whole job.  Replaces the per-file host loops of the reference's callers (hca.py:250, adx.py, awb.py:54-88).
+ *   cri_job_run_host        `blob` laid out like the device input (cri_job_input_offsets()): for a job created from one
+ *                           blob, that blob.  *out_blob is malloc'ed (cri_free); status[n] is caller-provided.
+ *   cri_job_run_host_into   the same into a caller-owned buffer of cri_job_output_bytes(job) bytes (reuse it across calls: a
+ *                           fresh allocation of that size costs more in page faults than the copy itself).  A job created
+ *                           from a cri_items list WITH caller offsets has no blob form: CRI_ERR_INVALID_ARG, use the next one.
+ *   cri_job_run_host_items  for a job created from a cri_items list: every item is uploaded from its own host buffer
+ *                           (`items`: the same n items with the same lengths; its offsets are ignored).
+ * The library keeps, per device, the device buffers of the last host call (up to 512 MB; larger ones are released when the
+ * call returns) and private streams: these calls allocate nothing in the steady state and wait for their own stream only.
+ * Large single-format HCA decode jobs run pipelined -- upload, kernels and download of successive slices overlap; with
+ * page-locked host memory (cri_pinned_alloc, or memory the caller registered with the HIP runtime) all PCIe copies are
+ * asynchronous DMA.  cri_release_cache drops what is kept for the calling thread's current device. */
 int cri_job_run_host(cri_job* job, const uint8_t* blob, uint8_t** out_blob, int32_t* status);
-/* the same into a caller-owned buffer of cri_job_output_bytes(job) bytes (reuse it across calls: a fresh allocation of that
- * size costs more in page faults than the copy itself) */
 int cri_job_run_host_into(cri_job* job, const uint8_t* blob, uint8_t* out, int32_t* status);
+int cri_job_run_host_items(cri_job* job, const cri_items* items, uint8_t* out, int32_t* status);
+void* cri_pinned_alloc(size_t bytes);   /* NULL without a device / on failure */
+void cri_pinned_free(void* p);
+void cri_release_cache(void);
 
 #ifdef __cplusplus
 }

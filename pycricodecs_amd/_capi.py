@@ -24,7 +24,7 @@ SYMBOLS = [
     "cri_job_create_hca_decode_items", "cri_job_create_adx_decode_items", "cri_job_create_adx_encode_items",
     "cri_job_create_hca_encode_items", "cri_job_create_hca_crypt_items", "cri_job_input_offsets", "cri_device_count", "cri_set_device", "cri_get_device", "cri_job_device", "cri_job_run_floats", "cri_job_float_count", "cri_job_float_offsets",
     "cri_usm_audio_mask", "cri_usm_index", "cri_job_create_usm_audio_demux", "cri_job_create_sfa_pack", "cri_job_item_tags", "cri_job_item_sizes",
-    "cri_job_hca_groups",
+    "cri_job_hca_groups", "cri_job_run_host_items", "cri_pinned_alloc", "cri_pinned_free", "cri_release_cache",
 ]
 
 
@@ -36,7 +36,7 @@ class UsmChunk(C.Structure):
 
 class HcaGroupInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("channels", "frames", "record_bytes", "flags_offset", "narrow_flag", "narrow_capable", "plain", "pad")] + \
-               [("first_record_offset", C.c_uint64)]
+               [("first_record_offset", C.c_uint64), ("lines_offset", C.c_uint64), ("code_desc_offset", C.c_uint64)]
 
 
 class AdxEncodeParams(C.Structure):
@@ -101,6 +101,13 @@ def lib():
     L.cri_job_float_offsets.restype = u64p
     L.cri_job_run_host.argtypes = [vp, vp, C.POINTER(u8p), i32p]
     L.cri_job_run_host_into.argtypes = [vp, vp, vp, i32p]
+    L.cri_job_run_host_items.argtypes = [vp, vp, vp, i32p]
+    L.cri_pinned_alloc.argtypes = [C.c_size_t]
+    L.cri_pinned_alloc.restype = vp
+    L.cri_pinned_free.argtypes = [vp]
+    L.cri_pinned_free.restype = None
+    L.cri_release_cache.argtypes = []
+    L.cri_release_cache.restype = None
     L.cri_job_enable_events.argtypes = [vp, C.c_int]
     L.cri_job_event_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int]
     L.cri_job_destroy.argtypes = [vp]

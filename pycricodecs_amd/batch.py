@@ -44,6 +44,35 @@ def items_struct(items, offsets=None):
     return st, (ptrs, lens, keep, offs, items)
 
 
+class _Pinned:
+    def __init__(self, nbytes):
+        self.ptr = _capi.lib().cri_pinned_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise MemoryError("cri_pinned_alloc(%d)" % nbytes)
+
+    def __del__(self):
+        try:
+            _capi.lib().cri_pinned_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_array(nbytes):
+    """uint8 numpy array over page-locked host memory (cri_pinned_alloc): PCIe copies to / from it are asynchronous DMA."""
+    owner = _Pinned(nbytes)
+    arr = np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 1)).from_address(owner.ptr))
+    arr = arr[:max(int(nbytes), 1)]
+    _PINNED_OWNERS[arr.ctypes.data] = owner
+    return arr
+
+
+_PINNED_OWNERS = {}
+
+
+def pinned_release(arr):
+    _PINNED_OWNERS.pop(arr.ctypes.data, None)
+
+
 class Job:
     """Owns a cri_job.  Create with one of the classmethods; `run()` enqueues it on torch's current stream.
     Batches are handed to the library item by item (cri_items): a list that repeats the same bytes object costs no host copy."""
@@ -266,18 +295,27 @@ class Job:
         n = _capi.lib().cri_job_event_ms(self._h, ms, names, 4)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
-    def run_host(self):
+    def run_host(self, out=None):
         """Upload, run, download: returns (list of outputs per item, status int32[n]).  The outputs are memoryviews into one
-        buffer owned by this Job and reused by its next run_host() call (copy what must outlive it with bytes(...))."""
+        buffer owned by this Job and reused by its next run_host() call (copy what must outlive it with bytes(...)), or into
+        `out` (a uint8 numpy array of at least output_bytes, e.g. pinned_array()).  A job made from an item list uploads every
+        item from its own bytes object (cri_job_run_host_items): no joined copy of the batch is made on the host."""
         n = max(self.output_bytes, 1)
-        if getattr(self, "_host_out", None) is None or self._host_out.size < n:
-            self._host_out = np.empty(n, dtype=np.uint8)
+        if out is None:
+            if getattr(self, "_host_out", None) is None or self._host_out.size < n:
+                self._host_out = np.empty(n, dtype=np.uint8)
+            out = self._host_out
+        assert out.dtype == np.uint8 and out.size >= n and out.flags["C_CONTIGUOUS"]
         status = (C.c_int32 * max(self.n, 1))()
-        blob = self.blob
-        rc = _capi.lib().cri_job_run_host_into(self._h, blob if blob else b"\0", self._host_out.ctypes.data, status)
+        if self.items is not None:
+            st, keep = items_struct(self.items)
+            rc = _capi.lib().cri_job_run_host_items(self._h, C.byref(st), out.ctypes.data, status)
+        else:
+            blob = self.blob
+            rc = _capi.lib().cri_job_run_host_into(self._h, blob if blob else b"\0", out.ctypes.data, status)
         if rc:
             _capi.raise_for(rc)
-        return self.split(memoryview(self._host_out)), np.array(status[:self.n], dtype=np.int32)
+        return self.split(memoryview(out)), np.array(status[:self.n], dtype=np.int32)
 
     def item_length(self, blob, i):
         """True byte length of output item i (offsets are 64-byte aligned, so the item carries its own size)."""

@@ -22,18 +22,67 @@ using namespace cri;
 
 namespace {
 
+// Job metadata (stream tables, cipher / ATH tables, header images ...) is staged on the host while a job is planned and goes
+// to the device as ONE allocation and ONE copy (MetaPool::commit): a single-file call used to pay eight hipMalloc + hipMemcpy
+// pairs and as many hipFree (each a device-wide wait).  Small allocations are recycled through a per-device cache.
+struct DevBuf;
+struct MetaPool {
+    std::vector<uint8_t> host; void* dev = nullptr; size_t cap = 0; int device = -1;
+    std::vector<DevBuf*> bufs;
+    int commit();
+    ~MetaPool();
+};
 struct DevBuf {
-    void* p = nullptr; size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    void* p = nullptr; size_t n = 0, off = 0; MetaPool* pool = nullptr;
     int upload(const void* src, size_t bytes) {
         n = bytes;
         if (!bytes) return 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return CRI_ERR_HIP; }
-        if (hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return CRI_ERR_HIP;
+        off = (pool->host.size() + 255) & ~(size_t)255;
+        pool->host.resize(off + bytes);
+        memcpy(pool->host.data() + off, src, bytes);
+        pool->bufs.push_back(this);
         return 0;
     }
     template <class T> int upload(const std::vector<T>& v) { return upload(v.data(), v.size() * sizeof(T)); }
 };
+struct MetaCache {                                            // recycled metadata allocations of one device (each at most 4 MB)
+    std::mutex mu; std::vector<std::pair<void*, size_t>> free_list;
+};
+static std::mutex g_meta_mu;
+static std::map<int, MetaCache*> g_meta_caches;
+static MetaCache* meta_cache_of(int device) {
+    std::lock_guard<std::mutex> lk(g_meta_mu);
+    auto it = g_meta_caches.find(device);
+    if (it == g_meta_caches.end()) it = g_meta_caches.emplace(device, new MetaCache()).first;
+    return it->second;
+}
+int MetaPool::commit() {
+    if (host.empty()) return 0;
+    const size_t need = host.size();
+    if (need <= (4u << 20)) {
+        MetaCache* c = meta_cache_of(device);
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (size_t k = 0; k < c->free_list.size(); k++)
+            if (c->free_list[k].second >= need) { dev = c->free_list[k].first; cap = c->free_list[k].second; c->free_list.erase(c->free_list.begin() + k); break; }
+    }
+    if (!dev) {
+        cap = need <= (4u << 20) ? ((need + 65535) & ~(size_t)65535) : need;
+        if (hipMalloc(&dev, cap) != hipSuccess) { dev = nullptr; return CRI_ERR_HIP; }
+    }
+    if (hipMemcpy(dev, host.data(), need, hipMemcpyHostToDevice) != hipSuccess) return CRI_ERR_HIP;
+    for (DevBuf* b : bufs) b->p = (uint8_t*)dev + b->off;
+    std::vector<uint8_t>().swap(host);
+    return 0;
+}
+MetaPool::~MetaPool() {
+    if (!dev) return;
+    if (cap <= (4u << 20)) {
+        MetaCache* c = meta_cache_of(device);
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->free_list.size() < 8) { c->free_list.emplace_back(dev, cap); return; }
+    }
+    (void)hipFree(dev);
+}
 
 struct Image { uint64_t dst; std::vector<uint8_t> bytes; };
 
@@ -44,13 +93,21 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 struct cri_job {
     uint32_t kind = 0, n = 0;
     int device = -1;                             // HIP device the job's metadata lives on (current device of the creating thread)
+    bool items_form = false;                     // created from a cri_items list (not one host blob) ...
+    bool items_packed = true;                    // ... whose device layout is the items back to back (no caller offsets)
+    std::vector<HcaStream> hca_streams_host;     // HCA decode: the sorted stream table (the pipelined host path slices it)
     std::vector<uint64_t> in_offsets, out_offsets;
     std::vector<int32_t> host_status;
     uint64_t in_bytes = 0, out_bytes = 0, scratch_bytes = 0, units = 0, units2 = 0, alg_bytes = 0;
     std::string dominant;
-    // device metadata
+    // device metadata (one allocation: MetaPool)
+    MetaPool meta;
     DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
-        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert;
+        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert, d_segs, d_crcmul, d_seg_chain;
+    cri_job() {
+        for (DevBuf* b : {&d_formats, &d_streams, &d_cipher, &d_ath, &d_img, &d_img_off, &d_img_dst, &d_chain_stream, &d_history, &d_stale,
+                          &d_frame_sizes, &d_first_frame, &d_adx_streams, &d_adx_order, &d_crc_off, &d_convert, &d_segs, &d_crcmul, &d_seg_chain}) b->pool = &meta;
+    }
     std::vector<ConvertItem> convert;            // WAV items whose samples are converted to PCM16 in scratch before encoding
     uint64_t convert_total = 0;
     // registers item data for conversion; returns the scratch offset its PCM16 will be at
@@ -71,14 +128,12 @@ struct cri_job {
     bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
     CryptArgs crypt{};
     SegmentArgs seg{};                           // USM demux / SFA pack: segment copies (+ audio mask)
-    DevBuf d_segs;
     std::vector<uint32_t> item_tags;
     std::vector<uint64_t> item_sizes;             // true byte length of every output item (jobs whose items carry no length of their own)
     std::vector<uint64_t> float_offsets;          // HCA decode: n + 1 offsets (in floats) of the items in the validation output
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
     std::vector<HcaEncArgs> hca_enc;
     std::vector<uint32_t> hca_enc_crc_off;       // per launch: offset into d_crcmul
-    DevBuf d_crcmul;
     uint32_t n_cipher = 0;
     // optional per-kernel-class event timing
     bool events_on = false;
@@ -135,10 +190,14 @@ extern "C" int cri_get_device(void) {
 }
 namespace {
 struct DeviceGuard {
-    int prev = -1; bool switched = false;
+    int prev = -1; bool switched = false, good = false;
     explicit DeviceGuard(int device) {
-        if (device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+        if (device < 0 || hipGetDevice(&prev) != hipSuccess) return;        // a job without a device never runs
+        if (prev == device) { good = true; return; }
+        switched = hipSetDevice(device) == hipSuccess;
+        good = switched;
     }
+    bool ok() const { return good; }                                          // false: the calling thread is NOT on the job's device
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 }  // namespace
@@ -230,16 +289,22 @@ struct ItemSrc {
 };
 
 static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess || device < 0) return nullptr;    // (callers return CRI_ERR_HIP)
     cri_job* j = new cri_job();
     j->kind = kind; j->n = n;
-    if (hipGetDevice(&j->device) != hipSuccess) j->device = -1;
+    j->device = device; j->meta.device = device;
     j->in_offsets.assign(offsets, offsets + n + 1);
     j->in_bytes = offsets[n];
     j->host_status.assign(n, 0);
     j->out_offsets.assign(n + 1, 0);
     return j;
 }
-static cri_job* new_job(uint32_t kind, const ItemSrc& it) { return new_job(kind, it.offsets, it.n); }
+static cri_job* new_job(uint32_t kind, const ItemSrc& it) {
+    cri_job* j = new_job(kind, it.offsets, it.n);
+    if (j) { j->items_form = it.ptrs != nullptr; j->items_packed = it.ptrs == nullptr || !it.packed.empty(); }
+    return j;
+}
 
 // ------------------------------------------------------------------------------------------------ HCA decode
 static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint16_t* subkeys,
@@ -248,6 +313,7 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
     if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_HCA_DECODE, it);
+    if (!j) return CRI_ERR_HIP;
     j->dominant = "k_hca_transform";
     std::vector<HcaFormat> formats; std::vector<HcaStream> streams;
     std::vector<uint8_t> cipher, ath(128, 0);
@@ -350,7 +416,9 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
         a.inlane = (!a.plain && !a.noise_fill && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) ? 1 : 0;
+        if (a.inlane && getenv("CRI_NO_INLANE")) a.inlane = 0;             // (developer switch: the general transform instead)
         if (a.channels == 4 && a.inlane && !a.noise_fill) a.narrow = 1;
+        if (a.channels == 4 && !a.inlane && !a.plain) a.narrow = 0;         // k_hca_transform<false, 4> reads int16 lines only
         j->hca_dec.push_back(a);
         j->hca_group_first_record.push_back(streams[b].scratch_offset);
         b = e;
@@ -370,6 +438,8 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
     if (cipher.empty()) cipher.assign(256, 0);
     if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_cipher.upload(cipher)) ||
         (rc = j->d_ath.upload(ath)) || (rc = j->upload_images())) { delete j; return rc; }
+    j->hca_streams_host = streams;
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -459,6 +529,7 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
     if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_ADX_DECODE, it);
+    if (!j) return CRI_ERR_HIP;
     j->dominant = "k_adx_decode";
     std::vector<AdxStream> streams, pend; std::vector<uint32_t> chain_stream; std::vector<int16_t> history, pend_hist;
     AdxWavePlan plan;
@@ -521,6 +592,7 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
         (!order.empty() && (rc = j->d_adx_order.upload(order))) || (rc = j->upload_images())) { delete j; return rc; }
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -707,6 +779,7 @@ extern "C" int cri_job_create_usm_audio_demux(const uint8_t* usm, size_t len, ui
     std::vector<uint64_t> in_off(n + 1, 0);
     for (uint32_t i = 0; i <= n; i++) in_off[i] = i == n ? (uint64_t)len : 0;          // every item reads the one container
     cri_job* j = new_job(CRI_JOB_USM_DEMUX, in_off.data(), n);
+    if (!j) return CRI_ERR_HIP;
     j->in_bytes = len;
     std::vector<uint64_t> size(n, 0);
     std::vector<uint32_t> codec(n, 0);
@@ -754,6 +827,7 @@ extern "C" int cri_job_create_usm_audio_demux(const uint8_t* usm, size_t len, ui
     cri_usm_audio_mask(key, mask);
     rc = upload_segments(j, segs, mask);
     if (rc) { delete j; return rc; }
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -774,6 +848,7 @@ extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offs
     const ItemSrc it = ItemSrc::from_blob(blob, offsets, n);
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_SFA_PACK, it);
+    if (!j) return CRI_ERR_HIP;
     std::vector<Segment> segs;
     uint64_t out_pos = 0;
     std::vector<uint8_t> hdr;
@@ -856,6 +931,7 @@ extern "C" int cri_job_create_sfa_pack(const uint8_t* blob, const uint64_t* offs
     int rc = j->upload_images();
     if (!rc) rc = upload_segments(j, segs, mask);
     if (rc) { delete j; return rc; }
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -869,6 +945,7 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     if (!it.ok() || !out || !p) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_ADX_ENCODE, it);
+    if (!j) return CRI_ERR_HIP;
     j->dominant = "k_adx_encode";
     std::vector<AdxStream> streams; std::vector<uint32_t> chain_stream; std::vector<int16_t> history; std::vector<uint8_t> stale;
     AdxWavePlan plan;
@@ -928,6 +1005,7 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
         (!order.empty() && (rc = j->d_adx_order.upload(order))) ||
         (rc = j->d_stale.upload(stale)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -949,6 +1027,7 @@ static int create_hca_crypt(const ItemSrc& it, uint32_t encrypt, uint32_t type, 
     if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_HCA_CRYPT, it);
+    if (!j) return CRI_ERR_HIP;
     j->dominant = "k_hca_crypt";
     std::vector<HcaStream> streams; std::vector<uint32_t> frame_sizes, first_frame{0}; std::vector<uint8_t> cipher;
     std::map<std::tuple<uint32_t, uint64_t, uint32_t>, uint32_t> cipher_index;
@@ -1011,6 +1090,7 @@ static int create_hca_crypt(const ItemSrc& it, uint32_t encrypt, uint32_t type, 
     if ((rc = j->d_streams.upload(streams)) || (rc = j->d_frame_sizes.upload(frame_sizes)) || (rc = j->d_first_frame.upload(first_frame)) ||
         (rc = j->d_crcmul.upload(crcpos)) || (rc = j->d_crc_off.upload(crc_off)) ||
         (rc = j->d_cipher.upload(cipher)) || (rc = j->upload_images())) { delete j; return rc; }
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -1036,6 +1116,7 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
     if (!it.ok() || !out) return CRI_ERR_INVALID_ARG;
     if (!cri_device_available()) return CRI_ERR_HIP;
     cri_job* j = new_job(CRI_JOB_HCA_ENCODE, it);
+    if (!j) return CRI_ERR_HIP;
     j->dominant = "k_hca_encode";
     std::vector<HcaFormat> formats; std::vector<HcaStream> streams;
     std::map<std::vector<uint32_t>, uint32_t> fmt_index;
@@ -1111,6 +1192,7 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
     if (crcmul.empty()) crcmul.assign(1024, 0);
     int rc = 0;
     if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
+    if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
 }
@@ -1129,6 +1211,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
     if (!j || !d_in || (!d_out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
     if (j->scratch_bytes && !d_scratch) return CRI_ERR_INVALID_ARG;
     DeviceGuard guard(j->device);                // the caller's buffers and stream must belong to the job's device
+    if (!guard.ok()) return CRI_ERR_HIP;
     hipStream_t s = (hipStream_t)hip_stream;
     if (j->events_on) j->begin_run();
     if (d_status) launch_fill_i32(d_status, 0, j->n, s);
@@ -1216,6 +1299,7 @@ extern "C" int cri_job_hca_groups(const cri_job* j, cri_hca_group_info* out, int
             g.channels = a.channels; g.frames = a.frames; g.record_bytes = hca_record_bytes(a.channels);
             g.flags_offset = HCA_REC_TAIL(a.channels) + 8; g.narrow_flag = HCA_REC_NARROW; g.narrow_capable = a.narrow;
             g.plain = a.plain; g.first_record_offset = j->hca_group_first_record[n];
+            g.lines_offset = a.qc_offset; g.code_desc_offset = a.resg_offset;
             out[n] = g;
         }
         n++;
@@ -1238,6 +1322,7 @@ extern "C" int cri_job_enable_events(cri_job* j, int on) {
 extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int max_classes) {
     if (!j || !ms) return CRI_ERR_INVALID_ARG;
     DeviceGuard guard(j->device);
+    if (!guard.ok()) return CRI_ERR_HIP;
     int n = (int)j->class_names.size();
     for (int c = 0; c < n && c < max_classes; c++) {
         float total = 0.f;
@@ -1252,32 +1337,203 @@ extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int m
     return n;
 }
 
-// Host buffers in, host buffers out: device allocations, H2D, the job, D2H.  `out` must hold cri_job_output_bytes(job).
-extern "C" int cri_job_run_host_into(cri_job* j, const uint8_t* blob, uint8_t* out, int32_t* status) {
-    if (!j || !blob || (!out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
+// ------------------------------------------------------------------------------------------------ host buffers in and out
+// What a caller with host memory pays besides the kernels: device allocations, two PCIe crossings, a wait.  The host entry
+// points keep, per device, an ARENA -- the four device buffers of the last call (grown on demand, released again when a call
+// leaves more than HOST_ARENA_KEEP behind: a 40 GB batch should not stay resident because it ran once) and three private,
+// non-blocking streams -- so a single-file call allocates nothing, waits for its own stream only (never hipDeviceSynchronize:
+// the host's other streams are not this library's business) and copies its result straight into the buffer it returns.
+// Large HCA decode jobs run PIPELINED: the group is cut into slices of whole parse tiles; slice k's input bytes go up on the
+// upload stream while slice k-1 is parsed and transformed on the run stream and slice k-2's PCM comes down on the download
+// stream (events order the three).  With pinned host memory (cri_pinned_alloc, or memory the caller registered) the copies
+// are asynchronous DMA and the three overlap fully; with pageable memory the runtime stages the copies on the calling thread,
+// which still overlaps them with the kernels and with the downloads already queued.
+namespace {
+const size_t HOST_ARENA_KEEP = 512ull << 20;
+struct HostArena {
+    std::mutex mu;
+    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
+    void* buf[4] = {nullptr, nullptr, nullptr, nullptr};       // in, out, scratch, status
+    size_t cap[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> events;
+    bool streams_ok() {
+        if (s_run) return true;
+        return hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking) == hipSuccess &&
+               hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking) == hipSuccess;
+    }
+    bool ensure(int k, size_t need) {
+        if (need < 256) need = 256;
+        if (cap[k] >= need) return true;
+        if (buf[k]) { (void)hipFree(buf[k]); buf[k] = nullptr; cap[k] = 0; }
+        const size_t want = need < (64u << 20) ? ((need * 3 / 2 + 4095) & ~(size_t)4095) : need;    // small buffers grow with slack
+        if (hipMalloc(&buf[k], want) != hipSuccess) { buf[k] = nullptr; return false; }
+        cap[k] = want;
+        return true;
+    }
+    hipEvent_t event(size_t i) {
+        while (events.size() <= i) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr; events.push_back(e); }
+        return events[i];
+    }
+    void release_buffers() { for (int k = 0; k < 4; k++) { if (buf[k]) (void)hipFree(buf[k]); buf[k] = nullptr; cap[k] = 0; } }
+    void trim() { if (cap[0] + cap[1] + cap[2] + cap[3] > HOST_ARENA_KEEP) release_buffers(); }
+    void destroy() {
+        release_buffers();
+        for (auto e : events) (void)hipEventDestroy(e);
+        events.clear();
+        if (s_up) (void)hipStreamDestroy(s_up);
+        if (s_run) (void)hipStreamDestroy(s_run);
+        if (s_down) (void)hipStreamDestroy(s_down);
+        s_up = s_run = s_down = nullptr;
+    }
+};
+std::mutex g_arena_mu;
+std::map<int, HostArena*> g_arenas;                            // per device; never destroyed at exit (the HIP runtime may be gone by then)
+HostArena* arena_of(int device) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    auto it = g_arenas.find(device);
+    if (it == g_arenas.end()) it = g_arenas.emplace(device, new HostArena()).first;
+    return it->second;
+}
+
+// where the input bytes come from: one host blob laid out like the device input, or the items' own host buffers
+struct HostSrc { const uint8_t* blob = nullptr; const cri_items* items = nullptr; };
+
+// uploads device-input bytes [lo, hi) on stream s
+int upload_range(const cri_job* j, const HostSrc& src, uint8_t* d_in, uint64_t lo, uint64_t hi, uint32_t& item_cursor, hipStream_t s) {
+    if (hi <= lo) return 0;
+    if (src.blob) return hipMemcpyAsync(d_in + lo, src.blob + lo, hi - lo, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : CRI_ERR_HIP;
+    // items: every item that starts inside the range goes up whole (ranges are cut at item starts by the callers)
+    while (item_cursor < j->n && j->in_offsets[item_cursor] < hi) {
+        const uint32_t i = item_cursor++;
+        const uint64_t len = src.items->lens[i];
+        if (len && hipMemcpyAsync(d_in + j->in_offsets[i], src.items->ptrs[i], len, hipMemcpyHostToDevice, s) != hipSuccess) return CRI_ERR_HIP;
+    }
+    return 0;
+}
+
+// A decode job the pipelined path can slice: one format group, on the run-per-wave transforms, streams in item order.
+bool hca_decode_sliceable(const cri_job* j) {
+    if (j->kind != CRI_JOB_HCA_DECODE || j->hca_dec.size() != 1 || j->convert_total) return false;
+    const HcaDecArgs& a = j->hca_dec[0];
+    if (a.noise_fill || !a.frames || !a.runs) return false;
+    const bool in_regs = a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    if (!in_regs) return false;
+    const auto& S = j->hca_streams_host;
+    if (S.size() != (size_t)(a.stream_end - a.stream_begin)) return false;
+    for (size_t k = 1; k < S.size(); k++) if (S[k].item <= S[k - 1].item) return false;
+    return true;
+}
+
+int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_copy, int32_t* status) {
     DeviceGuard guard(j->device);
-    void *d_in = nullptr, *d_out = nullptr, *d_scr = nullptr; int32_t* d_st = nullptr;
+    if (!guard.ok()) return CRI_ERR_HIP;
+    HostArena* shared = arena_of(j->device);
+    HostArena own;                                             // a second thread on the same device does not wait for the first: it
+    std::unique_lock<std::mutex> lk(shared->mu, std::try_to_lock);   // works with buffers and streams of its own for this call
+    HostArena& A = lk.owns_lock() ? *shared : own;
     int rc = 0;
     auto ok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = CRI_ERR_HIP; return e == hipSuccess; };
-    if (ok(hipMalloc(&d_in, j->in_bytes ? j->in_bytes : 1)) && ok(hipMalloc(&d_out, j->out_bytes ? j->out_bytes : 1)) &&
-        ok(hipMalloc(&d_scr, j->scratch_bytes ? j->scratch_bytes : 1)) && ok(hipMalloc((void**)&d_st, (j->n ? j->n : 1) * sizeof(int32_t)))) {
-        ok(hipMemcpy(d_in, blob, j->in_bytes, hipMemcpyHostToDevice));
-        // bytes no kernel writes (alignment gaps, undecoded tails) are defined as zero
-        ok(hipMemsetAsync(d_out, 0, j->out_bytes ? j->out_bytes : 1, nullptr));
-        if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, nullptr);
-        ok(hipDeviceSynchronize());
-        if (j->out_bytes) ok(hipMemcpy(out, d_out, j->out_bytes, hipMemcpyDeviceToHost));
-        if (status) {
-            std::vector<int32_t> st(j->n ? j->n : 1, 0);
-            ok(hipMemcpy(st.data(), d_st, j->n * sizeof(int32_t), hipMemcpyDeviceToHost));
-            for (uint32_t i = 0; i < j->n; i++) status[i] = j->host_status[i] ? j->host_status[i] : st[i];
-        }
+    if (!A.streams_ok() || !A.ensure(0, j->in_bytes) || !A.ensure(1, j->out_bytes) || !A.ensure(2, j->scratch_bytes) || !A.ensure(3, (size_t)(j->n ? j->n : 1) * 4)) {
+        if (&A == &own) own.destroy();
+        return CRI_ERR_HIP;
     }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (d_scr) (void)hipFree(d_scr);
-    if (d_st) (void)hipFree(d_st);
+    uint8_t* d_in = (uint8_t*)A.buf[0]; uint8_t* d_out = (uint8_t*)A.buf[1]; uint8_t* d_scr = (uint8_t*)A.buf[2]; int32_t* d_st = (int32_t*)A.buf[3];
+    if (out_copy > j->out_bytes) out_copy = j->out_bytes;
+    const bool gaps = src.items && j->n && j->in_bytes;       // an items layout may leave bytes between the items: they are defined as zero
+    uint32_t cursor = 0;
+    uint64_t slice_min = 256ull << 20;                       // (CRICODECS_HOST_SLICE_MIN: tests force the pipelined path on small jobs)
+    if (const char* e = getenv("CRICODECS_HOST_SLICE_MIN")) slice_min = strtoull(e, nullptr, 10);
+    const bool sliced = hca_decode_sliceable(j) && out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
+    if (!sliced) {
+        if (gaps && !j->items_packed) ok(hipMemsetAsync(d_in, 0, j->in_bytes, A.s_run));
+        if (!rc) rc = upload_range(j, src, d_in, 0, j->in_bytes, cursor, A.s_run);
+        // bytes no kernel writes (alignment gaps, undecoded tails) are defined as zero
+        if (j->out_bytes) ok(hipMemsetAsync(d_out, 0, j->out_bytes, A.s_run));
+        if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, A.s_run);
+        if (!rc && out_copy) ok(hipMemcpyAsync(out, d_out, out_copy, hipMemcpyDeviceToHost, A.s_run));
+    } else {
+        const HcaDecArgs base = j->hca_dec[0];
+        const auto& S = j->hca_streams_host;
+        const uint32_t tiles = (base.frames + 63) / 64, ns = (uint32_t)S.size();
+        // slices of whole tiles, about 256 MB of PCIe traffic each (at least 4, at most 64)
+        uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) >> 28);
+        K = K < 4 ? 4 : (K > 64 ? 64 : K);
+        if (K > tiles) K = tiles;
+        const uint32_t TS = (tiles + K - 1) / K;
+        if (gaps && !j->items_packed) ok(hipMemsetAsync(d_in, 0, j->in_bytes, A.s_up));
+        ok(hipMemsetAsync(d_out, 0, j->out_bytes, A.s_run));
+        if (d_st) launch_fill_i32(d_st, 0, j->n, A.s_run);
+        if (j->n_images)
+            launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, d_out, A.s_run);
+        uint64_t in_pos = 0, out_pos = 0;
+        uint32_t s_need = 0, s_done = 0, ev = 0;                 // streams whose input is up / whose PCM is down
+        for (uint32_t t0 = 0; t0 < tiles && !rc; t0 += TS) {
+            const uint32_t t1 = t0 + TS < tiles ? t0 + TS : tiles;
+            const uint64_t frames_end = (uint64_t)t1 * 64 < base.frames ? (uint64_t)t1 * 64 : base.frames;
+            // input: every stream that has a frame below frames_end
+            while (s_need < ns && S[s_need].first_frame < frames_end) s_need++;
+            const uint64_t in_end = s_need == ns ? j->in_bytes : j->in_offsets[S[s_need].item];
+            rc = upload_range(j, src, d_in, in_pos, in_end, cursor, A.s_up);
+            in_pos = in_end > in_pos ? in_end : in_pos;
+            hipEvent_t e_up = A.event(ev++), e_run = A.event(ev++);
+            if (!e_up || !e_run) { rc = CRI_ERR_HIP; break; }
+            ok(hipEventRecord(e_up, A.s_up));
+            ok(hipStreamWaitEvent(A.s_run, e_up, 0));
+            HcaDecArgs a = base;
+            a.in = d_in; a.out = d_out; a.scratch = d_scr; a.status = d_st;
+            a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
+            a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p; a.float_out = nullptr;
+            a.tile_begin = t0; a.tile_count = t1 - t0;
+            launch_hca_parse(a, A.s_run);
+            // transform: the streams whose frames are all parsed now
+            uint32_t s_to = s_done;
+            while (s_to < ns && (uint64_t)S[s_to].first_frame + S[s_to].frames <= frames_end) s_to++;
+            if (s_to > s_done) {
+                const uint32_t r0 = S[s_done].first_run, r1 = s_to == ns ? base.runs : S[s_to].first_run;
+                if (r1 > r0) { a.run_begin = r0; a.run_count = r1 - r0; launch_hca_transform(a, A.s_run); }
+                ok(hipEventRecord(e_run, A.s_run));
+                ok(hipStreamWaitEvent(A.s_down, e_run, 0));
+                const uint64_t out_end = s_to == ns ? j->out_bytes : j->out_offsets[S[s_to].item];
+                if (out_end > out_pos) ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, out_end - out_pos, hipMemcpyDeviceToHost, A.s_down));
+                out_pos = out_end > out_pos ? out_end : out_pos;
+                s_done = s_to;
+            }
+        }
+        if (!rc && hipGetLastError() != hipSuccess) rc = CRI_ERR_HIP;
+        if (!rc && out_pos < j->out_bytes) {                       // (streams without frames at the end: their headers only)
+            hipEvent_t e = A.event(ev++);
+            if (e) { ok(hipEventRecord(e, A.s_run)); ok(hipStreamWaitEvent(A.s_down, e, 0)); }
+            ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, j->out_bytes - out_pos, hipMemcpyDeviceToHost, A.s_down));
+        }
+        ok(hipStreamSynchronize(A.s_up));
+        ok(hipStreamSynchronize(A.s_down));
+    }
+    std::vector<int32_t> st(j->n ? j->n : 1, 0);
+    if (status && j->n) ok(hipMemcpyAsync(st.data(), d_st, (size_t)j->n * sizeof(int32_t), hipMemcpyDeviceToHost, A.s_run));
+    ok(hipStreamSynchronize(A.s_run));
+    if (status) for (uint32_t i = 0; i < j->n; i++) status[i] = j->host_status[i] ? j->host_status[i] : st[i];
+    if (&A == &own) own.destroy(); else A.trim();
     return rc;
+}
+}  // namespace
+
+// Host buffers in, host buffers out.  `blob` is laid out like the device input (cri_job_input_offsets): for a job made from
+// one blob, that blob; `out` must hold cri_job_output_bytes(job).
+extern "C" int cri_job_run_host_into(cri_job* j, const uint8_t* blob, uint8_t* out, int32_t* status) {
+    if (!j || !blob || (!out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
+    if (j->items_form && !j->items_packed) return CRI_ERR_INVALID_ARG;        // no blob describes that layout: cri_job_run_host_items
+    HostSrc src; src.blob = blob;
+    return run_host_core(j, src, out, j->out_bytes, status);
+}
+
+// The same for a job made from a cri_items list: every item goes up from its own host buffer to its place in the device input
+// (`items` must describe the same n items, with the lengths the job was created with; its offsets are ignored).
+extern "C" int cri_job_run_host_items(cri_job* j, const cri_items* items, uint8_t* out, int32_t* status) {
+    if (!j || !items || items->n != j->n || (j->n && (!items->ptrs || !items->lens)) || (!out && j->out_bytes)) return CRI_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < j->n; i++)
+        if (items->lens[i] > j->in_offsets[i + 1] - j->in_offsets[i] || (items->lens[i] && !items->ptrs[i])) return CRI_ERR_INVALID_ARG;
+    HostSrc src; src.items = items;
+    return run_host_core(j, src, out, j->out_bytes, status);
 }
 
 extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_blob, int32_t* status) {
@@ -1290,19 +1546,37 @@ extern "C" int cri_job_run_host(cri_job* j, const uint8_t* blob, uint8_t** out_b
     return 0;
 }
 
+// Page-locked host memory for the buffers handed to cri_job_run_host*: with it the PCIe copies are asynchronous DMA.
+extern "C" void* cri_pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!cri_device_available() || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void cri_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// Releases what the host entry points keep between calls on the calling thread's current device (buffers, streams, events).
+extern "C" void cri_release_cache(void) {
+    int d = -1;
+    if (!cri_device_available() || hipGetDevice(&d) != hipSuccess) return;
+    HostArena* A = arena_of(d);
+    std::lock_guard<std::mutex> lk(A->mu);
+    A->destroy();
+}
+
 // ------------------------------------------------------------------------------------------------ single-file entry points
+// (one item: the result is copied from the device straight into the buffer the caller gets -- item_len bytes, not the aligned blob)
 static int run_single(cri_job* j, const uint8_t* in, uint8_t** out, size_t* out_len, size_t item_len) {
     int32_t st = 0;
-    uint8_t* blob = nullptr;
     int rc = j->host_status[0];
-    if (!rc) rc = cri_job_run_host(j, in, &blob, &st);
+    uint8_t* res = nullptr;
+    if (!rc) {
+        res = (uint8_t*)malloc(item_len ? item_len : 1);
+        if (!res) rc = CRI_ERR_NOMEM;
+    }
+    if (!rc) { HostSrc src; src.blob = in; rc = run_host_core(j, src, res, item_len, &st); }
     if (!rc) rc = st;
-    if (rc) { free(blob); cri_job_destroy(j); return rc; }
-    uint8_t* res = (uint8_t*)malloc(item_len ? item_len : 1);
-    if (!res) { free(blob); cri_job_destroy(j); return CRI_ERR_NOMEM; }
-    memcpy(res, blob, item_len);
-    free(blob);
     cri_job_destroy(j);
+    if (rc) { free(res); return rc; }
     *out = res; *out_len = item_len;
     return 0;
 }

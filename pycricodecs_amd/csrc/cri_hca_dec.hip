@@ -403,7 +403,7 @@ template <bool IDENTITY, bool CT_LDS>
 __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const Fmt F = load_fmt(a.formats + a.format);
-    const uint32_t C = F.channels, lane = threadIdx.x, tile = blockIdx.x;
+    const uint32_t C = F.channels, lane = threadIdx.x, tile = blockIdx.x + a.tile_begin;
     uint32_t* ring = (uint32_t*)smem + lane;           // [RING_WORDS + 4][64]
     uint32_t* ostage = (uint32_t*)(smem + (RING_WORDS + 4) * 256);   // [16][OST]
     uint8_t* curve = (uint8_t*)(ostage + 16 * OST);    // 96 bytes reserved
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
 
 void launch_hca_parse(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
-    const dim3 grid((a.frames + 63) / 64), block(64);
+    const dim3 grid(a.tile_count ? a.tile_count : (a.frames + 63) / 64), block(64);
     const size_t lds = hca_parse_lds_bytes(a.cipher_identity ? 0 : a.n_cipher);
     if (a.cipher_identity) hipLaunchKernelGGL((k_hca_parse<true, true>), grid, block, lds, s, a);
     else if (a.n_cipher <= 16) hipLaunchKernelGGL((k_hca_parse<false, true>), grid, block, lds, s, a);
@@ -1377,9 +1377,10 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
 
     // run -> stream, first frame
     uint32_t lo = a.stream_begin, hi = a.stream_end;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t run = blockIdx.x + a.run_begin;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= run) lo = mid; else hi = mid; }
     const HcaStream st = a.streams[lo];
-    const uint32_t f0 = (blockIdx.x - st.first_run) * HCA_RUN;
+    const uint32_t f0 = (run - st.first_run) * HCA_RUN;
     const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
     const uint8_t* rec0 = a.scratch + st.scratch_offset;
 
@@ -1580,9 +1581,10 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     float* scale = (float*)(pcm + 512); float* range = scale + 64; uint8_t* curve = (uint8_t*)(range + 16);   // 80 bytes
 
     uint32_t lo = a.stream_begin, hi = a.stream_end;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= blockIdx.x) lo = mid; else hi = mid; }
+    const uint32_t run = blockIdx.x + a.run_begin;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= run) lo = mid; else hi = mid; }
     const HcaStream st = a.streams[lo];
-    const uint32_t f0 = (blockIdx.x - st.first_run) * HCA_RUN;
+    const uint32_t f0 = (run - st.first_run) * HCA_RUN;
     const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
     const uint8_t* rec0 = a.scratch + st.scratch_offset;
     const uint32_t h = (nf + NG - 1) / NG;                 // frames per group (the last groups may get fewer, or none)
@@ -1967,18 +1969,19 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (in_regs) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
         const bool flt = a.float_out != nullptr;
-#define CRI_LAUNCH_TR(P, CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform<P, CH, true>), dim3(a.runs), dim3(64), lds, s, a); \
-                                  else hipLaunchKernelGGL((k_hca_transform<P, CH, false>), dim3(a.runs), dim3(64), lds, s, a); } while (0)
-#define CRI_LAUNCH_PL(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, false>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); \
-                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, false>), dim3(a.runs), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
-#define CRI_LAUNCH_PJ(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true>), dim3(a.runs), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); \
-                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true>), dim3(a.runs), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); } while (0)
+        const uint32_t nruns = a.run_count ? a.run_count : a.runs;
+#define CRI_LAUNCH_TR(P, CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform<P, CH, true>), dim3(nruns), dim3(64), lds, s, a); \
+                                  else hipLaunchKernelGGL((k_hca_transform<P, CH, false>), dim3(nruns), dim3(64), lds, s, a); } while (0)
+#define CRI_LAUNCH_PL(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, false>), dim3(nruns), dim3(64), HCA_PLAIN_LDS, s, a); \
+                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, false>), dim3(nruns), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
+#define CRI_LAUNCH_PJ(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true>), dim3(nruns), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); \
+                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); } while (0)
         if (a.plain) switch (a.channels) {
             case 1: CRI_LAUNCH_PL(1); break;
             case 2: CRI_LAUNCH_PL(2); break;
             case 4: CRI_LAUNCH_PL(4); break;
             case 6: CRI_LAUNCH_TR(true, 6); break; default: CRI_LAUNCH_TR(true, 8); break;
-        } else if (a.inlane && !getenv("CRI_NO_INLANE")) switch (a.channels) {
+        } else if (a.inlane) switch (a.channels) {
             case 1: CRI_LAUNCH_PJ(1); break; case 2: CRI_LAUNCH_PJ(2); break; default: CRI_LAUNCH_PJ(4); break;
         } else switch (a.channels) {
             case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;

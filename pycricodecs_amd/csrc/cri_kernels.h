@@ -22,6 +22,9 @@ struct HcaDecArgs {
     uint32_t n_cipher;
     uint32_t cipher_identity;      // 1: every stream of the job is unencrypted (one identity table): the intake skips the lookups
     uint32_t pad0;
+    // a launch may cover a slice of the group (the pipelined host path, cri_capi.cpp): tiles [tile_begin, tile_begin + tile_count) of the
+    // parse, runs [run_begin, run_begin + run_count) of the run-per-wave transforms; counts of 0 = the whole group
+    uint32_t tile_begin, tile_count, run_begin, run_count;
     uint32_t channels;             // channel count of this format
     uint32_t plain;                // 1: no HFR and no joint stereo in this format (spectra need dequantisation only)
     uint32_t noise_fill;           // 1: min_resolution == 0 (v3.0): k_hca_noise_scan + noise reconstruction in the transform

@@ -169,3 +169,18 @@ def header_form_streams(hca_encode, wav):
         "v200_ath2": forge_header(q1, version=0x0200, ath=2),
         "v101_dec_ath_only_44_bytes": forge_header(m1, version=0x0101, dec=dict(stereo_type=0), ath=1, ciph=None, pad=False),
     }
+
+
+def frame_size_stream(hca: bytes, frame_size: int, nfr: int, seed: int) -> bytes:
+    """The header of `hca` rewritten to `frame_size` / `nfr` frames of seeded random bytes (sync + CRC in place): material for
+    HcaCrypt, which only walks frames -- frame sizes near 65535 take the crypt kernel that does not stage a frame in LDS."""
+    h = bytearray(forge_header(hca, frame_size=frame_size))
+    hs = struct.unpack(">H", h[6:8])[0]
+    h[0x10:0x14] = struct.pack(">I", nfr)
+    fix_header_crc(h)
+    rng = np.random.default_rng(seed)
+    body = b""
+    for _ in range(nfr):
+        fr = b"\xff\xff" + rng.integers(0, 256, frame_size - 4, dtype=np.uint8).tobytes()
+        body += fr + struct.pack(">H", crc16(fr))
+    return bytes(h[:hs]) + body

@@ -62,3 +62,163 @@ def test_sfa_adx_two_streams_match_reference_generator(cc):
     lists = usm.sfa_chunks([G.load(f) for f in m["files"]], "adx")
     assert [len(l) for l in lists] == m["n_chunks"]
     assert [G.sha(b"".join(l)) for l in lists] == m["all_sha"]
+
+
+# ------------------------------------------------------------------------------------------------ a12 / a37: kernel instances without a test
+def _many_key_streams(n):
+    rng = np.random.default_rng(77)
+    items, keys, subkeys, plain = [], [], [], []
+    for i in range(n):
+        w = synth.wav(800 + i, 1024 * int(rng.integers(2, 7)) + int(rng.integers(0, 900)), 1 + i % 2, 48000)
+        h = O.hca_encode(w, 1 + i % 3)
+        key = int(rng.integers(1, 2**63)) * 2 + 1
+        sub = int(rng.integers(0, 65536)) if i % 3 == 0 else 0
+        plain.append(h)
+        items.append(O.hca_crypt(h, 1, 56, key, sub))
+        keys.append(key)
+        subkeys.append(sub)
+    return items, keys, subkeys, plain
+
+
+def test_hca_decode_more_than_16_cipher_tables(cc):
+    """A decode job whose streams carry 24 distinct keys (and subkeys): past 16 tables the parse kernel reads the cipher tables
+    from global memory instead of an LDS copy -- k_hca_parse<false, false> (cri_hca_dec.hip, launch_hca_parse)."""
+    from pycricodecs_amd.batch import Job
+    items, keys, subkeys, _ = _many_key_streams(24)
+    assert len(set(zip(keys, subkeys))) == 24
+    job = Job.hca_decode(items, keys=keys, subkeys=subkeys)
+    outs, status = run_job(job)
+    assert not status.any() and not job.host_status.any()
+    for i, (o, it) in enumerate(zip(outs, items)):
+        assert bytes(o) == O.hca_decode(it, keys[i], subkeys[i]), i
+    # a wrong key among them: that stream alone does what the oracle does with it (the frame checksum is taken over the
+    # ciphered bytes, hca.cpp:1166-1169, so a wrong key is an unpack error or garbage PCM, not a checksum error)
+    bad = list(keys)
+    bad[5] ^= 0x10
+    job = Job.hca_decode(items, keys=bad, subkeys=subkeys)
+    outs, status = run_job(job)
+    assert not np.delete(status, 5).any()
+    try:
+        want = O.hca_decode(items[5], bad[5], subkeys[5])
+    except O.OracleError:
+        want = None
+    assert (status[5] != 0) == (want is None)
+    if want is not None:
+        assert bytes(outs[5]) == want
+
+
+@pytest.mark.parametrize("encrypt", [1, 0])
+def test_hca_crypt_more_than_16_cipher_tables(cc, encrypt):
+    """HcaCrypt as one job over 24 streams with 24 keys, both directions, against the oracle."""
+    from pycricodecs_amd.batch import Job
+    enc, keys, subkeys, plain = _many_key_streams(24)
+    src = plain if encrypt else enc
+    job = Job.hca_crypt(src, encrypt, 56 if encrypt else 0, keys=keys, subkeys=subkeys)
+    outs, status = run_job(job)
+    assert not status.any() and not job.host_status.any()
+    for i, o in enumerate(outs):
+        assert bytes(o)[:len(src[i])] == O.hca_crypt(src[i], encrypt, 56 if encrypt else 0, keys[i], subkeys[i]), i
+
+
+@pytest.mark.parametrize("fs", [8, 65400, 65535])
+def test_hca_crypt_frames_that_do_not_fit_lds(cc, fs):
+    """Frames near the 16-bit frame-size limit do not fit the wave-per-frame kernel's LDS image: launch_hca_crypt falls back to
+    k_hca_crypt, lane per frame (8-byte frames are the wave-per-frame kernel's lower edge).  Oracle bytes (pinned to the reference for these
+    sizes in tests/test_oracle_vs_reference.py::test_hca_crypt_extreme_frame_sizes), single call and as a job beside
+    ordinary streams."""
+    import hca_forge
+    from pycricodecs_amd.batch import Job
+    base = O.hca_encode(synth.wav(5, 3000, 2, 48000), 1)
+    s = hca_forge.frame_size_stream(base, fs, 3, fs)
+    hs = int.from_bytes(s[6:8], "big")
+    e = cc.HcaCrypt(s, 1, hs, 56, KEY, 0)
+    assert e == O.hca_crypt(s, 1, 56, KEY)
+    assert cc.HcaCrypt(e, 0, hs, 0, KEY, 0) == s
+    assert cc.HcaCrypt(s, 1, hs, 1, 0, 0) == O.hca_crypt(s, 1, 1, 0)
+    job = Job.hca_crypt([base, s, base], 1, 56, keys=[KEY, KEY + 2, 0x1234567])
+    outs, status = run_job(job)
+    assert not status.any()
+    for o, (src, k) in zip(outs, [(base, KEY), (s, KEY + 2), (base, 0x1234567)]):
+        assert bytes(o)[:len(src)] == O.hca_crypt(src, 1, 56, k)
+
+
+# ------------------------------------------------------------------------------------------------ host path (b)
+def _ragged_hca_batch():
+    """HCA streams of ragged lengths (one of them shorter than a frame's delay, i.e. no samples), one rejected header in the
+    middle, repeats of the same bytes object."""
+    rng = np.random.default_rng(5)
+    uniq = [O.hca_crypt(O.hca_encode(synth.wav(300 + k, int(rng.integers(200, 30000)), 2, 48000), 1), 1, 56, KEY) for k in range(9)]
+    items = [uniq[int(k)] for k in rng.integers(0, len(uniq), 70)]
+    items[17] = b"HCA\0" + bytes(200)                           # rejected on the host
+    items[40] = uniq[0][:96]                                    # a header without any frame
+    return uniq, items
+
+
+@pytest.mark.parametrize("slice_min", [None, "0"])
+def test_run_host_equals_device_resident_run(cc, monkeypatch, slice_min):
+    """cri_job_run_host_items (every item from its own host buffer, the arena's private streams; with
+    CRICODECS_HOST_SLICE_MIN=0 the pipelined path: upload / kernels / download of tile slices overlapped) gives the bytes and
+    statuses of the device-resident cri_job_run, and those are the oracle's."""
+    from pycricodecs_amd.batch import Job, pinned_array, pinned_release
+    if slice_min is not None:
+        monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", slice_min)
+    uniq, items = _ragged_hca_batch()
+    job = Job.hca_decode(items, keys=[KEY] * len(items))
+    assert job.host_status[17] != 0
+    want, st_dev = run_job(job)
+    for rep in range(2):                                        # (the second call runs on the cached arena)
+        outs, st = job.run_host()
+        assert (st == np.where(job.host_status != 0, job.host_status, st_dev)).all()
+        for i, (a, b) in enumerate(zip(outs, want)):
+            assert bytes(a) == bytes(b), (rep, i)
+    refs = {id(u): O.hca_decode(u, KEY) for u in uniq}
+    for i, it in enumerate(items):
+        if id(it) in refs:
+            assert bytes(want[i]) == refs[id(it)], i
+    # into page-locked memory
+    buf = pinned_array(job.output_bytes)
+    outs, st = job.run_host(out=buf)
+    for i, (a, b) in enumerate(zip(outs, want)):
+        assert bytes(a) == bytes(b), i
+    del outs
+    pinned_release(buf)
+
+
+def test_run_host_blob_form_and_items_with_offsets(cc):
+    """The blob form (cri_job_run_host_into) on a job made from one blob; a job made from items placed at caller offsets has no
+    blob form (CRI_ERR_INVALID_ARG) and runs through cri_job_run_host_items."""
+    import ctypes as C
+    from pycricodecs_amd import _capi
+    from pycricodecs_amd.batch import Job, pack
+    adx = [O.adx_encode(synth.wav(610 + k, 3200 + 640 * k, 1 + k % 2, 48000)) for k in range(5)]
+    refs = [O.adx_decode(a) for a in adx]
+    blob, offs = pack(adx)
+    h = C.c_void_p()
+    rc = _capi.lib().cri_job_create_adx_decode(blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(adx), C.byref(h))
+    assert rc == 0
+    job = Job(h, blob, offs)
+    outs, st = job.run_host()
+    assert not st.any() and [bytes(o) for o in outs] == refs
+    # items at 256-byte aligned device offsets
+    aligned = np.zeros(len(adx) + 1, dtype=np.uint64)
+    for i, a in enumerate(adx):
+        aligned[i + 1] = (int(aligned[i]) + len(a) + 255) // 256 * 256
+    job2 = Job.adx_decode(adx, offsets=aligned)
+    outs, st = job2.run_host()
+    assert not st.any() and [bytes(o) for o in outs] == refs
+    out = np.empty(max(job2.output_bytes, 1), dtype=np.uint8)
+    status = (C.c_int32 * len(adx))()
+    assert _capi.lib().cri_job_run_host_into(job2._h, blob, out.ctypes.data, status) == -301
+
+
+def test_single_file_calls_reuse_the_arena(cc):
+    """Back-to-back single-file calls of different sizes and kinds (the arena grows, is reused, and cri_release_cache drops it)."""
+    from pycricodecs_amd import _capi
+    for rep in range(3):
+        for n in (320, 48000, 4800, 96000):
+            w = synth.wav(900 + n % 7, n, 2, 48000)
+            a = cc.AdxEncode(w, 4, 18, 3, 500, 0, 4, False)
+            assert a == O.adx_encode(w) and cc.AdxDecode(a) == O.adx_decode(a)
+            h = cc.HcaEncode(w, False, 1)
+            assert h == O.hca_encode(w, 1) and cc.HcaDecode(h, 96, 0, 0) == O.hca_decode(h)
+        _capi.lib().cri_release_cache()

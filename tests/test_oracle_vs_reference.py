@@ -312,3 +312,14 @@ def test_sfa_adx_golden_is_what_the_reference_generator_writes():
         assert [G.sha(x) for x in chunks] == [y["sha"] for y in c["chunks"]], c["file"]
     lists = m.reference_chunks([G.load(f) for f in gold["multi"]["files"]])
     assert [G.sha(b"".join(l)) for l in lists] == gold["multi"]["all_sha"]
+
+
+@pytest.mark.parametrize("fs", [8, 65400, 65535])
+def test_hca_crypt_extreme_frame_sizes(fs):
+    """HcaCrypt over frames of 8 bytes and near the 16-bit limit (the device takes a different kernel for frames that do not fit a
+    wave's LDS): oracle == reference, both directions."""
+    s = hca_forge.frame_size_stream(O.hca_encode(synth.wav(5, 3000, 2, 48000), 1), fs, 3, fs)
+    e = both(lambda: O.hca_crypt(s, 1, 56, KEY), lambda: R.hca_crypt(s, 1, 56, KEY))
+    assert e is not None
+    assert both(lambda: O.hca_crypt(e, 0, 0, KEY), lambda: R.hca_crypt(e, 0, 0, KEY)) == s
+    both(lambda: O.hca_crypt(s, 1, 1, 0), lambda: R.hca_crypt(s, 1, 1, 0))
