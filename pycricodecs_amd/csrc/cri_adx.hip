@@ -697,6 +697,251 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Segmented chains (decode): speculate, verify, repair
+// ------------------------------------------------------------------------------------------------------------
+// The recurrence is serial, but the decoder FORGETS: two decodes of the same blocks from different histories differ by an
+// error that the prediction filter (poles near 0.9 for the standard coefficients) shrinks to a few units within tens of
+// samples, and the floor shifts then merge the two trajectories exactly -- after 400 samples on average for 500 Hz / 48 kHz
+// (coefficients 7400, -3342), practically always within 3000; the time scales with 1 / (4096 - c0 - c1).  Once two decodes
+// hold the same two history samples they are identical for good.  So a file is cut into segments of `seg_rows` block rows and
+//   1. k_adx_seg_decode   every (segment, channel) is a lane: it decodes `warm_rows` rows before its segment from a zero
+//                         history (nothing stored), records the state it arrives with, decodes and stores its segment and
+//                         records the state it ends with.  Segment 0 starts from the header's history: it is exact;
+//   2. k_adx_seg_fix      lane per segment again: if the state the previous segment ended with is not the state this one
+//                         started from, the segment is decoded again from the right state, row by row, until its state equals
+//                         what the speculative pass stored there (from that row on the stored samples are right already).  A
+//                         repair that reaches the segment's end with a different state than recorded flags its chain;
+//   3. k_adx_seg_serial   lane per (file, channel) chain, for flagged chains only (and chains with an end-of-stream marker):
+//                         walks the segments in order from the header history and repairs what is still inconsistent.
+// Every unflagged chain is exact by induction: segment k's samples are the decode from the recorded end state of segment
+// k - 1, and no recorded end state changed.  Flagged chains are exact by construction.  The result never depends on the
+// warm-up length -- only the time does.  One 10 s file becomes some hundred lanes of 150 rows instead of two of 15 000.
+// Standard layout only (blocksize 18, bitdepth 4, modes 2 / 3): a block is 16 code bytes, a row of samples fits registers.
+struct SegLane {
+    AdxStream S; uint32_t ch, k, r0, r1, w0; bool valid;
+    const uint8_t* src; uint8_t* dst; uint32_t rowb;
+};
+__device__ __forceinline__ uint32_t seg_pack(int32_t h1, int32_t h2) { return ((uint32_t)h1 & 0xFFFFu) | ((uint32_t)h2 << 16); }
+__device__ __forceinline__ void seg_unpack(uint32_t s, int32_t& h1, int32_t& h2) { h1 = (int32_t)(int16_t)(s & 0xFFFF); h2 = (int32_t)(int16_t)(s >> 16); }
+__device__ __forceinline__ bool seg_locate(const AdxArgs& a, uint32_t g, SegLane& X) {
+    X.valid = g < a.seg_lanes;
+    uint32_t lo = 0, hi = a.n_streams;
+    const uint32_t gg = X.valid ? g : 0;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.seg_first[mid] <= gg) lo = mid; else hi = mid; }
+    X.S = a.streams[lo];
+    const uint32_t local = gg - X.S.first_seg, C = X.S.channels;
+    X.k = local / C; X.ch = local - X.k * C;
+    if (X.k >= X.S.seg_count) { X.valid = false; X.k = 0; X.ch = 0; }           // (a padding lane: stereo pairs start on even lanes)
+    X.r0 = X.k * X.S.seg_rows;
+    X.r1 = X.r0 + X.S.seg_rows < X.S.frames ? X.r0 + X.S.seg_rows : X.S.frames;
+    X.w0 = X.k == 0 ? 0 : (X.r0 > X.S.warm_rows ? X.r0 - X.S.warm_rows : 0);
+    X.src = a.in + X.S.src_offset; X.dst = a.out + X.S.dst_offset; X.rowb = 18 * C;
+    return X.valid;
+}
+// a block's scale word -> scale and the block's coefficients (adx.cpp:196-203)
+__device__ __forceinline__ void seg_scale(const AdxStream& S, uint32_t word, int32_t& scale, int32_t& c0, int32_t& c1) {
+    if (S.mode == 2) {
+        const uint32_t pred = (word >> 13) & 7;
+        scale = (int32_t)(word & 0x1FFF) + 1;
+        c0 = pred < 4 ? ADX_STATIC_COEFS[pred * 2] : 0;
+        c1 = pred < 4 ? ADX_STATIC_COEFS[pred * 2 + 1] : 0;
+    } else { scale = (int32_t)word + 1; c0 = S.coef0; c1 = S.coef1; }
+}
+__device__ __forceinline__ uint32_t ld_be16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return ((uint32_t)v >> 8) | (((uint32_t)v & 0xFF) << 8); }
+// one block of 32 samples on registers (adx.cpp:204-213); 24-bit multiplies are exact: |code| <= 8, scale <= 2^16,
+// |coefficient| <= 2^13, |history| <= 2^15
+__device__ __forceinline__ void seg_block(const uint4& cw, int32_t scale, int32_t c0, int32_t c1, int32_t& h1, int32_t& h2, int32_t (&s)[32]) {
+    const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t d = w[i >> 2]; const uint32_t sh = 8 * (i & 3);
+        int32_t code = __builtin_amdgcn_sbfe(d, sh + 4, 4);                      // first sample of a byte: the high nibble
+        int32_t v = clamp_sym(__mul24(code, scale) + (__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12), 0x7FFF);
+        h2 = h1; h1 = v; s[2 * i] = v;
+        code = __builtin_amdgcn_sbfe(d, sh, 4);
+        v = clamp_sym(__mul24(code, scale) + (__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12), 0x7FFF);
+        h2 = h1; h1 = v; s[2 * i + 1] = v;
+    }
+}
+// a row's samples to the WAV: sample i of channel ch at ((row * 32 + i) * C + ch) * 2.  Whole rows of mono / stereo files leave
+// as 64 contiguous bytes per lane (stereo: the two lanes of a pair trade halves, so that lane ch stores half ch of the row's
+// 128 interleaved bytes); anything else sample by sample.  `fast` must be the same in both lanes of a stereo pair.
+__device__ __forceinline__ void seg_store_row(const SegLane& X, uint32_t row, const int32_t (&s)[32], bool fast) {
+    const uint32_t C = X.S.channels;
+    if (fast && C <= 2) {
+        uint32_t P[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) P[j] = __builtin_amdgcn_perm((uint32_t)s[2 * j + 1], (uint32_t)s[2 * j], 0x05040100u);
+        uint32_t o[16];
+        if (C == 2) {
+            const bool hi = X.ch != 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t keep = hi ? P[8 + j] : P[j], send = hi ? P[j] : P[8 + j];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // the pair's other lane (lane ^ 1)
+                const uint32_t L = hi ? recv : keep, R = hi ? keep : recv;
+                o[2 * j] = __builtin_amdgcn_perm(R, L, 0x05040100u);
+                o[2 * j + 1] = __builtin_amdgcn_perm(R, L, 0x07060302u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) o[j] = P[j];
+        }
+        uint4* q = (uint4*)(X.dst + ((uint64_t)row * 32 * C + (C == 2 ? X.ch * 32 : 0)) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+        return;
+    }
+    int16_t* q = (int16_t*)X.dst;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint64_t idx = (uint64_t)row * 32 + i;
+        if (idx < X.S.samples) q[idx * C + X.ch] = (int16_t)s[i];
+    }
+}
+// end-of-stream test of a row (adx.cpp:405-406 and the reads past the input): the scale word of the row's FIRST block
+__device__ __forceinline__ bool seg_row_ends(const SegLane& X, uint32_t row) {
+    return row >= X.S.rows_avail || ld_be16(X.src + (uint64_t)row * X.rowb) == 0x8001u;
+}
+
+__global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
+    const uint32_t lane = threadIdx.x, g = blockIdx.x * 64 + lane;
+    SegLane X;
+    seg_locate(a, g, X);
+    const AdxStream& S = X.S;
+    const uint32_t n = X.valid ? X.r1 - X.w0 : 0, chain = S.first_chain + X.ch;
+    int32_t h1 = 0, h2 = 0;
+    if (X.valid && X.k == 0) { h1 = a.history[2 * chain]; h2 = a.history[2 * chain + 1]; }
+    uint32_t spec = seg_pack(h1, h2), stop_row = 0xFFFFFFFFu;
+    bool stopped = false;
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
+    // the next row's bytes are asked for while the current row is decoded
+    uint4 cw = make_uint4(0, 0, 0, 0); uint32_t word = 0; bool ends = true;
+    auto fetch = [&](uint32_t row, bool on) {
+        if (on && row < S.rows_avail) {
+            const uint8_t* p = X.src + (uint64_t)row * X.rowb;
+            ends = ld_be16(p) == 0x8001u;
+            p += X.ch * 18;
+            word = ld_be16(p);
+            __builtin_memcpy(&cw, p + 2, 16);
+        } else ends = true;
+    };
+    fetch(X.w0, n > 0);
+    for (uint32_t t = 0; t < nmax; t++) {
+        const bool act = t < n;
+        const uint32_t row = X.w0 + t;
+        const uint4 ccw = cw; const uint32_t cword = word; const bool cends = ends;
+        fetch(row + 1, act && t + 1 < n && !stopped && !cends);
+        if (act) {
+            if (row == X.r0) spec = seg_pack(h1, h2);
+            if (!stopped && cends) { stopped = true; stop_row = row > X.r0 ? row : X.r0; }
+            int32_t s[32];
+            if (!stopped) {
+                int32_t scale, c0, c1;
+                seg_scale(S, cword, scale, c0, c1);
+                seg_block(ccw, scale, c0, c1, h1, h2, s);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; i++) s[i] = 0;                 // rows never reached decode to silence
+            }
+            if (row >= X.r0) seg_store_row(X, row, s, (uint64_t)(row + 1) * 32 <= S.samples);
+        }
+    }
+    if (X.valid) {
+        uint32_t* rec = a.seg_state + 4 * (uint64_t)g;
+        const uint32_t e = seg_pack(h1, h2);
+        rec[0] = spec; rec[1] = e; rec[2] = e; rec[3] = stop_row;
+        if (stop_row != 0xFFFFFFFFu) atomicOr(&a.seg_flags[chain], 1u);
+    }
+}
+
+// Decodes rows [r0, r_end) of a segment again from (h1, h2), storing them, until the state after a row equals what is stored
+// there (`true`: from that row on the stored samples are this trajectory's already).  Whole rows only can be compared.
+__device__ __forceinline__ bool seg_repair(const SegLane& X, uint32_t r_end, int32_t& h1, int32_t& h2) {
+    const AdxStream& S = X.S;
+    const int16_t* q = (const int16_t*)X.dst;
+    for (uint32_t row = X.r0; row < r_end; row++) {
+        const uint8_t* p = X.src + (uint64_t)row * X.rowb + X.ch * 18;
+        uint4 cw; __builtin_memcpy(&cw, p + 2, 16);
+        int32_t scale, c0, c1;
+        seg_scale(S, ld_be16(p), scale, c0, c1);
+        int32_t s[32];
+        seg_block(cw, scale, c0, c1, h1, h2, s);
+        const bool whole = (uint64_t)(row + 1) * 32 <= S.samples;
+        bool same = false;
+        if (whole) {
+            const uint64_t i31 = ((uint64_t)row * 32 + 31) * S.channels + X.ch, i30 = i31 - S.channels;
+            same = (int32_t)q[i31] == s[31] && (int32_t)q[i30] == s[30];
+        }
+        seg_store_row(X, row, s, false);
+        if (same) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_adx_seg_fix(AdxArgs a) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    SegLane X;
+    if (!seg_locate(a, g, X) || X.k == 0) return;
+    uint32_t* rec = a.seg_state + 4 * (uint64_t)g;
+    const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - X.S.channels) + 1];
+    if (prev_end == rec[0]) return;                                  // the speculation was right
+    int32_t h1, h2;
+    seg_unpack(prev_end, h1, h2);
+    const uint32_t stop_row = rec[3], r_end = stop_row < X.r1 ? stop_row : X.r1;
+    const bool merged = seg_repair(X, r_end, h1, h2);
+    const uint32_t e = seg_pack(h1, h2);
+    if (!merged && e != rec[1]) { rec[2] = e; atomicOr(&a.seg_flags[X.S.first_chain + X.ch], 1u); }   // the next segment started from a stale state
+}
+
+__global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a) {
+    const uint32_t chain = blockIdx.x * 64 + threadIdx.x;
+    if (chain >= a.chains || !a.seg_flags[chain]) return;
+    SegLane X;
+    seg_locate(a, 0, X);                                             // (fills the fields that do not depend on the lane)
+    {   // chain -> stream
+        uint32_t lo = 0, hi = a.n_streams;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_chain <= chain) lo = mid; else hi = mid; }
+        X.S = a.streams[lo];
+    }
+    const AdxStream& S = X.S;
+    X.ch = chain - S.first_chain; X.valid = true;
+    X.src = a.in + S.src_offset; X.dst = a.out + S.dst_offset; X.rowb = 18 * S.channels;
+    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+    uint32_t cur = seg_pack(h1, h2), used = cur;
+    bool stopped = false;
+    for (uint32_t k = 0; k < S.seg_count; k++) {
+        const uint64_t g = (uint64_t)S.first_seg + (uint64_t)k * S.channels + X.ch;
+        uint32_t* rec = a.seg_state + 4 * g;
+        X.k = k; X.r0 = k * S.seg_rows; X.r1 = X.r0 + S.seg_rows < S.frames ? X.r0 + S.seg_rows : S.frames;
+        if (stopped) {                                               // everything after the end of the stream is silence
+            int16_t* q = (int16_t*)X.dst;
+            const uint64_t i0 = (uint64_t)X.r0 * 32, i1 = (uint64_t)X.r1 * 32 < S.samples ? (uint64_t)X.r1 * 32 : S.samples;
+            for (uint64_t i = i0; i < i1; i++) q[i * S.channels + X.ch] = 0;
+            continue;
+        }
+        const uint32_t stop_row = rec[3], r_end = stop_row < X.r1 ? stop_row : X.r1;
+        uint32_t end = rec[2];
+        if (used != cur) {                                           // the segment's samples were decoded from `used`
+            seg_unpack(cur, h1, h2);
+            if (!seg_repair(X, r_end, h1, h2)) end = seg_pack(h1, h2);
+        }
+        if (stop_row != 0xFFFFFFFFu) stopped = true;
+        used = rec[1];                                               // what passes 1 and 2 decoded the next segment from
+        cur = end;
+    }
+}
+
+void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s) {
+    if (!a.seg_lanes) return;
+    hipLaunchKernelGGL(k_adx_seg_decode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_adx_seg_fix, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_adx_seg_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
+}
+
 void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s) {
     if (n_streams) hipLaunchKernelGGL(k_adx_decode_wpf, dim3(n_streams), dim3(64), 0, s, a);
 }

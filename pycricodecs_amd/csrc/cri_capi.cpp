@@ -126,6 +126,8 @@ struct cri_job {
     AdxArgs adx{};
     uint32_t adx_streams = 0;                    // number of valid ADX streams
     bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
+    bool adx_seg = false;                        // segmented chains (k_adx_seg_*): long files of the standard layout
+    uint64_t adx_seg_flags_offset = 0;           // scratch offset of the per-chain flag words (the lanes' records are at 0)
     CryptArgs crypt{};
     SegmentArgs seg{};                           // USM demux / SFA pack: segment copies (+ audio mask)
     std::vector<uint32_t> item_tags;
@@ -470,6 +472,40 @@ static bool adx_pick_wave_per_file(bool all_std, size_t n_streams, bool encode) 
     return n_streams <= (encode ? 65536u : 12288u);
 }
 
+// Segmented chains (k_adx_seg_*, cri_adx.hip).  A decode that starts from a wrong history merges with the right one after a
+// time that scales with 1 / (4096 - c0 - c1) (measured on synthetic material, oracle-side: mean 16 000 / g samples, 99.5 %
+// within 5 x that); the warm-up is 3.5 x the mean -- a few per cent of the segments then need the repair pass, which costs a
+// few more rows -- and a segment is at least three warm-ups long.  Segment counts are chosen for ~256 K lanes per job (four
+// waves per SIMD).  Only the time depends on any of this.  Returns false when no file would get more than one segment (or the
+// layout is not the standard one): the unsegmented kernels stay.
+// CRICODECS_ADX_MAPPING = "seg" forces it where it applies, "chain" / "file" pick the unsegmented kernels.
+static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
+    const char* e = getenv("CRICODECS_ADX_MAPPING");
+    if (e && (!strcmp(e, "chain") || !strcmp(e, "file"))) return false;
+    if (streams.empty() || encode) return false;
+    uint64_t chains = 0;
+    for (const AdxStream& S : streams) {
+        if (!(S.blocksize == 18 && S.bitdepth == 4 && (S.mode == 2 || S.mode == 3))) return false;
+        chains += S.channels;
+    }
+    const char* we = getenv("CRICODECS_ADX_WARM");               // (developer switch: warm-up length in per cent of the default)
+    const uint64_t warm_pct = we ? strtoull(we, nullptr, 10) : 100;
+    const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains);
+    bool any = false;
+    for (AdxStream& S : streams) {
+        const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;     // (mode 2: the slowest of the four static filters)
+        S.rows_avail = (uint32_t)std::min<uint64_t>(S.frames, (S.src_end - S.src_offset) / (18ull * S.channels));
+        S.seg_rows = S.frames; S.seg_count = S.frames ? 1 : 0; S.warm_rows = 0;
+        if (g <= 0 || !S.frames) continue;                           // no decay (high-pass 0): one segment, i.e. the plain serial decode
+        const uint64_t warm = std::max<uint64_t>(1, (56000ull * warm_pct / 100 / (uint64_t)g + 31) / 32);
+        const uint64_t rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, 3 * warm);
+        if (rows >= S.frames) continue;
+        S.seg_rows = (uint32_t)rows; S.seg_count = (uint32_t)((S.frames + rows - 1) / rows); S.warm_rows = (uint32_t)warm;
+        any = true;
+    }
+    return any || (e && !strcmp(e, "seg"));
+}
+
 // LDS plan of the lane-per-chain ADX kernels.  A wave stages, for each of its files, T rows of blocks and of PCM in LDS
 // (regions padded to 4 bytes + 4), so what a wave needs is the sum over ITS files, not 64 x the largest item of the batch:
 // one ADX item with bitdepth 1 and blocksize 255 (8 * 253 samples per block, 4.3 KB per chain and row) must not size -- or
@@ -565,6 +601,34 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
         j->alg_bytes += (uint64_t)h.blocks * h.channels * (h.blocksize + 2ull * h.samples_per_block);
     }
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
+    if (adx_plan_segments(pend, false)) {
+        // segmented chains: every (segment, channel) of every file is a lane; no LDS staging, no padding besides even pair starts
+        j->adx_seg = true; j->dominant = "k_adx_seg_decode";
+        std::vector<uint32_t> seq(pend.size()), hist_at(pend.size()), seg_first;
+        for (size_t k = 0, hpos = 0; k < pend.size(); k++) { seq[k] = (uint32_t)k; hist_at[k] = (uint32_t)hpos; hpos += 2 * pend[k].channels; }
+        std::stable_sort(seq.begin(), seq.end(), [&](uint32_t x, uint32_t y) { return pend[x].seg_rows + pend[x].warm_rows > pend[y].seg_rows + pend[y].warm_rows; });
+        uint32_t lanes = 0, chains = 0;
+        for (uint32_t k : seq) {
+            AdxStream S = pend[k];
+            if (S.channels == 2 && (lanes & 1)) lanes++;
+            S.first_seg = lanes; S.first_chain = chains; S.hist_offset = chains;
+            seg_first.push_back(lanes);
+            lanes += S.seg_count * S.channels; chains += S.channels;
+            for (uint32_t c = 0; c < S.channels; c++) { history.push_back(pend_hist[hist_at[k] + 2 * c]); history.push_back(pend_hist[hist_at[k] + 2 * c + 1]); }
+            streams.push_back(S);
+        }
+        seg_first.push_back(lanes);
+        j->adx.chains = chains; j->adx.seg_lanes = lanes; j->adx.n_streams = (uint32_t)streams.size();
+        j->adx_streams = (uint32_t)streams.size();
+        j->adx_seg_flags_offset = align_up(16ull * lanes, 256);
+        j->scratch_bytes = j->adx_seg_flags_offset + align_up(4ull * chains, 256);
+        if (history.empty()) history.assign(2, 0);
+        int rc = 0;
+        if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_seg_chain.upload(seg_first)) || (rc = j->d_history.upload(history)) || (rc = j->upload_images())) { delete j; return rc; }
+        if ((rc = j->meta.commit())) { delete j; return rc; }
+        *out = j;
+        return 0;
+    }
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, pend.size(), false);
     if (j->adx_wave_per_file) j->dominant = "k_adx_decode_wpf";
     {   // chains are laid out now.  Lane per chain: a wave lasts as long as the longest of its 64 chains, so the files go in by
@@ -1239,6 +1303,15 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
             a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
             a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p; a.wpf_order = (const uint32_t*)j->d_adx_order.p;
+            if (j->adx_seg) {
+                a.seg_first = (const uint32_t*)j->d_seg_chain.p; a.seg_state = (uint32_t*)d_scratch;
+                a.seg_flags = (uint32_t*)((uint8_t*)d_scratch + j->adx_seg_flags_offset);
+                j->mark(0, true, s);
+                launch_fill_i32((int32_t*)a.seg_flags, 0, a.chains, s);
+                launch_adx_decode_seg(a, s);
+                j->mark(0, false, s);
+                break;
+            }
             j->mark(0, true, s);
             if (j->adx_wave_per_file) { if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode_wpf(a, j->adx_streams, s); else launch_adx_encode_wpf(a, j->adx_streams, s); }
             else if (j->kind == CRI_JOB_ADX_DECODE) launch_adx_decode(a, s); else launch_adx_encode(a, s);

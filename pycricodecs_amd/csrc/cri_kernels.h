@@ -65,12 +65,17 @@ struct AdxArgs {
     uint32_t rows_per_round;       // block rows staged in LDS per round (T)
     uint32_t lds_in_bytes, lds_out_bytes;
     const uint32_t* wpf_order;     // wave-per-file kernels: stream of workgroup b (longest files first), or null = b
+    // segmented chains: first (segment, channel) lane of every stream (n_streams + 1 entries), the lanes' records
+    // {speculative start state, end state, end state after repair, stop row} and one flag word per (stream, channel) chain
+    const uint32_t* seg_first; uint32_t n_streams, seg_lanes; uint32_t* seg_state; uint32_t* seg_flags;
 };
 void launch_adx_decode(const AdxArgs& a, hipStream_t s);
 void launch_adx_encode(const AdxArgs& a, hipStream_t s);
 // wave-per-file variants (blocksize 18, bitdepth 4, <= 2 channels, no header spill); one block per stream
 void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
 void launch_adx_encode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
+// segmented chains (standard layout): speculative decode of all segments, parallel repair, serial repair of flagged chains
+void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s);
 
 struct CryptArgs {
     const uint8_t* in; uint8_t* out;

@@ -83,4 +83,8 @@ struct AdxStream {
     uint32_t first_chain;          // global chain number of channel 0
     uint32_t stale_offset, stale_len; // encode: header image bytes that overlap the block area (OR-ed into first block bytes)
     uint32_t src_in_scratch;       // encode: src_offset is relative to the job scratch (converted PCM16), not to the input blob
+    // segmented chains (k_adx_seg_*, cri_adx.hip): the stream's block rows are cut into seg_count segments of seg_rows rows; a
+    // segment is decoded speculatively from a warm-up of warm_rows rows before it.  first_seg = global number of the stream's
+    // first (segment, channel) lane; rows_avail = block rows the input fully contains (decode)
+    uint32_t seg_rows, seg_count, warm_rows, first_seg, rows_avail;
 };

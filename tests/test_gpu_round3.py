@@ -222,3 +222,94 @@ def test_single_file_calls_reuse_the_arena(cc):
             h = cc.HcaEncode(w, False, 1)
             assert h == O.hca_encode(w, 1) and cc.HcaDecode(h, 96, 0, 0) == O.hca_decode(h)
         _capi.lib().cri_release_cache()
+
+
+# ------------------------------------------------------------------------------------------------ a3 / a4: segmented ADX decode
+def _adx_files():
+    rng = np.random.default_rng(123)
+    files = []
+    for k, (n, ch, sr, mode, hp) in enumerate([(32 * 400, 2, 48000, 3, 500), (32 * 1000 + 17, 1, 48000, 3, 500), (32 * 700, 2, 44100, 3, 500),
+                                               (32 * 900, 2, 48000, 2, 500), (32 * 333, 4, 48000, 3, 2000), (32 * 1500, 2, 48000, 3, 100),
+                                               (32 * 64, 2, 22050, 3, 500), (32 * 5, 1, 48000, 3, 500), (32 * 2100, 2, 48000, 3, 500)]):
+        w = synth.wav(1200 + k, n, ch, sr)
+        files.append(O.adx_encode(w, 4, 18, mode, hp, 0, 4))
+    loud = (rng.integers(-32768, 32768, (32 * 600, 2))).astype(np.int16)          # full-scale noise: the clamp is hit all the time
+    loud[:64] = 0                                                                 # (a first scale word >= 0x100 is rejected, adx.cpp:345-348)
+    files.append(O.adx_encode(synth.wav_bytes(loud, 48000)))
+    return files
+
+
+@pytest.mark.parametrize("warm", ["100", "10", "1"])
+def test_adx_segmented_decode_vs_oracle(cc, monkeypatch, warm):
+    """k_adx_seg_decode / _fix / _serial: files cut into segments decoded speculatively from a warm-up, verified and repaired.
+    With the default warm-up nearly every speculation is right; at 10 % and 1 % of it most are wrong and the repair passes do
+    the work -- the bytes are the oracle's either way (modes 2 and 3, 1 / 2 / 4 channels, several coefficient sets, a sample
+    count that is not a whole row, full-scale noise)."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "seg")
+    monkeypatch.setenv("CRICODECS_ADX_WARM", warm)
+    files = _adx_files()
+    job = Job.adx_decode(files)
+    assert job.dominant_kernel == "k_adx_seg_decode"
+    refs = [O.adx_decode(f) for f in files]
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert bytes(o) == r, i
+    outs, st = job.run_host()                                   # and through the host path (scratch from the arena)
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert bytes(o) == r, i
+
+
+@pytest.mark.parametrize("warm", ["100", "2"])
+def test_adx_segmented_decode_end_markers_and_truncation(cc, monkeypatch, warm):
+    """adx.cpp:405-406 inside a segmented file: an end-of-stream scale word on a row's first block (in the first segment, in a
+    later one, right at a segment's first row), inputs cut in the middle of a row, a header that announces more blocks than the
+    file holds, a sample count below a whole row -- everything after the end decodes to silence, in every later segment."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "seg")
+    monkeypatch.setenv("CRICODECS_ADX_WARM", warm)
+    base = O.adx_encode(synth.wav(1300, 32 * 1200, 2, 48000))
+    mono = O.adx_encode(synth.wav(1301, 32 * 800, 1, 48000))
+    do = int.from_bytes(base[2:4], "big") + 4
+    files = []
+    for row in (0, 1, 37, 140, 599, 1199):
+        b = bytearray(base)
+        b[do + row * 36:do + row * 36 + 2] = b"\x80\x01"
+        files.append(bytes(b))
+    b = bytearray(base); b[do + 500 * 36 + 18:do + 500 * 36 + 20] = b"\x80\x01"      # on the SECOND channel's block: not an end marker
+    try:
+        O.adx_decode(bytes(b)); files.append(bytes(b))
+    except O.OracleError:
+        pass
+    for cut in (do + 36 * 700 + 5, do + 36 * 3, do + 36 * 1199 + 35, do + 1):
+        files.append(base[:cut])
+    dm = int.from_bytes(mono[2:4], "big") + 4
+    files.append(mono[:dm + 18 * 411 + 9])
+    b = bytearray(mono); b[12:16] = (32 * 800 - 13).to_bytes(4, "big"); files.append(bytes(b))   # sample count inside the last row
+    b = bytearray(mono); b[12:16] = (32 * 500 + 1).to_bytes(4, "big"); files.append(bytes(b))
+    job = Job.adx_decode(files)
+    assert job.dominant_kernel == "k_adx_seg_decode"
+    outs, st = run_job(job)
+    for i, (o, f) in enumerate(zip(outs, files)):
+        try:
+            want = O.adx_decode(f)
+        except O.OracleError:
+            want = None
+        if want is None:
+            assert job.host_status[i] != 0 or st[i] != 0, i
+        else:
+            assert bytes(o) == want, i
+
+
+def test_adx_ten_second_file_takes_the_segmented_path(cc):
+    """The drop-in single-file call on a 10 s stereo file (one or two chains of 480 000 dependent steps for the unsegmented
+    kernels) runs as a few hundred segments by default; high-pass 0 (no decay: coefficients 8192, -4096) stays one segment."""
+    from pycricodecs_amd.batch import Job
+    w = synth.wav(1400, 480000, 2, 48000)
+    a = O.adx_encode(w)
+    assert Job.adx_decode([a]).dominant_kernel == "k_adx_seg_decode"
+    assert cc.AdxDecode(a) == O.adx_decode(a)
+    a0 = O.adx_encode(w, 4, 18, 3, 0, 0, 4)
+    assert Job.adx_decode([a0]).dominant_kernel != "k_adx_seg_decode"
+    assert cc.AdxDecode(a0) == O.adx_decode(a0)
