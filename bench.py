@@ -143,9 +143,30 @@ def timed_loop(fn, seconds):
     return reps, time.time() - t0
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def criref_all_cores(what, data, seconds, key, frames):
+    """The same reference loop in one process per host core at once (single thread AND all cores from the same run)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    with ThreadPoolExecutor(n) as ex:
+        res = list(ex.map(lambda _: criref_bench(what, data, seconds, key), range(n)))
+    return {"value": round(sum(r * frames / s for r, s in res), 1), "unit": "frames/s", "cores": n, "cpu_model": cpu_model(),
+            "sample": "%d processes x %.0f s of the single-thread loop, all at once" % (n, seconds)}
+
+
 def cpu_baseline(kind, sample, frames, seconds=10.0):
     """kind: hcadec (sample = encrypted stream), hcaenc (sample = WAV), adxrt (sample = WAV: encode, then decode of the result).
-    `frames` = the metric's units one repetition processes."""
+    `frames` = the metric's units one repetition processes.  value / cores = ONE host thread; all_cores = every core at once."""
     import oracle_lib as O
     what = {"hcadec": "HCA decode of one stream of this workload", "hcaenc": "HCA encode (High) of one WAV of this workload",
             "adxrt": "ADX encode + decode of one WAV of this workload"}[kind]
@@ -158,8 +179,19 @@ def cpu_baseline(kind, sample, frames, seconds=10.0):
             else:
                 reps, secs = criref_bench(kind, sample, seconds, KEY if kind == "hcadec" else 0)
                 value = reps * frames / secs
-            return {"value": round(value, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
-                    "sample": "%d x %s (%d frames each), reference C++ built from /root/reference (oracle/_ref/criref), single thread" % (reps, what, frames)}
+            out = {"value": round(value, 1), "unit": "frames/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
+                   "sample": "%d x %s (%d frames each), reference C++ built from /root/reference (oracle/_ref/criref), single thread" % (reps, what, frames)}
+            try:
+                if kind == "adxrt":
+                    a = criref_all_cores("adxenc", sample, seconds / 2, 0, frames / 2)
+                    b = criref_all_cores("adxdec", O.adx_encode(sample), seconds / 2, 0, frames / 2)
+                    a["value"] = round(frames / (frames / 2 / a["value"] + frames / 2 / b["value"]), 1)
+                    out["all_cores"] = a
+                else:
+                    out["all_cores"] = criref_all_cores(kind, sample, seconds, KEY if kind == "hcadec" else 0, frames)
+            except Exception as e:
+                log("all-cores baseline failed:", e)
+            return out
         except Exception as e:  # fall through to the port
             log("criref bench failed:", e)
     if kind == "hcadec":
@@ -168,7 +200,7 @@ def cpu_baseline(kind, sample, frames, seconds=10.0):
         reps, secs = timed_loop(lambda: O.hca_encode(sample, 1), seconds)
     else:
         reps, secs = timed_loop(lambda: O.adx_decode(O.adx_encode(sample)), seconds)
-    return {"value": round(reps * frames / secs, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": round(reps * frames / secs, 1), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d x %s (%d frames each), oracle/cri_oracle.c, single thread" % (reps, what, frames)}
 
 
@@ -262,7 +294,7 @@ def roofline_of(alg_bytes, alg_bytes_path, kernel_ms, dt, traffic=None, extra=No
     dom = max(kernel_ms, key=kernel_ms.get)
     achieved = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
     e2e = alg_bytes_path / dt / 1e9
-    r = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    r = {"bound": "valu" if extra and "valu" in extra else "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
          "end_to_end": {"achieved": round(e2e, 2), "frac": round(e2e / HBM_PEAK_GBPS, 5),
                         "what": "algorithmic bytes of the whole path / wall time of a step (all kernels of the path, launch gaps included)"},
@@ -294,18 +326,49 @@ def committed_traffic(units, dom):
     return out
 
 
+VALU_PEAK_PER_S = 520e9       # wave64 VALU instructions per second the chip retires: 256 CUs x 1 per clock (a wave64 instruction holds its
+                              # SIMD for 4 cycles, 4 SIMDs per CU) at the ~2.03 GHz it holds under this load
+
+
+def committed_valu(units, kernel_ms):
+    """What bounds the HCA decode kernels is VALU issue, not HBM: instructions per frame from the committed SQ counter passes of this
+    path (profiles/r*_pmc_1000streams.json: SQ_INSTS_VALU per dispatch / frames), the time those instructions need at the chip's
+    issue rate (floor_ms) and the share of each kernel's measured time they fill (busy)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1000streams.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        pj = json.load(fh)
+    per, busy, floor = {}, {}, 0.0
+    for name, k in pj.get("kernels", {}).items():
+        cls = "k_hca_parse" if "parse" in name else ("k_hca_transform" if "transform" in name else None)
+        if not cls or "VALU_per_frame" not in k:
+            continue
+        per[cls] = k["VALU_per_frame"]
+        ms = k["VALU_per_frame"] * units / VALU_PEAK_PER_S * 1e3
+        floor += ms
+        if kernel_ms.get(cls):
+            busy[cls] = round(ms / kernel_ms[cls], 3)
+    if not per:
+        return None
+    return {"valu": {"insts_per_frame": per, "peak_insts_per_s": VALU_PEAK_PER_S, "floor_ms": round(floor, 3), "busy": busy,
+                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU, counters-only passes)" % os.path.basename(files[-1])}}
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def make_hca_streams(unique, seconds, rank, quality, family):
     import oracle_lib as O
     return [O.hca_crypt(O.hca_encode(family_wav(1000 * rank + u, seconds, family), quality), 1, 56, KEY) for u in range(unique)]
 
 
-def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True):
-    """Decode of `streams` copies of `unique` streams.  Returns a result dict (rank-local verification, rank-reduced timing)."""
+def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True, uniq=None):
+    """Decode of `streams` copies of `unique` streams (or of the prepared encrypted streams `uniq`).  Returns a result dict
+    (rank-local verification, rank-reduced timing)."""
     import torch
     import oracle_lib as O
     from pycricodecs_amd.batch import Job
-    uniq = make_hca_streams(unique, seconds, D.rank, quality, family)
+    if uniq is None:
+        uniq = make_hca_streams(unique, seconds, D.rank, quality, family)
     items = tile(uniq, streams)
     job = Job.hca_decode(items, keys=[KEY] * len(items))
     assert not job.host_status.any(), "synthetic inputs rejected at the header stage"
@@ -421,7 +484,7 @@ def build_awb_bank(n_total, rank, world, seed=77):
     return head.ljust(hs, b"\0") + b"".join(parts), uniq, order, subkey
 
 
-def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True):
+def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=False):
     """Decode of a mixed AFS2 bank through the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM.
     With world > 1 every rank decodes its LPT share of clips x world clips and (gather=True) the decoded PCM of all
     ranks is collected on rank 0 inside the timed region -- the only collective-like step of the whole path."""
@@ -430,7 +493,7 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True):
     from pycricodecs_amd import shard
     from pycricodecs_amd.batch import Job
     world = D.world
-    bank, uniq, order, subkey = build_awb_bank(clips * world, D.rank, world)
+    bank, uniq, order, subkey = build_awb_bank(clips if strong else clips * world, D.rank, world)      # strong: `clips` is the whole job
     n = len(order)
     hj, aj = Job.awb_decode(bank, KEY)
     d_in, ho, hscr, hst = hj.alloc(D.dev)
@@ -500,6 +563,19 @@ def secondary_measurements(args, D):
                       "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
                       "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "record_forms": census_text(r["census"]),
                       "verified_items": r["verified"]["items"]}
+    # the other transform kernels of the decode path: k_hca_transform<PLAIN, 6 | 8> (wide layouts), k_hca_transform<false, 2> with the
+    # v3.0 noise fill (a v2.0 stream re-headed as v3.0 with min_resolution 0: every band below the noise level is reconstructed),
+    # k_hca_transform_generic (3 channels: a stereo pair that does not start on an even channel)
+    import hca_forge
+    nw = max(1, n // 4)
+    for label, ch, v3 in (("hca_decode_6ch", 6, False), ("hca_decode_8ch", 8, False), ("hca_decode_v3_noise_fill", 2, True), ("hca_decode_3ch_generic", 3, False)):
+        plain = [O.hca_encode(family_wav(8000 + 10 * ch + u, args.seconds, "tonal", ch=ch), 1) for u in range(4)]
+        if v3:
+            plain = [hca_forge.forge_v3(h, 0) for h in plain]
+        r = hca_decode_run(D, nw, 4, args.seconds, 1, "tonal", 3, 1, uniq=[O.hca_crypt(h, 1, 56, KEY) for h in plain])
+        out[label] = {"workload": "HCA decode, %d x %.0f s encrypted %d-channel streams, quality High%s" % (nw, args.seconds, ch, ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""),
+                      "transform_kernel": r["job"].dominant_kernel, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
+                      "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "verified_items": r["verified"]["items"]}
     r = hca_encode_run(D, n, uq, args.seconds, 1, "tonal", 3, 1)
     out["hca_encode"] = {"workload": "HCA encode (quality High), %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), "frames_per_s": round(r["units"] / r["dt"], 1),
                          "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"], "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()},
@@ -535,7 +611,75 @@ def secondary_measurements(args, D):
     del bufs
     torch.cuda.empty_cache()
     out["awb_mixed_decode"] = awb_mixed_run(D, args.awb_clips, 3, 1)
+    out["single_call_ms"] = single_call_latency(args.seconds)
+    out["hca_decode_host"] = host_path_run(min(args.streams, args.host_streams), uq, args.seconds)
     return out
+
+
+def single_call_latency(seconds):
+    """The five drop-in single-file calls (host bytes in, host bytes out: what PyCriCodecs' ADX / HCA classes call, hca.py:250, adx.py)
+    on one stereo file of `seconds`, beside the reference's own time for the same call on one host core of this box."""
+    import oracle_lib as O
+    from pycricodecs_amd import CriCodecs as cc
+    w = family_wav(9000, seconds, "tonal")
+    hca = O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY)
+    adx = O.adx_encode(w)
+    hs = int.from_bytes(hca[6:8], "big")
+
+    def ms(fn, n=10):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return round((time.perf_counter() - t0) / n * 1e3, 3)
+
+    def ref(what, data, key=0):
+        if not criref():
+            return None
+        reps, secs = criref_bench(what, data, 1.0, key)
+        return round(secs / reps * 1e3, 3)
+    assert cc.AdxDecode(adx) == O.adx_decode(adx) and cc.HcaDecode(hca, hs, KEY, 0) == O.hca_decode(hca, KEY)
+    return {"file": "%.0f s 48 kHz stereo" % seconds, "unit": "ms per call, device path | reference C++ on one host core",
+            "AdxDecode": [ms(lambda: cc.AdxDecode(adx)), ref("adxdec", adx)], "AdxEncode": [ms(lambda: cc.AdxEncode(w, 4, 18, 3, 500, 0, 4, False)), ref("adxenc", w)],
+            "HcaDecode": [ms(lambda: cc.HcaDecode(hca, hs, KEY, 0)), ref("hcadec", hca, KEY)], "HcaEncode": [ms(lambda: cc.HcaEncode(w, False, 1)), ref("hcaenc", w)],
+            "HcaCrypt": [ms(lambda: cc.HcaCrypt(hca, 0, hs, 0, KEY, 0)), None]}
+
+
+def host_path_run(streams, unique, seconds):
+    """PCIe-inclusive: HCA decode of `streams` encrypted streams from HOST memory to host memory through cri_job_run_host_into (one
+    pageable host blob up, the kernels, the WAVs down into a page-locked buffer) -- what a caller without device buffers sees.
+    Job planning (header parse of every item) is outside the timed call, as for the device-resident line."""
+    import numpy as np
+    import oracle_lib as O
+    from pycricodecs_amd.batch import Job, pinned_array, pinned_release
+    uniq = make_hca_streams(unique, seconds, 0, 1, "tonal")
+    items = tile(uniq, streams)
+    job = Job.hca_decode(items, keys=[KEY] * len(items))
+    out = pinned_array(job.output_bytes)
+    job.blob                                                   # the batch as one host blob (built once)
+    job.run_host(out=out, joined=True)
+    best, st = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        outs, st = job.run_host(out=out, joined=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    assert not st.any()
+    refs = [O.hca_decode(h, KEY) for h in uniq]
+    step = max(1, streams // 97)
+    checked = 0
+    for i in list(range(0, streams, step)) + [streams - 1]:
+        assert bytes(outs[i]) == refs[i % len(uniq)], "host path: item %d differs from the oracle" % i
+        checked += 1
+    res = {"workload": "HCA decode of %d x %.0f s encrypted stereo streams, host bytes in (pageable) -> host WAVs out (page-locked), cri_job_run_host_into" % (streams, seconds),
+           "frames_per_s": round(job.units / best, 1), "ms": round(best * 1e3, 2), "frames": job.units,
+           "GBps_in_plus_out": round((job.input_bytes + job.output_bytes) / best / 1e9, 2), "bytes": {"in": job.input_bytes, "out": job.output_bytes},
+           "verified_items": checked, "verified_how": "every %d-th output compared on the host with the oracle's bytes; all statuses zero" % step}
+    del outs
+    pinned_release(out)
+    from pycricodecs_amd import _capi
+    _capi.lib().cri_release_cache()
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -563,11 +707,14 @@ def main():
     ap.add_argument("--seconds", type=float, default=None, help="seconds per item (default 10; hca_encode 30)")
     ap.add_argument("--data", default="tonal", choices=["tonal", "sparse", "noise", "mixed"], help="signal family of the synthetic inputs (see family_pcm)")
     ap.add_argument("--quality", type=int, default=1, help="HCA quality: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR), 4 Lowest")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --streams (--awb-clips) items PER GPU; strong: that many in total, dealt out to the ranks (BASELINE configs[3] / [4]: a fixed batch, file-sharded 1 -> 8)")
     ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
+    ap.add_argument("--host-streams", type=int, default=2500, help="streams of the host-memory secondary (page-locked output: 1.92 MB each)")
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -581,12 +728,16 @@ def main():
     seconds = args.seconds or (30.0 if wl == "hca_encode" else 10.0)
     verify = not args.no_verify
     args.streams, args.unique, args.seconds = streams, unique, seconds
-    common = {"n_gpus": D.world, **({"launcher_smoke_test": "ranks share one GPU over gloo; not a measurement"} if D.shared and D.world > 1 else {}), "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None}
-    par = "file-sharded x%d, one process per GPU, no data-path collective" % D.world
+    strong = args.scaling == "strong"
+    total_streams = streams
+    if strong:                                                 # this rank's share of the fixed batch (equal items: dealt round robin; the AWB bank: LPT by frames)
+        streams = len(range(D.rank, total_streams, D.world))
+    common = {"n_gpus": D.world, **({"launcher_smoke_test": "ranks share one GPU over gloo; not a measurement"} if D.shared and D.world > 1 else {}), "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None}
+    par = "file-sharded x%d, one process per GPU, no data-path collective%s" % (D.world, " (a fixed batch of %d dealt out to the ranks)" % total_streams if strong else "")
     t_setup = time.time()
 
     if wl == "awb_mixed":                                      # BASELINE configs[4]; its own metric line
-        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify)
+        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify, strong=strong)
         if D.rank == 0:
             print(json.dumps(dict(common, metric="audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", value=r["frames_per_s"], unit="frames/s",
                                   ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (24 unique durations x 2 codecs, tiled; tonal family)",
@@ -600,12 +751,16 @@ def main():
                            % (streams, seconds, QNAME.get(args.quality, "?"), r["frame_size"]),
                "streams_per_gpu": streams, "frames_per_stream": r["frames_per_stream"], "unique_streams": unique, "parallelism": par,
                "record_forms": census_text(r["census"])}
+        if strong:
+            cfg["batch_total"] = total_streams
         dtype, unit_bytes = "f32", "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"]
         cpu = ("hcadec", r["sample"], r["frames_per_stream"])
     elif wl == "hca_encode":
         r = hca_encode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify)
         cfg = {"workload": "BASELINE configs[3]: HCA encode (v2.0, quality %s), %d 48 kHz stereo WAVs x %.0f s per GPU" % (QNAME.get(args.quality, "?"), streams, seconds),
                "streams_per_gpu": streams, "frames_per_stream": r["frames_per_stream"], "unique_wavs": unique, "parallelism": par}
+        if strong:
+            cfg["batch_total"] = total_streams
         dtype, unit_bytes = "f32", "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"]
         cpu = ("hcaenc", r["sample"], r["frames_per_stream"])
     else:
@@ -620,11 +775,15 @@ def main():
         ok = D.reduce([float(r["verified"]["items"])], "sum")[0]
         cfg["verified"]["items_all_ranks"] = int(ok)
     units, dt, kms = r["units"], r["dt"], r["kernel_ms"]
+    units_all = D.reduce([float(units)], "sum")[0]             # the whole job's units (weak: world x this rank's; strong: the fixed batch)
     dom = max(kms, key=kms.get)
     alg_dom = r.get("alg_bytes_by_kernel", {}).get(dom, r["alg_bytes"])
     traffic = committed_traffic(units, dom) if (wl == "hca_decode" and args.quality == 1 and args.data == "tonal") else None
-    roof = roofline_of(alg_dom, r["alg_bytes"], kms, dt, traffic, {"bytes_per_unit": unit_bytes})
-    out = dict(common, metric="audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline", value=round(units * D.world / dt, 1), unit="frames/s",
+    extra = {"bytes_per_unit": unit_bytes}
+    if wl == "hca_decode":
+        extra.update(committed_valu(units, kms) or {})
+    roof = roofline_of(alg_dom, r["alg_bytes"], kms, dt, traffic, extra)
+    out = dict(common, metric="audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline", value=round(units_all / dt, 1), unit="frames/s",
                ms_per_step=round(dt * 1e3, 3), dtype=dtype,
                data="synthetic, %s family (%s); %d unique inputs tiled to %d, each copy in its own HBM" % (
                    args.data, {"tonal": "seeded sines + noise floor", "sparse": "pure / sparse tones and low-passed noise", "noise": "full-scale noise / square / clicks / loud tones in noise",
@@ -633,11 +792,15 @@ def main():
     # other rows of the same hot path and the host-core baseline: single-GPU run only (ranks of a scaling run must not wait)
     if D.rank == 0 and D.world == 1 and wl == "hca_decode" and not args.no_secondary:
         out["secondary"] = secondary_measurements(args, D)
-    if D.rank == 0 and D.world == 1 and not args.no_cpu:
+    rank, world = D.rank, D.world
+    if world > 1:
+        D.close()                                              # (the other ranks are done; the host-core baseline is rank 0's alone)
+    if rank == 0 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(*cpu)
-    if D.rank == 0:
+    if rank == 0:
         print(json.dumps(out), flush=True)
-    D.close()
+    if world == 1:
+        D.close()
 
 
 if __name__ == "__main__":

@@ -241,9 +241,10 @@ void cri_job_destroy(cri_job* job);
  *                           (`items`: the same n items with the same lengths; its offsets are ignored).
  * The library keeps, per device, the device buffers of the last host call (up to 512 MB; larger ones are released when the
  * call returns) and private streams: these calls allocate nothing in the steady state and wait for their own stream only.
- * Large single-format HCA decode jobs run pipelined -- upload, kernels and download of successive slices overlap; with
- * page-locked host memory (cri_pinned_alloc, or memory the caller registered with the HIP runtime) all PCIe copies are
- * asynchronous DMA.  cri_release_cache drops what is kept for the calling thread's current device. */
+ * With page-locked host memory (cri_pinned_alloc, or memory the caller registered with the HIP runtime) the PCIe copies are
+ * asynchronous DMA.  (A pipelined order -- upload, kernels and download of successive slices of a large HCA decode job on three
+ * streams -- is implemented and tested but off by default: it measured no faster on this runtime; CRICODECS_HOST_SLICE_MIN
+ * = job size in bytes turns it on.)  cri_release_cache drops what is kept for the calling thread's current device. */
 int cri_job_run_host(cri_job* job, const uint8_t* blob, uint8_t** out_blob, int32_t* status);
 int cri_job_run_host_into(cri_job* job, const uint8_t* blob, uint8_t* out, int32_t* status);
 int cri_job_run_host_items(cri_job* job, const cri_items* items, uint8_t* out, int32_t* status);

@@ -295,11 +295,12 @@ class Job:
         n = _capi.lib().cri_job_event_ms(self._h, ms, names, 4)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
-    def run_host(self, out=None):
+    def run_host(self, out=None, joined=False):
         """Upload, run, download: returns (list of outputs per item, status int32[n]).  The outputs are memoryviews into one
         buffer owned by this Job and reused by its next run_host() call (copy what must outlive it with bytes(...)), or into
         `out` (a uint8 numpy array of at least output_bytes, e.g. pinned_array()).  A job made from an item list uploads every
-        item from its own bytes object (cri_job_run_host_items): no joined copy of the batch is made on the host."""
+        item from its own bytes object (cri_job_run_host_items): no joined copy of the batch is made on the host -- unless
+        `joined` asks for it (one upload of Job.blob, built once and kept: faster per call for batches of many small items)."""
         n = max(self.output_bytes, 1)
         if out is None:
             if getattr(self, "_host_out", None) is None or self._host_out.size < n:
@@ -307,7 +308,8 @@ class Job:
             out = self._host_out
         assert out.dtype == np.uint8 and out.size >= n and out.flags["C_CONTIGUOUS"]
         status = (C.c_int32 * max(self.n, 1))()
-        if self.items is not None:
+        packed = self.n == 0 or int(self.offsets[self.n]) == sum(len(b) for b in (self.items or []))
+        if self.items is not None and not (joined and packed):
             st, keep = items_struct(self.items)
             rc = _capi.lib().cri_job_run_host_items(self._h, C.byref(st), out.ctypes.data, status)
         else:

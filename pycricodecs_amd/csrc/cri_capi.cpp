@@ -1416,11 +1416,9 @@ extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int m
 // leaves more than HOST_ARENA_KEEP behind: a 40 GB batch should not stay resident because it ran once) and three private,
 // non-blocking streams -- so a single-file call allocates nothing, waits for its own stream only (never hipDeviceSynchronize:
 // the host's other streams are not this library's business) and copies its result straight into the buffer it returns.
-// Large HCA decode jobs run PIPELINED: the group is cut into slices of whole parse tiles; slice k's input bytes go up on the
-// upload stream while slice k-1 is parsed and transformed on the run stream and slice k-2's PCM comes down on the download
-// stream (events order the three).  With pinned host memory (cri_pinned_alloc, or memory the caller registered) the copies
-// are asynchronous DMA and the three overlap fully; with pageable memory the runtime stages the copies on the calling thread,
-// which still overlaps them with the kernels and with the downloads already queued.
+// A PIPELINED order exists for large single-format HCA decode jobs (the group cut into slices of whole parse tiles: slice k's
+// input goes up on the upload stream while slice k-1 is parsed and transformed on the run stream and slice k-2's PCM comes
+// down on the download stream, events ordering the three); it is off by default -- see run_host_core for what it measured.
 namespace {
 const size_t HOST_ARENA_KEEP = 512ull << 20;
 struct HostArena {
@@ -1514,7 +1512,13 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
     if (out_copy > j->out_bytes) out_copy = j->out_bytes;
     const bool gaps = src.items && j->n && j->in_bytes;       // an items layout may leave bytes between the items: they are defined as zero
     uint32_t cursor = 0;
-    uint64_t slice_min = 256ull << 20;                       // (CRICODECS_HOST_SLICE_MIN: tests force the pipelined path on small jobs)
+    // The pipelined path is OFF unless CRICODECS_HOST_SLICE_MIN names a job size (bytes in + out) from which to use it: measured on
+    // MI355X / ROCm 7.2 (tools/debug/host_path_time.py, 2000 x 10 s streams, 0.64 GB in, 3.84 GB out) the single-stream order below
+    // takes 86 ms -- upload 11, kernels 4, download 67 at the link's 57 GB/s -- and the sliced order 87-89 ms from a pageable source
+    // and 132-140 ms from a page-locked one, whatever the slice count, the download stream or the queueing order; a replica of the
+    // same three-stream shape in PyTorch (tools/debug/pcie_duplex.py) does overlap the two directions (80 ms for 1 + 4 GB against 94
+    // in sequence), so the overlap exists on this link -- why this path misses it is open.  The tests run both.
+    uint64_t slice_min = ~0ull;
     if (const char* e = getenv("CRICODECS_HOST_SLICE_MIN")) slice_min = strtoull(e, nullptr, 10);
     const bool sliced = hca_decode_sliceable(j) && out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
     if (!sliced) {
@@ -1531,6 +1535,8 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         // slices of whole tiles, about 256 MB of PCIe traffic each (at least 4, at most 64)
         uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) >> 28);
         K = K < 4 ? 4 : (K > 64 ? 64 : K);
+        if (const char* e = getenv("CRICODECS_HOST_SLICES")) K = (uint32_t)strtoul(e, nullptr, 10);   // (developer switch)
+        if (K < 1) K = 1;
         if (K > tiles) K = tiles;
         const uint32_t TS = (tiles + K - 1) / K;
         if (gaps && !j->items_packed) ok(hipMemsetAsync(d_in, 0, j->in_bytes, A.s_up));
@@ -1540,17 +1546,34 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
             launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, d_out, A.s_run);
         uint64_t in_pos = 0, out_pos = 0;
         uint32_t s_need = 0, s_done = 0, ev = 0;                 // streams whose input is up / whose PCM is down
-        for (uint32_t t0 = 0; t0 < tiles && !rc; t0 += TS) {
+        hipStream_t s_dn = A.s_down;
+        // Page-locked source: all uploads are queued first (asynchronous DMA), then the kernels and downloads -- the order in which the
+        // two copy directions overlap on this runtime; a pageable source is staged on this thread, chunk by chunk between the launches.
+        bool src_pinned = false;
+        if (src.blob) {
+            hipPointerAttribute_t at;
+            src_pinned = hipPointerGetAttributes(&at, src.blob) == hipSuccess && at.type == hipMemoryTypeHost;
+            (void)hipGetLastError();
+        }
+        auto slice_upload = [&](uint32_t t1, hipEvent_t e_up) {
+            const uint64_t frames_end = (uint64_t)t1 * 64 < base.frames ? (uint64_t)t1 * 64 : base.frames;
+            while (s_need < ns && S[s_need].first_frame < frames_end) s_need++;      // every stream that has a frame below frames_end
+            const uint64_t in_end = s_need == ns ? j->in_bytes : j->in_offsets[S[s_need].item];
+            const int r = upload_range(j, src, d_in, in_pos, in_end, cursor, A.s_up);
+            in_pos = in_end > in_pos ? in_end : in_pos;
+            ok(hipEventRecord(e_up, A.s_up));
+            return r;
+        };
+        const uint32_t nslices = (tiles + TS - 1) / TS;
+        for (uint32_t k = 0; k < 2 * nslices + 1; k++) if (!A.event(k)) rc = CRI_ERR_HIP;
+        if (src_pinned && !rc)
+            for (uint32_t k = 0, t0 = 0; t0 < tiles && !rc; k++, t0 += TS) rc = slice_upload(t0 + TS < tiles ? t0 + TS : tiles, A.event(2 * k));
+        for (uint32_t k = 0, t0 = 0; t0 < tiles && !rc; k++, t0 += TS) {
             const uint32_t t1 = t0 + TS < tiles ? t0 + TS : tiles;
             const uint64_t frames_end = (uint64_t)t1 * 64 < base.frames ? (uint64_t)t1 * 64 : base.frames;
-            // input: every stream that has a frame below frames_end
-            while (s_need < ns && S[s_need].first_frame < frames_end) s_need++;
-            const uint64_t in_end = s_need == ns ? j->in_bytes : j->in_offsets[S[s_need].item];
-            rc = upload_range(j, src, d_in, in_pos, in_end, cursor, A.s_up);
-            in_pos = in_end > in_pos ? in_end : in_pos;
-            hipEvent_t e_up = A.event(ev++), e_run = A.event(ev++);
-            if (!e_up || !e_run) { rc = CRI_ERR_HIP; break; }
-            ok(hipEventRecord(e_up, A.s_up));
+            hipEvent_t e_up = A.event(2 * k), e_run = A.event(2 * k + 1);
+            if (!src_pinned) rc = slice_upload(t1, e_up);
+            ev = 2 * nslices;
             ok(hipStreamWaitEvent(A.s_run, e_up, 0));
             HcaDecArgs a = base;
             a.in = d_in; a.out = d_out; a.scratch = d_scr; a.status = d_st;
@@ -1564,10 +1587,9 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
             if (s_to > s_done) {
                 const uint32_t r0 = S[s_done].first_run, r1 = s_to == ns ? base.runs : S[s_to].first_run;
                 if (r1 > r0) { a.run_begin = r0; a.run_count = r1 - r0; launch_hca_transform(a, A.s_run); }
-                ok(hipEventRecord(e_run, A.s_run));
-                ok(hipStreamWaitEvent(A.s_down, e_run, 0));
+                ok(hipEventRecord(e_run, A.s_run)); ok(hipStreamWaitEvent(A.s_down, e_run, 0));
                 const uint64_t out_end = s_to == ns ? j->out_bytes : j->out_offsets[S[s_to].item];
-                if (out_end > out_pos) ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, out_end - out_pos, hipMemcpyDeviceToHost, A.s_down));
+                if (out_end > out_pos) ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, out_end - out_pos, hipMemcpyDeviceToHost, s_dn));
                 out_pos = out_end > out_pos ? out_end : out_pos;
                 s_done = s_to;
             }
@@ -1576,7 +1598,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         if (!rc && out_pos < j->out_bytes) {                       // (streams without frames at the end: their headers only)
             hipEvent_t e = A.event(ev++);
             if (e) { ok(hipEventRecord(e, A.s_run)); ok(hipStreamWaitEvent(A.s_down, e, 0)); }
-            ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, j->out_bytes - out_pos, hipMemcpyDeviceToHost, A.s_down));
+            ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, j->out_bytes - out_pos, hipMemcpyDeviceToHost, s_dn));
         }
         ok(hipStreamSynchronize(A.s_up));
         ok(hipStreamSynchronize(A.s_down));
