@@ -308,8 +308,8 @@ class Job:
             out = self._host_out
         assert out.dtype == np.uint8 and out.size >= n and out.flags["C_CONTIGUOUS"]
         status = (C.c_int32 * max(self.n, 1))()
-        packed = self.n == 0 or int(self.offsets[self.n]) == sum(len(b) for b in (self.items or []))
-        if self.items is not None and not (joined and packed):
+        use_blob = self.items is None or (joined and int(self.offsets[self.n]) == sum(len(b) for b in self.items))
+        if not use_blob:
             st, keep = items_struct(self.items)
             rc = _capi.lib().cri_job_run_host_items(self._h, C.byref(st), out.ctypes.data, status)
         else:

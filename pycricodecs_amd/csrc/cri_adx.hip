@@ -585,30 +585,33 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
     for (uint64_t i = (uint64_t)done * 32 * C + lane; i < (uint64_t)S.samples * C; i += 64) ((int16_t*)out)[i] = 0;
 }
 
-// (an instance per channel count, both launched over all streams: a block whose stream has the other count leaves at once)
-template <int C>
-__global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
-    __shared__ uint8_t blk_img[40];
-    __shared__ __attribute__((aligned(16))) int32_t xl[64];   // a frame's (sample << 12), by lane
-    const AdxStream S = a.streams[a.wpf_order ? a.wpf_order[blockIdx.x] : blockIdx.x];
-    if (S.channels != (uint32_t)C) return;
+// a chain's state between two rows: its two history samples
+__device__ __forceinline__ uint32_t seg_pack(int32_t h1, int32_t h2) { return ((uint32_t)h1 & 0xFFFFu) | ((uint32_t)h2 << 16); }
+__device__ __forceinline__ void seg_unpack(uint32_t s, int32_t& h1, int32_t& h2) { h1 = (int32_t)(int16_t)(s & 0xFFFF); h2 = (int32_t)(int16_t)(s >> 16); }
+
+// Rows [row_begin, row_end) of stream S by one wave: lanes 0-31 = channel 0's block, 32-63 = channel 1's.  Rows below
+// `store_from` are encoded but not stored (the warm-up of a segment, see the segmented kernels below).  h1 / h2: the half's
+// history, the same in every lane of a half.  after_round(next_row) runs after every round of R rows -- rounds start at
+// row_begin, R apart -- and ends the walk when it returns true (wave-uniform).
+#define ADX_WPF_R 4
+template <int C, class AfterRound>
+__device__ __forceinline__ void adx_wpf_rows(const AdxArgs& a, const AdxStream& S, uint32_t row_begin, uint32_t row_end, uint32_t store_from,
+                                             int32_t& h1, int32_t& h2, uint8_t* blk_img, int32_t* xl, AfterRound&& after_round) {
     const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31;
     const bool act = half < C;
-    const uint32_t chain = S.first_chain + (act ? half : 0);
-    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
     const int32_t c0 = S.coef0, c1 = S.coef1;
     const uint8_t* pcm = (S.src_in_scratch ? a.scratch : a.in) + S.src_offset;
     uint8_t* dst = a.out + S.dst_offset;
-    constexpr int R = 4;
+    constexpr int R = ADX_WPF_R;
     int32_t nx[R];
     auto fetch = [&](uint32_t fr, int32_t& x) {
         x = 0;
         const uint64_t idx = (uint64_t)fr * 32 + s;
-        if (fr < S.frames && idx < S.samples && act) { const uint8_t* p = pcm + (idx * C + half) * 2; x = (int32_t)(int16_t)(p[0] | (p[1] << 8)); }
+        if (fr < row_end && idx < S.samples && act) { const uint8_t* p = pcm + (idx * C + half) * 2; x = (int32_t)(int16_t)(p[0] | (p[1] << 8)); }
     };
 #pragma unroll
-    for (int t = 0; t < R; t++) fetch((uint32_t)t, nx[t]);
-    for (uint32_t f0 = 0; f0 < S.frames; f0 += R) {
+    for (int t = 0; t < R; t++) fetch(row_begin + (uint32_t)t, nx[t]);
+    for (uint32_t f0 = row_begin; f0 < row_end; f0 += R) {
         int32_t xr[R];
 #pragma unroll
         for (int t = 0; t < R; t++) xr[t] = nx[t];
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
 #pragma unroll
         for (int t = 0; t < R; t++) {
             const uint32_t fr = f0 + t;
-            if (fr >= S.frames) break;
+            if (fr >= row_end) break;
             const int32_t x = xr[t];
             // pass A (adx.cpp:221-230): residual against the two previous RAW samples; lanes 0/1 of a block see the carried history
             // (the previous lanes' samples: wave_shr:1 twice; what the first two lanes of a half receive is replaced just below)
@@ -649,8 +652,8 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
             int32_t thr;
             {
                 const int32_t j = (int32_t)s;
-                const int32_t t = j < 8 ? 1 - ((8 - j) * iscale - hs) : (j - 7) * iscale - hs;
-                thr = j < 15 ? t * 4096 : 0x7FFFFFFF;
+                const int32_t tt = j < 8 ? 1 - ((8 - j) * iscale - hs) : (j - 7) * iscale - hs;
+                thr = j < 15 ? tt * 4096 : 0x7FFFFFFF;
             }
             // (a lone wave issues an instruction every four cycles whatever it is, so the instruction count per step matters as
             //  much as the chain: the sample of step k comes to the half's lanes through one crossbar read, the two halves'
@@ -682,6 +685,7 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
                 mine = (int)s == k ? code : mine;
             }
             h1 = silent ? raw1 : g1; h2 = silent ? raw2 : g2;
+            if (fr < store_from) continue;                                             // (wave-uniform) a warm-up row: only the history counts
             // two 4-bit codes per byte, first sample in the high nibble; even lanes hold the byte
             const uint32_t nib = silent ? 0u : ((uint32_t)mine & 15);
             const uint32_t nxt = (uint32_t)__shfl_xor((int)nib, 1);
@@ -693,6 +697,127 @@ __global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
             wave_lds_sync();
             uint8_t* row = dst + (uint64_t)fr * 18 * C;
             if (lane < 18 * C) row[lane] = blk_img[lane];
+        }
+        if (after_round(f0 + R < row_end ? f0 + R : row_end)) break;
+    }
+}
+
+// (an instance per channel count, both launched over all streams: a block whose stream has the other count leaves at once)
+template <int C>
+__global__ __launch_bounds__(64) void k_adx_encode_wpf(AdxArgs a) {
+    __shared__ uint8_t blk_img[40];
+    __shared__ __attribute__((aligned(16))) int32_t xl[64];   // a frame's (sample << 12), by lane
+    const AdxStream S = a.streams[a.wpf_order ? a.wpf_order[blockIdx.x] : blockIdx.x];
+    if (S.channels != (uint32_t)C) return;
+    const uint32_t half = threadIdx.x >> 5;
+    const uint32_t chain = S.first_chain + (half < C ? half : 0);
+    int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+    adx_wpf_rows<C>(a, S, 0, S.frames, 0, h1, h2, blk_img, xl, [](uint32_t) { return false; });
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Segmented chains (encode)
+// ------------------------------------------------------------------------------------------------------------
+// The encoder forgets its history too: the reconstruction it carries from block to block tracks the input within half a
+// quantiser step whatever it started from, and two encodes of the same samples from different histories end up with identical
+// histories -- later than the decoder's merge (the errors are requantised every sample): 120 rows on average for the bench's
+// tonal material, 500 for sparse narrow-band material, 600 / 2200 at worst (coefficients 7400, -3342; oracle-side measurement).
+// The same three passes as for the decoder, a WAVE per (file, segment) because the per-row work is the wave-per-file encoder's:
+//   pass 0   every segment: `warm_rows` rows before it are encoded from the raw samples as history (nothing stored), the state
+//            at the segment's first row is recorded, the segment is encoded and stored, the history after every round of four
+//            rows goes to a checkpoint array (the output holds codes, not histories), the state at the end is recorded;
+//   pass 1   a segment whose start state is not the previous segment's end state is encoded again from the right state until,
+//            at a round's end, BOTH channels' histories equal the checkpoints (the stored blocks from there on are right);
+//            reaching the segment's end with another state than recorded flags the file;
+//   pass 2   flagged files only: the segments in order from the header history, repairing what is still inconsistent.
+// rec[(segment * 2 + channel) * 4] = {start state, end state, end state after repair, -};  AdxStream::rows_avail = the file's
+// first checkpoint (a checkpoint per round and channel).
+__device__ __forceinline__ bool seg_enc_locate(const AdxArgs& a, uint32_t b, AdxStream& S, uint32_t& k) {
+    if (b >= a.seg_lanes) return false;
+    uint32_t lo = 0, hi = a.n_streams;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.seg_first[mid] <= b) lo = mid; else hi = mid; }
+    S = a.streams[lo];
+    k = b - S.first_seg;
+    return k < S.seg_count;
+}
+// re-encode of segment k from (h1, h2) against the checkpoints; true: merged with what is stored before the segment's end
+template <int C>
+__device__ __forceinline__ bool seg_enc_repair(const AdxArgs& a, const AdxStream& S, uint32_t k, int32_t& h1, int32_t& h2, uint8_t* blk_img, int32_t* xl) {
+    const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31;
+    const bool act = half < C;
+    const uint32_t r0 = k * S.seg_rows, r1 = r0 + S.seg_rows < S.frames ? r0 + S.seg_rows : S.frames;
+    bool merged = false;
+    adx_wpf_rows<C>(a, S, r0, r1, r0, h1, h2, blk_img, xl, [&](uint32_t next) {
+        uint32_t* ck = a.seg_ckpt + ((uint64_t)S.rows_avail + (next + ADX_WPF_R - 1) / ADX_WPF_R - 1) * 2 + (act ? half : 0);
+        const uint32_t now = seg_pack(h1, h2), was = *ck;
+        const bool same = !act || was == now;
+        __builtin_amdgcn_wave_barrier();
+        if (act && s == 0) *ck = now;
+        merged = __all(same);
+        return merged;
+    });
+    return merged;
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void k_adx_seg_encode(AdxArgs a, uint32_t pass) {
+    __shared__ uint8_t blk_img[40];
+    __shared__ __attribute__((aligned(16))) int32_t xl[64];
+    const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31;
+    const bool act = half < C;
+    AdxStream S; uint32_t k;
+    if (pass < 2) {
+        if (!seg_enc_locate(a, blockIdx.x, S, k) || S.channels != (uint32_t)C) return;
+    } else {
+        if (blockIdx.x >= a.n_streams) return;
+        S = a.streams[blockIdx.x]; k = 0;
+        if (S.channels != (uint32_t)C || !a.seg_flags[blockIdx.x]) return;
+    }
+    const uint32_t chain = S.first_chain + (act ? half : 0);
+    auto rec_of = [&](uint32_t kk) { return a.seg_state + (((uint64_t)S.first_seg + kk) * 2 + (act ? half : 0)) * 4; };
+    if (pass == 0) {
+        const uint32_t r0 = k * S.seg_rows, r1 = r0 + S.seg_rows < S.frames ? r0 + S.seg_rows : S.frames;
+        const uint32_t w0 = k == 0 ? 0 : (r0 > S.warm_rows ? r0 - S.warm_rows : 0);
+        int32_t h1, h2;
+        if (k == 0) { h1 = a.history[2 * chain]; h2 = a.history[2 * chain + 1]; }
+        else {                                                       // a guess: the raw samples before the warm-up (the reconstruction is near them)
+            const uint8_t* pcm = (S.src_in_scratch ? a.scratch : a.in) + S.src_offset;
+            auto raw = [&](uint64_t idx) { const uint8_t* p = pcm + (idx * C + (act ? half : 0)) * 2; return idx < S.samples ? (int32_t)(int16_t)(p[0] | (p[1] << 8)) : 0; };
+            h1 = w0 ? raw((uint64_t)w0 * 32 - 1) : 0; h2 = w0 ? raw((uint64_t)w0 * 32 - 2) : 0;
+        }
+        uint32_t spec = seg_pack(h1, h2);
+        adx_wpf_rows<C>(a, S, w0, r1, r0, h1, h2, blk_img, xl, [&](uint32_t next) {
+            if (next == r0) spec = seg_pack(h1, h2);
+            if (next > r0 && act && s == 0) a.seg_ckpt[((uint64_t)S.rows_avail + (next + ADX_WPF_R - 1) / ADX_WPF_R - 1) * 2 + half] = seg_pack(h1, h2);
+            return false;
+        });
+        if (act && s == 0) { uint32_t* rec = rec_of(k); const uint32_t e = seg_pack(h1, h2); rec[0] = spec; rec[1] = e; rec[2] = e; rec[3] = 0; }
+    } else if (pass == 1) {
+        if (k == 0) return;
+        const uint32_t prev_end = rec_of(k - 1)[1], mine = rec_of(k)[0];
+        if (!__any(act && prev_end != mine)) return;                 // the speculation was right for every channel
+        int32_t h1, h2;
+        seg_unpack(prev_end, h1, h2);
+        const bool merged = seg_enc_repair<C>(a, S, k, h1, h2, blk_img, xl);
+        const uint32_t e = seg_pack(h1, h2);
+        const bool changed = !merged && act && e != rec_of(k)[1];
+        if (changed && s == 0) rec_of(k)[2] = e;
+        if (__any(changed) && lane == 0) {                           // the next segment started from a stale state
+            uint32_t lo = 0, hi = a.n_streams;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.seg_first[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+            a.seg_flags[lo] = 1u;
+        }
+    } else {
+        int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
+        uint32_t cur = seg_pack(h1, h2), used = cur;
+        for (k = 0; k < S.seg_count; k++) {
+            uint32_t end = rec_of(k)[2];
+            if (__any(act && used != cur)) {                         // the segment's blocks were encoded from `used`
+                seg_unpack(cur, h1, h2);
+                if (!seg_enc_repair<C>(a, S, k, h1, h2, blk_img, xl)) end = seg_pack(h1, h2);
+            }
+            used = rec_of(k)[1];
+            cur = end;
         }
     }
 }
@@ -722,8 +847,6 @@ struct SegLane {
     AdxStream S; uint32_t ch, k, r0, r1, w0; bool valid;
     const uint8_t* src; uint8_t* dst; uint32_t rowb;
 };
-__device__ __forceinline__ uint32_t seg_pack(int32_t h1, int32_t h2) { return ((uint32_t)h1 & 0xFFFFu) | ((uint32_t)h2 << 16); }
-__device__ __forceinline__ void seg_unpack(uint32_t s, int32_t& h1, int32_t& h2) { h1 = (int32_t)(int16_t)(s & 0xFFFF); h2 = (int32_t)(int16_t)(s >> 16); }
 __device__ __forceinline__ bool seg_locate(const AdxArgs& a, uint32_t g, SegLane& X) {
     X.valid = g < a.seg_lanes;
     uint32_t lo = 0, hi = a.n_streams;
@@ -932,6 +1055,15 @@ __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a) {
         if (stop_row != 0xFFFFFFFFu) stopped = true;
         used = rec[1];                                               // what passes 1 and 2 decoded the next segment from
         cur = end;
+    }
+}
+
+void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s) {
+    if (!a.seg_lanes) return;
+    for (uint32_t pass = 0; pass < 3; pass++) {
+        const uint32_t blocks = pass < 2 ? a.seg_lanes : a.n_streams;
+        hipLaunchKernelGGL(k_adx_seg_encode<2>, dim3(blocks), dim3(64), 0, s, a, pass);
+        hipLaunchKernelGGL(k_adx_seg_encode<1>, dim3(blocks), dim3(64), 0, s, a, pass);
     }
 }
 

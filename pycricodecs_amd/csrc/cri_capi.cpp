@@ -128,6 +128,7 @@ struct cri_job {
     bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
     bool adx_seg = false;                        // segmented chains (k_adx_seg_*): long files of the standard layout
     uint64_t adx_seg_flags_offset = 0;           // scratch offset of the per-chain flag words (the lanes' records are at 0)
+    uint64_t adx_seg_state_offset = 0, adx_seg_ckpt_offset = 0;   // encode: records / checkpoints (after the converted PCM)
     CryptArgs crypt{};
     SegmentArgs seg{};                           // USM demux / SFA pack: segment copies (+ audio mask)
     std::vector<uint32_t> item_tags;
@@ -482,14 +483,33 @@ static bool adx_pick_wave_per_file(bool all_std, size_t n_streams, bool encode) 
 static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
     const char* e = getenv("CRICODECS_ADX_MAPPING");
     if (e && (!strcmp(e, "chain") || !strcmp(e, "file"))) return false;
-    if (streams.empty() || encode) return false;
+    if (streams.empty()) return false;
     uint64_t chains = 0;
     for (const AdxStream& S : streams) {
-        if (!(S.blocksize == 18 && S.bitdepth == 4 && (S.mode == 2 || S.mode == 3))) return false;
+        if (!(S.blocksize == 18 && S.bitdepth == 4 && (S.mode == 2 || S.mode == 3 || (encode && S.mode == 4)))) return false;
+        if (encode && S.channels > 2) return false;
         chains += S.channels;
     }
     const char* we = getenv("CRICODECS_ADX_WARM");               // (developer switch: warm-up length in per cent of the default)
     const uint64_t warm_pct = we ? strtoull(we, nullptr, 10) : 100;
+    if (encode) {
+        // a WAVE per (file, segment): four waves per SIMD fill the chip (the wave-per-file encoder's rate stops growing there); the
+        // encoder merges later than the decoder -- 120 rows on average for tonal material, 500 for sparse, at the standard coefficients
+        const uint64_t w_target = std::max<uint64_t>(1, 4096 / streams.size());
+        bool any = false;
+        for (AdxStream& S : streams) {
+            const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
+            S.seg_rows = S.frames; S.seg_count = S.frames ? 1 : 0; S.warm_rows = 0;
+            if (g <= 0 || !S.frames) continue;
+            const uint64_t warm = std::max<uint64_t>(4, (384ull * 39 * warm_pct / 100 / (uint64_t)g + 3) / 4 * 4);
+            uint64_t rows = std::max<uint64_t>((S.frames + w_target - 1) / w_target, 3 * warm);
+            rows = (rows + 3) / 4 * 4;                               // rounds of four rows: checkpoints sit on multiples of four
+            if (rows >= S.frames) continue;
+            S.seg_rows = (uint32_t)rows; S.seg_count = (uint32_t)((S.frames + rows - 1) / rows); S.warm_rows = (uint32_t)warm;
+            any = true;
+        }
+        return any || (e && !strcmp(e, "seg"));
+    }
     const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains);
     bool any = false;
     for (AdxStream& S : streams) {
@@ -1061,13 +1081,30 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     j->adx_streams = (uint32_t)streams.size();
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), true);
     if (j->adx_wave_per_file) j->dominant = "k_adx_encode_wpf";
+    std::vector<uint32_t> seg_first;
+    if (all_std && !streams.empty() && adx_plan_segments(streams, true)) {
+        // segmented chains on the wave-per-file kernel: a workgroup per (file, segment)
+        j->adx_seg = true; j->adx_wave_per_file = false; j->dominant = "k_adx_seg_encode";
+        uint32_t segs = 0; uint64_t rounds = 0;
+        for (AdxStream& S : streams) {
+            S.first_seg = segs; S.rows_avail = (uint32_t)rounds;      // (encode: the stream's first checkpoint)
+            seg_first.push_back(segs);
+            segs += S.seg_count; rounds += (S.frames + 3) / 4;
+        }
+        seg_first.push_back(segs);
+        j->adx.seg_lanes = segs; j->adx.n_streams = (uint32_t)streams.size();
+        j->adx_seg_state_offset = align_up(j->scratch_bytes, 256);
+        j->adx_seg_ckpt_offset = j->adx_seg_state_offset + align_up(32ull * segs, 256);
+        j->adx_seg_flags_offset = j->adx_seg_ckpt_offset + align_up(8ull * rounds, 256);
+        j->scratch_bytes = j->adx_seg_flags_offset + align_up(4ull * streams.size(), 256);
+    }
     const std::vector<uint32_t> order = j->adx_wave_per_file ? adx_longest_first(streams) : std::vector<uint32_t>();
     if (streams.empty()) { AdxStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (chain_stream.empty()) { chain_stream.push_back(0xFFFFFFFFu); history.assign(2, 0); }
     if (stale.empty()) stale.push_back(0);
     int rc = 0;
     if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_chain_stream.upload(chain_stream)) || (rc = j->d_history.upload(history)) ||
-        (!order.empty() && (rc = j->d_adx_order.upload(order))) ||
+        (!order.empty() && !j->adx_seg && (rc = j->d_adx_order.upload(order))) || (!seg_first.empty() && (rc = j->d_seg_chain.upload(seg_first))) ||
         (rc = j->d_stale.upload(stale)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
@@ -1303,6 +1340,16 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
             a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
             a.streams = (const AdxStream*)j->d_adx_streams.p; a.chain_stream = (const uint32_t*)j->d_chain_stream.p;
             a.history = (const int16_t*)j->d_history.p; a.stale = (const uint8_t*)j->d_stale.p; a.wpf_order = (const uint32_t*)j->d_adx_order.p;
+            if (j->adx_seg && j->kind == CRI_JOB_ADX_ENCODE) {
+                uint8_t* sc = (uint8_t*)d_scratch;
+                a.seg_first = (const uint32_t*)j->d_seg_chain.p; a.seg_state = (uint32_t*)(sc + j->adx_seg_state_offset);
+                a.seg_ckpt = (uint32_t*)(sc + j->adx_seg_ckpt_offset); a.seg_flags = (uint32_t*)(sc + j->adx_seg_flags_offset);
+                j->mark(0, true, s);
+                launch_fill_i32((int32_t*)a.seg_flags, 0, a.n_streams, s);
+                launch_adx_encode_seg(a, s);
+                j->mark(0, false, s);
+                break;
+            }
             if (j->adx_seg) {
                 a.seg_first = (const uint32_t*)j->d_seg_chain.p; a.seg_state = (uint32_t*)d_scratch;
                 a.seg_flags = (uint32_t*)((uint8_t*)d_scratch + j->adx_seg_flags_offset);

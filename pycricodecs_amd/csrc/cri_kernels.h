@@ -68,6 +68,7 @@ struct AdxArgs {
     // segmented chains: first (segment, channel) lane of every stream (n_streams + 1 entries), the lanes' records
     // {speculative start state, end state, end state after repair, stop row} and one flag word per (stream, channel) chain
     const uint32_t* seg_first; uint32_t n_streams, seg_lanes; uint32_t* seg_state; uint32_t* seg_flags;
+    uint32_t* seg_ckpt;            // encode: the history after every round of four rows, per channel (the output holds codes, not histories)
 };
 void launch_adx_decode(const AdxArgs& a, hipStream_t s);
 void launch_adx_encode(const AdxArgs& a, hipStream_t s);
@@ -76,6 +77,7 @@ void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
 void launch_adx_encode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
 // segmented chains (standard layout): speculative decode of all segments, parallel repair, serial repair of flagged chains
 void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s);
+void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s);
 
 struct CryptArgs {
     const uint8_t* in; uint8_t* out;

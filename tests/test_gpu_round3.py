@@ -313,3 +313,53 @@ def test_adx_ten_second_file_takes_the_segmented_path(cc):
     a0 = O.adx_encode(w, 4, 18, 3, 0, 0, 4)
     assert Job.adx_decode([a0]).dominant_kernel != "k_adx_seg_decode"
     assert cc.AdxDecode(a0) == O.adx_decode(a0)
+
+
+# ------------------------------------------------------------------------------------------------ a5 / a6: segmented ADX encode
+def _enc_wavs():
+    rng = np.random.default_rng(321)
+    wavs = [synth.wav(1500, 32 * 900, 2, 48000), synth.wav(1501, 32 * 1300 + 7, 1, 48000), synth.wav(1502, 32 * 640, 2, 44100),
+            synth.wav(1503, 32 * 50, 2, 48000), synth.wav(1504, 31, 1, 48000)]
+    quiet = synth.pcm16(1505, 32 * 800, 2, 48000)
+    quiet[32 * 200:32 * 330] = 0                                # digital silence in the middle: silent blocks keep the RAW history (adx.cpp:231-234)
+    quiet[32 * 500:32 * 501] = 0
+    wavs.append(synth.wav_bytes(quiet, 48000))
+    loud = rng.integers(-32768, 32768, (32 * 700, 2)).astype(np.int16)          # full-scale noise: clamps everywhere
+    loud[:64] = 0
+    wavs.append(synth.wav_bytes(loud, 48000))
+    return wavs
+
+
+@pytest.mark.parametrize("mode,hp", [(3, 500), (4, 500), (2, 500), (3, 2000)])
+@pytest.mark.parametrize("warm", ["100", "5", "1"])
+def test_adx_segmented_encode_vs_oracle(cc, monkeypatch, warm, mode, hp):
+    """k_adx_seg_encode: files cut into segments, each encoded by a wave of its own from a warm-up, verified against the previous
+    segment's end state and repaired (passes 0 / 1 / 2).  At 5 % and 1 % of the default warm-up nearly every speculation is wrong
+    and the repair passes write most of the bytes -- which are the oracle's either way."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "seg")
+    monkeypatch.setenv("CRICODECS_ADX_WARM", warm)
+    wavs = _enc_wavs()
+    job = Job.adx_encode(wavs, mode=mode, highpass=hp)
+    assert job.dominant_kernel == "k_adx_seg_encode"
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, w) in enumerate(zip(outs, wavs)):
+        assert bytes(o) == O.adx_encode(w, 4, 18, mode, hp, 0, 4), i
+    outs, st = job.run_host()
+    for i, (o, w) in enumerate(zip(outs, wavs)):
+        assert bytes(o) == O.adx_encode(w, 4, 18, mode, hp, 0, 4), i
+
+
+def test_adx_ten_second_file_encodes_in_segments(cc):
+    """The drop-in AdxEncode on a 10 s stereo file runs as a dozen segments by default (two chains of 480 000 dependent steps
+    otherwise); typed (24-bit) input goes through the conversion scratch first; high-pass 0 stays one segment."""
+    from pycricodecs_amd.batch import Job
+    w = synth.wav(1600, 480000, 2, 48000)
+    assert Job.adx_encode([w]).dominant_kernel == "k_adx_seg_encode"
+    assert cc.AdxEncode(w, 4, 18, 3, 500, 0, 4, False) == O.adx_encode(w)
+    w24 = synth.wav_typed(1601, 32 * 5000, 2, 48000, "s24")
+    assert Job.adx_encode([w24]).dominant_kernel == "k_adx_seg_encode"
+    assert cc.AdxEncode(w24, 4, 18, 3, 500, 0, 4, False) == O.adx_encode(w24)
+    assert Job.adx_encode([w], highpass=0).dominant_kernel != "k_adx_seg_encode"
+    assert cc.AdxEncode(w, 4, 18, 3, 0, 0, 4, False) == O.adx_encode(w, 4, 18, 3, 0, 0, 4)
