@@ -28,12 +28,21 @@ namespace cri {
 
 // Developer instrumentation (-DCRI_ENC_PROFILE through CRI_HIPCC_EXTRA): cycles per phase of k_hca_encode, summed over frames
 #ifdef CRI_ENC_PROFILE
-__device__ unsigned long long g_enc_prof[1024][16];      // spread over 1024 slots so the atomics do not serialise on one address
+__device__ unsigned long long g_enc_prof[1024][24];      // spread over 1024 slots so the atomics do not serialise on one address
 #define ENC_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
-#define ENC_PROF_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_enc_prof[g & 1023][k_], prof_acc[k_]); } while (0)
+#define ENC_PROF_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 24; k_++) atomicAdd(&g_enc_prof[g & 1023][k_], prof_acc[k_]); } while (0)
 #else
 #define ENC_MARK(k) do {} while (0)
 #define ENC_PROF_FLUSH() do {} while (0)
+#endif
+#ifdef CRI_ENC_PROFILE
+#define ENC_COUNT(k, n) do { prof_acc[k] += (n); } while (0)
+#define ENC_TIC() const unsigned long long tic_ = __builtin_readcyclecounter()
+#define ENC_TOC(k) do { prof_acc[k] += __builtin_readcyclecounter() - tic_; } while (0)
+#else
+#define ENC_COUNT(k, n) do {} while (0)
+#define ENC_TIC() do {} while (0)
+#define ENC_TOC(k) do {} while (0)
 #endif
 
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v);
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
     };
 
 #ifdef CRI_ENC_PROFILE
-    unsigned long long prof_acc[16] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
+    unsigned long long prof_acc[24] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     // ---- MDCT of every (channel, subframe): hca.cpp:2529-2553 (window + fold), 2481-2527 (DCT-IV), in registers.
     // Four transforms at a time: slot = lane >> 4 picks the transform, its 16 lanes hold the 64 complex points of the
@@ -591,6 +600,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             bool over = false;                             // "mid_value > available bits" of the last step (hca.cpp:2806-2815)
             while (low != high) {
                 const int mid = (low + high) / 2;
+                ENC_COUNT(16, 1);
                 if constexpr (CT > 0) {
                     // the same decision from per-resolution bounds when they settle it (far from the answer they do): the
                     // fewest / most bits a band of that resolution can take, summed -- no quantisation of the spectra
@@ -602,7 +612,9 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                     if (least > avail) over = true;
                     else if (most <= avail) over = false;
                     else {
+                        ENC_TIC();
                         over = used_bits(mid, 0) > avail;
+                        ENC_TOC(18); ENC_COUNT(17, 1);
                         if (over) { over_noise = mid; _Pragma("unroll") for (int b = 0; b < NB; b++) over_bits[b] = last[b]; }
                         else { fit_noise = mid; _Pragma("unroll") for (int b = 0; b < NB; b++) fit_bits[b] = last[b]; }
                     }
@@ -863,10 +875,10 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
 
 #ifdef CRI_ENC_PROFILE
 extern "C" int cri_debug_enc_profile(unsigned long long* out16, int reset) {
-    static unsigned long long h[1024][16];
-    if (out16) {
+    static unsigned long long h[1024][24];
+    if (out16) {                                             // (24 values: 16 phases, then rate-loop detail)
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(cri::g_enc_prof), sizeof h) != hipSuccess) return -1;
-        for (int k = 0; k < 16; k++) { out16[k] = 0; for (int s = 0; s < 1024; s++) out16[k] += h[s][k]; }
+        for (int k = 0; k < 24; k++) { out16[k] = 0; for (int s = 0; s < 1024; s++) out16[k] += h[s][k]; }
     }
     if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(cri::g_enc_prof), h, sizeof h) != hipSuccess) return -1; }
     return 0;
