@@ -326,14 +326,11 @@ def committed_traffic(units, dom):
     return out
 
 
-VALU_PEAK_PER_S = 520e9       # wave64 VALU instructions per second the chip retires: 256 CUs x 1 per clock (a wave64 instruction holds its
-                              # SIMD for 4 cycles, 4 SIMDs per CU) at the ~2.03 GHz it holds under this load
-
-
 def committed_valu(units, kernel_ms):
-    """What bounds the HCA decode kernels is VALU issue, not HBM: instructions per frame from the committed SQ counter passes of this
-    path (profiles/r*_pmc_1000streams.json: SQ_INSTS_VALU per dispatch / frames), the time those instructions need at the chip's
-    issue rate (floor_ms) and the share of each kernel's measured time they fill (busy)."""
+    """What bounds the HCA decode kernels is VALU issue, not HBM: from the committed SQ counter passes of this path
+    (profiles/r*_pmc_1000streams.json) the wave64 VALU instructions per frame and `busy` = the share of a kernel's cycles its SIMDs
+    spend issuing them (4 cycles each on one of 1024 SIMDs, against GRBM_GUI_ACTIVE: clock-independent).  floor_ms = the time this
+    run's kernels would take if VALU issue were all they did (busy x measured time)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1000streams.json")))
     if not files:
         return None
@@ -345,14 +342,13 @@ def committed_valu(units, kernel_ms):
         if not cls or "VALU_per_frame" not in k:
             continue
         per[cls] = k["VALU_per_frame"]
-        ms = k["VALU_per_frame"] * units / VALU_PEAK_PER_S * 1e3
-        floor += ms
-        if kernel_ms.get(cls):
-            busy[cls] = round(ms / kernel_ms[cls], 3)
+        if "valu_busy" in k:
+            busy[cls] = k["valu_busy"]
+            floor += k["valu_busy"] * kernel_ms.get(cls, 0.0)
     if not per:
         return None
-    return {"valu": {"insts_per_frame": per, "peak_insts_per_s": VALU_PEAK_PER_S, "floor_ms": round(floor, 3), "busy": busy,
-                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU, counters-only passes)" % os.path.basename(files[-1])}}
+    return {"valu": {"insts_per_frame": per, "busy": busy, "floor_ms": round(floor, 3) if busy else None,
+                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE, counters-only passes, 1000-stream batch)" % os.path.basename(files[-1])}}
 
 
 # ------------------------------------------------------------------------------------------------ workloads

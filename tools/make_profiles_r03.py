@@ -78,7 +78,8 @@ def main(tag):
     # ---- SQ counters
     sq = {"_about": "rocprofv3 --pmc passes (counters only, no trace domains; tools/prof_r03.sh) at commit %s: average per dispatch over 1000-stream batches "
                     "(469 000 frames).  SQ_ACTIVE_INST_VALU is in quad-cycles (= SQ_INSTS_VALU: a wave64 VALU instruction holds its SIMD for 4 cycles).  "
-                    "VALU_per_frame = SQ_INSTS_VALU / frames: bench.py turns it into the VALU floor of the HCA decode line." % commit,
+                    "VALU_per_frame = SQ_INSTS_VALU / frames; valu_busy = 4 * SQ_INSTS_VALU / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): the share of the "
+                    "kernel's cycles its SIMDs spend issuing VALU instructions (clock-independent).  bench.py quotes both in the HCA decode line." % commit,
           "frames_per_dispatch": FRAMES_1000, "kernels": {}, "workloads": {}}
     for w in ("hca_decode", "hca_decode_sparse", "hca_encode", "adx_roundtrip"):
         for k, v in raw.get(w, {}).items():
@@ -87,6 +88,9 @@ def main(tag):
             ent = {c: v[c] for c in sorted(v) if c.startswith("SQ_") or c.startswith("GRBM")}
             if "SQ_INSTS_VALU" in v and w != "adx_roundtrip":
                 ent["VALU_per_frame"] = round(v["SQ_INSTS_VALU"] / FRAMES_1000, 1)
+            if "SQ_INSTS_VALU" in v and v.get("GRBM_GUI_ACTIVE"):
+                # a wave64 VALU instruction holds one of the chip's 1024 SIMDs for 4 cycles; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles
+                ent["valu_busy"] = round(v["SQ_INSTS_VALU"] * 4 / 1024 / (v["GRBM_GUI_ACTIVE"] / 8), 3)
             if w == "hca_decode":
                 sq["kernels"][short(k)] = ent
             sq["workloads"].setdefault(w, {})[short(k)] = ent
