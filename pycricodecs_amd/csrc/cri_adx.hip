@@ -12,6 +12,7 @@
 //   3. the wave copies the output regions to HBM, again 256 contiguous bytes per instruction.
 // File regions in LDS are padded by 4 bytes each so that the lanes of a wave fall on different banks.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "cri_kernels.h"
 #include "cri_device.h"
 #include "../../include/cricodecs_hip.h"
@@ -1056,6 +1057,288 @@ __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a) {
         used = rec[1];                                               // what passes 1 and 2 decoded the next segment from
         cur = end;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Segmented chains (encode), a LANE per (file, channel, segment): batches of many files
+// ------------------------------------------------------------------------------------------------------------
+// The wave-per-(file, segment) encoder above spends a wave's 64 lanes on two chains; with hundreds of files that is what its
+// time is made of (its VALU pipes are busy 93 % of the time, profiles/r03_a_pmc_1000streams.json).  Here every (file, channel,
+// segment) is one lane and a block row is ~1000 instructions for 64 chains at once.  There is no warm-up: pass 0 encodes every
+// segment from a guessed history (the raw samples before it), pass 1 encodes every segment AGAIN from the previous segment's
+// recorded end state until the history at a checkpoint (every four rows) equals what pass 0 left there -- for most segments some
+// hundred rows -- and pass 2 walks flagged files.  The two lanes of a stereo pair move in lock step (they share the loads of
+// a row's samples and the stores of its two blocks), so a pair repairs together and merges when both channels have.
+// Records and checkpoints as for the wave form: rec[(lane) * 4] = {start state, end state, end state after repair, -},
+// checkpoint ((file's first + round) * 2 + channel).  Standard layout, one or two channels.
+struct EncLane {
+    AdxStream S; uint32_t ch, k, r0, r1, stream; bool valid;
+    const uint8_t* pcm; uint8_t* dst;
+};
+__device__ __forceinline__ bool enc_lane_locate(const AdxArgs& a, uint32_t g, EncLane& X) {
+    X.valid = g < a.seg_lanes;
+    uint32_t lo = 0, hi = a.n_streams;
+    const uint32_t gg = X.valid ? g : 0;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.seg_first[mid] <= gg) lo = mid; else hi = mid; }
+    X.S = a.streams[lo]; X.stream = lo;
+    const uint32_t local = gg - X.S.first_seg, C = X.S.channels;
+    X.k = local / C; X.ch = local - X.k * C;
+    if (X.k >= X.S.seg_count) { X.valid = false; X.k = 0; X.ch = 0; }           // (a padding lane: stereo pairs start on even lanes)
+    X.r0 = X.k * X.S.seg_rows;
+    X.r1 = X.r0 + X.S.seg_rows < X.S.frames ? X.r0 + X.S.seg_rows : X.S.frames;
+    X.pcm = (X.S.src_in_scratch ? a.scratch : a.in) + X.S.src_offset; X.dst = a.out + X.S.dst_offset;
+    return X.valid;
+}
+// this lane's channel of row `row`: 32 samples.  A stereo pair loads the row's 128 bytes once (64 per lane) and trades halves.
+__device__ __forceinline__ void enc_lane_load(const EncLane& X, uint32_t row, int32_t (&x)[32]) {
+    const uint32_t C = X.S.channels;
+    const bool whole = (uint64_t)(row + 1) * 32 <= X.S.samples;      // (samples past the input are zero padding, adx.cpp:453-456)
+    if (whole && C == 2) {
+        const uint4* p = (const uint4*)(X.pcm + ((uint64_t)row * 32 + 16 * X.ch) * 4);
+        uint32_t own[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { uint4 v; __builtin_memcpy(&v, p + j, 16); own[4 * j] = v.x; own[4 * j + 1] = v.y; own[4 * j + 2] = v.z; own[4 * j + 3] = v.w; }
+        // lane ch 0 holds samples 0..15 of both channels, lane ch 1 samples 16..31: one permute per dword makes {x[i], x[16 + i]} of MY channel
+        const uint32_t sel = X.ch ? 0x03020706u : 0x05040100u;       // ch 0: own.lo | partner.lo << 16;  ch 1: partner.hi | own.hi << 16
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t partner = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own[i], 0xB1, 0xF, 0xF, true);
+            const uint32_t pr = __builtin_amdgcn_perm(partner, own[i], sel);
+            x[i] = (int32_t)(int16_t)(pr & 0xFFFF); x[16 + i] = (int32_t)pr >> 16;
+        }
+        return;
+    }
+    if (whole && C == 1) {
+        const uint8_t* p = X.pcm + (uint64_t)row * 64;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint4 v; __builtin_memcpy(&v, p + 16 * j, 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) { x[8 * j + 2 * q] = (int32_t)(int16_t)(w[q] & 0xFFFF); x[8 * j + 2 * q + 1] = (int32_t)w[q] >> 16; }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint64_t idx = (uint64_t)row * 32 + i;
+        int16_t v = 0;
+        if (idx < X.S.samples) __builtin_memcpy(&v, X.pcm + (idx * C + X.ch) * 2, 2);
+        x[i] = v;
+    }
+}
+// ChannelFrame::Encode (adx.cpp:215-273) of one block on registers: the scale word, the 16 code bytes as four little-endian
+// words, the new history.  (The quantiser is k_adx_encode's float form: exact for |delta| capped at (limit + 2) * scale.)
+__device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t (&x)[32], int32_t& h1, int32_t& h2, uint32_t& word, uint32_t (&cw)[4]) {
+    const int32_t c0 = S.coef0, c1 = S.coef1;
+    int32_t mn = 0, mx = 0, p1 = h1, p2 = h2;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {                                   // pass A: residual range against the RAW history
+        const int32_t r = ((int32_t)((uint32_t)x[i] << 12) - __mul24(c0, p1) - __mul24(c1, p2)) >> 12;
+        mn = r < mn ? r : mn; mx = r > mx ? r : mx;
+        p2 = p1; p1 = x[i];
+    }
+    if (!mn && !mx) { word = 0; cw[0] = cw[1] = cw[2] = cw[3] = 0; h1 = x[31]; h2 = x[30]; return; }      // adx.cpp:231-234: the history stays raw
+    const int32_t qa = mx / 7, qb = (int32_t)((uint32_t)(-mn) >> 3);
+    uint32_t scale = (uint32_t)(qa > qb ? qa : qb) & 0xFFFF;
+    if (scale > 0x1000) scale = 0x1000;
+    if (S.mode == 4) {
+        const uint32_t power = scale ? (32 - __clz((int)scale)) : 0;
+        scale = (1u << power) & 0xFFFF;
+        word = (uint32_t)(12 - (int32_t)power) & 0xFFFF;
+    } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
+    else word = scale;
+    if (!scale) scale = 1;
+    const float rcp = 1.0f / (float)scale, half_rcp = 0.5f * rcp;
+    const int32_t hs = (int32_t)(scale >> 1), cap = 9 * (int32_t)scale, iscale = (int32_t)scale;
+    int32_t g1 = h1, g2 = h2;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                                // pass B (adx.cpp:254-271)
+            const int32_t v = x[8 * w + i];
+            const int32_t pred = __mul24(c0, g1) + __mul24(c1, g2);
+            const int32_t d = ((int32_t)((uint32_t)v << 12) - pred) >> 12;
+            const bool neg = d < 0;
+            int32_t an = (neg ? -d : d) + hs;
+            an = an < cap ? an : cap;
+            int32_t q = (int32_t)__builtin_fmaf((float)an, rcp, half_rcp);
+            const int32_t qmax = neg ? 8 : 7;
+            q = q < qmax ? q : qmax;
+            const int32_t code = neg ? -q : q;
+            int32_t sim = (int32_t)(((uint32_t)__mul24(code, iscale) << 12) + (uint32_t)pred) >> 12;
+            sim = clamp_sym(sim, 0x7FFF);
+            g2 = g1; g1 = sim;
+            acc = (acc << 4) | ((uint32_t)code & 15u);               // first sample in the high nibble of the first byte
+        }
+        cw[w] = __builtin_bswap32(acc);
+    }
+    h1 = g1; h2 = g2;
+}
+// the row's blocks to the file.  Stereo: the pair's 36 bytes are nine aligned words; lane ch 0 stores words 0..4 (the last one
+// carries its own last two code bytes and the partner's scale word), lane ch 1 words 5..8.
+__device__ __forceinline__ void enc_lane_store(const EncLane& X, uint32_t row, uint32_t word, const uint32_t (&cw)[4], bool pair) {
+    const uint32_t C = X.S.channels;
+    const uint32_t sw = ((word >> 8) & 0xFF) | ((word & 0xFF) << 8);                 // big-endian scale word
+    if (pair) {
+        const uint32_t psw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sw, 0xB1, 0xF, 0xF, true);
+        uint32_t* q = (uint32_t*)(X.dst + (uint64_t)row * 36);
+        if (X.ch == 0) {
+            typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+            *(u4u*)q = u4u{sw | (cw[0] << 16), __builtin_amdgcn_alignbit(cw[1], cw[0], 16), __builtin_amdgcn_alignbit(cw[2], cw[1], 16), __builtin_amdgcn_alignbit(cw[3], cw[2], 16)};
+            q[4] = (cw[3] >> 16) | (psw << 16);
+        } else {
+            typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+            *(u4u*)(q + 5) = u4u{cw[0], cw[1], cw[2], cw[3]};
+        }
+        return;
+    }
+    uint8_t* q = X.dst + ((uint64_t)row * C + X.ch) * 18;
+    const uint16_t s16 = (uint16_t)sw;
+    __builtin_memcpy(q, &s16, 2);
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const uint16_t lo = (uint16_t)cw[w], hi = (uint16_t)(cw[w] >> 16); __builtin_memcpy(q + 2 + 4 * w, &lo, 2); __builtin_memcpy(q + 4 + 4 * w, &hi, 2); }
+}
+
+// pass 0: every segment from a guessed history; pass 1: again from the recorded end of the previous one, until merged
+__global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass) {
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    EncLane X;
+    enc_lane_locate(a, g, X);
+    const AdxStream& S = X.S;
+    const uint32_t C = S.channels, chain = S.first_chain + X.ch;
+    const bool pair = C == 2;                                        // (a pair's lanes are g, g ^ 1: the planner starts stereo files on even lanes)
+    uint32_t* rec = a.seg_state + 4 * (uint64_t)(X.valid ? g : 0);
+    uint32_t* ck = a.seg_ckpt + ((uint64_t)S.rows_avail * 2 + X.ch);
+    int32_t h1 = 0, h2 = 0;
+    bool run = X.valid && X.r1 > X.r0;
+    uint32_t want_end = 0;
+    if (pass == 0) {
+        if (X.valid) {
+            if (X.k == 0) { h1 = a.history[2 * chain]; h2 = a.history[2 * chain + 1]; }
+            else {
+                auto raw = [&](uint64_t idx) { int16_t v = 0; if (idx < S.samples) __builtin_memcpy(&v, X.pcm + (idx * C + X.ch) * 2, 2); return (int32_t)v; };
+                h1 = raw((uint64_t)X.r0 * 32 - 1); h2 = raw((uint64_t)X.r0 * 32 - 2);
+            }
+            rec[0] = seg_pack(h1, h2);
+        }
+    } else {
+        bool mis = false;
+        if (X.valid && X.k > 0) {
+            const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - C) + 1];
+            mis = prev_end != rec[0];
+            seg_unpack(prev_end, h1, h2);
+            want_end = rec[1];
+        }
+        // (the exchange runs in every lane, outside any condition on `mis`: a lane that is masked off reads as 0)
+        const bool partner_mis = __builtin_amdgcn_update_dpp(0, (int)mis, 0xB1, 0xF, 0xF, true) != 0;
+        const bool pmis = mis || (pair && partner_mis);
+        run = run && X.k > 0 && pmis;                                // the pair repairs together: the channel that was right re-encodes the same bytes
+    }
+    uint32_t nrows = run ? X.r1 - X.r0 : 0, nmax = nrows;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
+    bool merged = false;
+    for (uint32_t t = 0; t < nmax; t++) {
+        const bool act = run && t < nrows && !merged;
+        if (__builtin_expect(!__any(act), 0)) break;
+        if (act) {
+            const uint32_t row = X.r0 + t;
+            int32_t x[32];
+            enc_lane_load(X, row, x);
+            uint32_t word, cw[4];
+            enc_lane_block(S, x, h1, h2, word, cw);
+            enc_lane_store(X, row, word, cw, pair);
+            if (((row + 1) & 3) == 0 || row + 1 == X.r1) {
+                uint32_t* c = ck + (uint64_t)((row + 4) / 4 - 1) * 2;
+                const uint32_t now = seg_pack(h1, h2);
+                if (pass == 0) *c = now;
+                else {
+                    const bool mine = *c == now;
+                    *c = now;
+                    const bool partner_same = __builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true) != 0;
+                    merged = mine && (!pair || partner_same);
+                }
+            }
+        }
+    }
+    if (!X.valid) return;
+    const uint32_t e = seg_pack(h1, h2);
+    if (pass == 0) { rec[1] = e; rec[2] = e; rec[3] = 0; }
+    else if (run && !merged && e != want_end) { rec[2] = e; a.seg_flags[X.stream] = 1u; }   // the next segment started from a stale state
+}
+
+// pass 2: flagged files, a lane (pair) per file, the segments in order
+__global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a) {
+    const uint32_t chain = blockIdx.x * 64 + threadIdx.x;
+    EncLane X;
+    X.valid = chain < a.chains;
+    uint32_t lo = 0, hi = a.n_streams;
+    const uint32_t cc = X.valid ? chain : 0;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_chain <= cc) lo = mid; else hi = mid; }
+    X.S = a.streams[lo]; X.stream = lo;
+    const AdxStream& S = X.S;
+    X.ch = cc - S.first_chain;
+    if (X.ch >= S.channels) { X.valid = false; X.ch = 0; }
+    X.pcm = (S.src_in_scratch ? a.scratch : a.in) + S.src_offset; X.dst = a.out + S.dst_offset;
+    const uint32_t C = S.channels;
+    const bool pair = C == 2;
+    const bool go = X.valid && a.seg_flags[lo] != 0;
+    if (!__any(go)) return;
+    int32_t h1 = 0, h2 = 0;
+    if (go) { h1 = a.history[2 * cc]; h2 = a.history[2 * cc + 1]; }
+    uint32_t cur = seg_pack(h1, h2), used = cur;
+    uint32_t* ck = a.seg_ckpt + ((uint64_t)S.rows_avail * 2 + X.ch);
+    uint32_t kmax = go ? S.seg_count : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)kmax, o); kmax = t > kmax ? t : kmax; }
+    for (uint32_t k = 0; k < kmax; k++) {
+        const bool on = go && k < S.seg_count;
+        uint32_t* rec = a.seg_state + 4 * ((uint64_t)S.first_seg + (uint64_t)(on ? k : 0) * C + X.ch);
+        uint32_t end = on ? rec[2] : 0;
+        bool mis = on && used != cur;
+        const bool partner_mis = __builtin_amdgcn_update_dpp(0, (int)mis, 0xB1, 0xF, 0xF, true) != 0;
+        const bool pmis = mis || (pair && partner_mis);
+        const bool run = on && pmis;                                 // the segment's blocks were encoded from `used`
+        X.k = k; X.r0 = k * S.seg_rows; X.r1 = X.r0 + S.seg_rows < S.frames ? X.r0 + S.seg_rows : S.frames;
+        uint32_t nrows = run ? X.r1 - X.r0 : 0, nmax = nrows;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
+        if (run) seg_unpack(cur, h1, h2);
+        bool merged = false;
+        for (uint32_t t = 0; t < nmax; t++) {
+            const bool act = run && t < nrows && !merged;
+            if (!__any(act)) break;
+            if (act) {
+                const uint32_t row = X.r0 + t;
+                int32_t x[32];
+                enc_lane_load(X, row, x);
+                uint32_t word, cw[4];
+                enc_lane_block(S, x, h1, h2, word, cw);
+                enc_lane_store(X, row, word, cw, pair);
+                if (((row + 1) & 3) == 0 || row + 1 == X.r1) {
+                    uint32_t* c = ck + (uint64_t)((row + 4) / 4 - 1) * 2;
+                    const uint32_t now = seg_pack(h1, h2);
+                    const bool mine = *c == now;
+                    *c = now;
+                    const bool partner_same = __builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true) != 0;
+                    merged = mine && (!pair || partner_same);
+                }
+            }
+        }
+        if (run && !merged) end = seg_pack(h1, h2);
+        if (on) { used = rec[1]; cur = end; }
+    }
+}
+
+void launch_adx_encode_lane(const AdxArgs& a, hipStream_t s) {
+    if (!a.seg_lanes) return;
+    const char* e = getenv("CRI_LANE_PASSES");
+    const int m = e ? atoi(e) : 7;
+    if (m & 1) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 0u);
+    if (m & 2) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 1u);
+    if (m & 4) hipLaunchKernelGGL(k_adx_lane_encode_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
 }
 
 void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s) {

@@ -127,6 +127,7 @@ struct cri_job {
     uint32_t adx_streams = 0;                    // number of valid ADX streams
     bool adx_wave_per_file = false;              // few chains, standard layout: use the wave-per-file kernels
     bool adx_seg = false;                        // segmented chains (k_adx_seg_*): long files of the standard layout
+    bool adx_lane = false;                       // encode: a lane per (file, channel, segment) (k_adx_lane_encode) instead of a wave per (file, segment)
     uint64_t adx_seg_flags_offset = 0;           // scratch offset of the per-chain flag words (the lanes' records are at 0)
     uint64_t adx_seg_state_offset = 0, adx_seg_ckpt_offset = 0;   // encode: records / checkpoints (after the converted PCM)
     CryptArgs crypt{};
@@ -1082,7 +1083,53 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     j->adx_wave_per_file = adx_pick_wave_per_file(all_std, streams.size(), true);
     if (j->adx_wave_per_file) j->dominant = "k_adx_encode_wpf";
     std::vector<uint32_t> seg_first;
-    if (all_std && !streams.empty() && adx_plan_segments(streams, true)) {
+    // Segmented chains.  Many files: a LANE per (file, channel, segment) -- no warm-up, every segment is encoded twice at its start
+    // (k_adx_lane_encode); few files: a WAVE per (file, segment) on the wave-per-file encoder (k_adx_seg_encode).
+    // CRICODECS_ADX_MAPPING = "lane" / "wave" forces one of the two where segments apply.
+    const char* map_env = getenv("CRICODECS_ADX_MAPPING");
+    const bool want_lane = all_std && !streams.empty() && !(map_env && (!strcmp(map_env, "chain") || !strcmp(map_env, "file") || !strcmp(map_env, "wave") || !strcmp(map_env, "seg"))) &&
+                           (streams.size() >= 128 || (map_env && !strcmp(map_env, "lane")));
+    if (want_lane) {
+        uint64_t chains_total = 0;
+        for (const AdxStream& S : streams) chains_total += S.channels;
+        const char* we = getenv("CRICODECS_ADX_WARM");
+        const uint64_t pct = we ? strtoull(we, nullptr, 10) : 100;
+        const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains_total);
+        uint32_t lanes = 0, chains = 0; uint64_t rounds = 0;
+        std::vector<int16_t> hist2;
+        bool usable = true;
+        for (AdxStream& S : streams) {
+            const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
+            // a segment has to be longer than the encoder's merge time (600 rows at worst for tonal material, 2200 for sparse, at g = 39)
+            uint64_t rows = S.frames;
+            if (g > 0 && S.frames) {
+                const uint64_t lmin = std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4);
+                rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, lmin);
+                rows = (rows + 3) / 4 * 4;
+                if (rows > S.frames) rows = S.frames;
+            }
+            if (S.channels > 2) usable = false;
+            S.seg_rows = (uint32_t)rows; S.seg_count = S.frames ? (uint32_t)((S.frames + rows - 1) / rows) : 0; S.warm_rows = 0;
+            if (S.channels == 2 && (lanes & 1)) lanes++;
+            if (S.channels == 2 && (chains & 1)) { chains++; hist2.push_back(0); hist2.push_back(0); }
+            S.first_seg = lanes; S.rows_avail = (uint32_t)rounds;
+            seg_first.push_back(lanes);
+            for (uint32_t c = 0; c < S.channels; c++) { hist2.push_back(history[2 * (S.first_chain + c)]); hist2.push_back(history[2 * (S.first_chain + c) + 1]); }
+            S.first_chain = chains; S.hist_offset = chains;
+            lanes += S.seg_count * S.channels; chains += S.channels; rounds += (S.frames + 3) / 4;
+        }
+        seg_first.push_back(lanes);
+        if (usable) {
+            j->adx_seg = true; j->adx_lane = true; j->adx_wave_per_file = false; j->dominant = "k_adx_lane_encode";
+            history.swap(hist2);
+            j->adx.chains = chains; j->adx.seg_lanes = lanes; j->adx.n_streams = (uint32_t)streams.size();
+            j->adx_seg_state_offset = align_up(j->scratch_bytes, 256);
+            j->adx_seg_ckpt_offset = j->adx_seg_state_offset + align_up(16ull * lanes, 256);
+            j->adx_seg_flags_offset = j->adx_seg_ckpt_offset + align_up(8ull * rounds, 256);
+            j->scratch_bytes = j->adx_seg_flags_offset + align_up(4ull * streams.size(), 256);
+        } else seg_first.clear();
+    }
+    if (!j->adx_lane && all_std && !streams.empty() && adx_plan_segments(streams, true)) {
         // segmented chains on the wave-per-file kernel: a workgroup per (file, segment)
         j->adx_seg = true; j->adx_wave_per_file = false; j->dominant = "k_adx_seg_encode";
         uint32_t segs = 0; uint64_t rounds = 0;
@@ -1346,7 +1393,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
                 a.seg_ckpt = (uint32_t*)(sc + j->adx_seg_ckpt_offset); a.seg_flags = (uint32_t*)(sc + j->adx_seg_flags_offset);
                 j->mark(0, true, s);
                 launch_fill_i32((int32_t*)a.seg_flags, 0, a.n_streams, s);
-                launch_adx_encode_seg(a, s);
+                if (j->adx_lane) launch_adx_encode_lane(a, s); else launch_adx_encode_seg(a, s);
                 j->mark(0, false, s);
                 break;
             }

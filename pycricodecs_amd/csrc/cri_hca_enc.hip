@@ -74,8 +74,11 @@ struct EncTab {
     const uint8_t* sfbase;                                                  // [32] entries of deq[0..62] that are <= 2^(j - 25)
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
     const uint32_t* bnd;                                                    // [16] per resolution: fewest | most << 16 bits one spectrum can take
+    const uint32_t* gb;                                                     // [64] bnd[curve[position]]: the bounds straight from the curve position
+    const int16_t* rowoff;                                                  // [16] resolution r < 8: r * 16 - shiftDown(r), so that clen[rowoff + (int)t] is the code length
+                                                                            // of the quantised spectrum t (hca.cpp:2778-2784 without its double arithmetic per band)
 };
-#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32 + 64)
+#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32 + 64 + 256 + 32)
 __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads, const uint16_t* crc_mul) {
     float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 72;
     float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
@@ -83,6 +86,8 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
     uint16_t* cm = (uint16_t*)(shuf + 128);
     uint8_t* sfb = (uint8_t*)(cm + 96);
     uint32_t* bnd = (uint32_t*)(sfb + 32);
+    uint32_t* gbt = bnd + 16;
+    int16_t* rowoff = (int16_t*)(gbt + 64);
     (void)crc_mul;                                                          // (read by the checksum step itself, a row per lane)
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[2 * i] = HCA_ENC_COS[i >> 6][i & 63]; esin[2 * i + 1] = HCA_ENC_SIN[i >> 6][i & 63]; }   // etw[i] = {cos, sin}: a twiddle is one register pair
@@ -100,9 +105,17 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
         if (i >= 8) { hi = i - 3; lo = hi - 1; }           // sign-magnitude: max bits, one less for a zero
         else { lo = i ? 15 : 0; hi = 0; for (uint32_t q = 8 - i; q <= 8 + i; q++) { const uint32_t l = HCA_ENC_CODE_LEN[i][q]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; } }
         bnd[i] = lo | (hi << 16);                          // per spectrum; a band has 8
+        rowoff[i] = (int16_t)((int)i * 16 - (int)((double)HCA_ENC_INV_STEP[i] + 0.5 - 8));
+    }
+    for (uint32_t i = tid; i < 64; i += nthreads) {        // (the same arithmetic as above, per curve position)
+        const uint32_t r = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0;
+        uint32_t lo, hi;
+        if (r >= 8) { hi = r - 3; lo = hi - 1; }
+        else { lo = r ? 15 : 0; hi = 0; for (uint32_t q = 8 - r; q <= 8 + r; q++) { const uint32_t l = HCA_ENC_CODE_LEN[r][q]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; } }
+        gbt[i] = lo | (hi << 16);
     }
     EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.etw = (const f2*)esin; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
-    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb; T.bnd = bnd;
+    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb; T.bnd = bnd; T.gb = gbt; T.rowoff = rowoff;
     return T;
 }
 
@@ -202,14 +215,14 @@ __device__ __forceinline__ int enc_band_bits(const EncTab& T, const f2 x[4], int
 #pragma unroll
         for (int j = 0; j < 4; j++) part += (fabsf(x[j].x) >= dz ? 1 : 0) + (fabsf(x[j].y) >= dz ? 1 : 0);
     } else {
+        // (|x| < 1 by ScaleSpectra's clamp, so (int)t - shiftDown is 0 .. 2 * res: no mask; the row offset carries the shift)
         const float inv = T.inv[res], up = inv + 1;
-        const int down = (int)((double)inv + 0.5 - 8);
-        const uint8_t* row = T.clen + res * 16;
+        const uint8_t* row = T.clen + T.rowoff[res];
         const f2 invv = {inv, inv}, upv = {up, up};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const f2 t = x[j] * invv + upv;
-            part += row[((int)t.x - down) & 15] + row[((int)t.y - down) & 15];
+            part += row[(int)t.x] + row[(int)t.y];
         }
     }
     return part;
@@ -556,6 +569,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
     // scaled spectra, scalefactor and "is coded" flag.
     constexpr int NB = CT > 0 ? 2 * CT : 1;
     f2 xr[NB][4]; int sfr[NB]; bool inr[NB];
+    int kb[NB]; bool live[NB];                             // curve position of band b at noise level n: n - kb[b]; live: coded and scalefactor != 0
     auto load_bands = [&]() {
         if constexpr (CT > 0) {
 #pragma unroll
@@ -563,6 +577,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                 const uint32_t c = b >> 1, i = lane + 64 * (b & 1);
                 inr[b] = i < F.coded(c);
                 sfr[b] = L.sfac[c * 128 + i];
+                kb[b] = 5 * sfr[b] / 2 - 2; live[b] = inr[b] && sfr[b] != 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) xr[b][j] = f2{L.sc[(c * 8 + 2 * j) * 128 + i], L.sc[(c * 8 + 2 * j + 1) * 128 + i]};
             }
@@ -598,6 +613,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
         for (;;) {
             int low = 0, high = 255;
             bool over = false;                             // "mid_value > available bits" of the last step (hca.cpp:2806-2815)
+            const int hb = header_bits();
             while (low != high) {
                 const int mid = (low + high) / 2;
                 ENC_COUNT(16, 1);
@@ -606,9 +622,13 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
                     // fewest / most bits a band of that resolution can take, summed -- no quantisation of the spectra
                     uint32_t part = 0;
 #pragma unroll
-                    for (int b = 0; b < NB; b++) part += inr[b] ? T.bnd[enc_resolution(T, sfr[b], mid)] : 0u;
+                    for (int b = 0; b < NB; b++) {                             // bnd[resolution] straight from the curve position
+                        int cp = mid - kb[b];
+                        cp = cp < 0 ? 0 : (cp > 58 ? 58 : cp);
+                        part += live[b] ? T.gb[cp] : 0u;
+                    }
                     const uint32_t tot = (uint32_t)wave_sum((int)part);                      // at most 2 * CT * 64 * 12 per half: no carry
-                    const int hb = header_bits(), least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
+                    const int least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
                     if (least > avail) over = true;
                     else if (most <= avail) over = false;
                     else {

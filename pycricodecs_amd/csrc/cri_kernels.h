@@ -78,6 +78,7 @@ void launch_adx_encode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s);
 // segmented chains (standard layout): speculative decode of all segments, parallel repair, serial repair of flagged chains
 void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s);
 void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s);
+void launch_adx_encode_lane(const AdxArgs& a, hipStream_t s);   // lane per (file, channel, segment): batches of many files
 
 struct CryptArgs {
     const uint8_t* in; uint8_t* out;

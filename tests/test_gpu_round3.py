@@ -363,3 +363,43 @@ def test_adx_ten_second_file_encodes_in_segments(cc):
     assert cc.AdxEncode(w24, 4, 18, 3, 500, 0, 4, False) == O.adx_encode(w24)
     assert Job.adx_encode([w], highpass=0).dominant_kernel != "k_adx_seg_encode"
     assert cc.AdxEncode(w, 4, 18, 3, 0, 0, 4, False) == O.adx_encode(w, 4, 18, 3, 0, 0, 4)
+
+
+@pytest.mark.parametrize("mode,hp", [(3, 500), (4, 500), (2, 500)])
+@pytest.mark.parametrize("pct", ["100", "20", "3"])
+def test_adx_lane_encode_vs_oracle(cc, monkeypatch, pct, mode, hp):
+    """k_adx_lane_encode / _serial: a lane per (file, channel, segment), every segment encoded from a guessed history and again from
+    the previous segment's end until the two histories merge at a checkpoint.  With the default minimum segment length the files of
+    this test are one to three segments; at 20 % and 3 % of it they are dozens of segments too short to merge in, so the files are
+    flagged and the serial pass rewrites them -- the bytes are the oracle's either way."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "lane")
+    monkeypatch.setenv("CRICODECS_ADX_WARM", pct)
+    wavs = _enc_wavs() + [synth.wav(1700, 32 * 2600, 2, 48000), synth.wav(1701, 32 * 2100 + 5, 1, 48000)]
+    job = Job.adx_encode(wavs, mode=mode, highpass=hp)
+    assert job.dominant_kernel == "k_adx_lane_encode"
+    refs = [O.adx_encode(w, 4, 18, mode, hp, 0, 4) for w in wavs]
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert bytes(o) == r, i
+    outs, st = job.run_host()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert bytes(o) == r, i
+
+
+def test_adx_lane_encode_many_files_default_mapping(cc):
+    """From 128 files on the encoder takes the lane mapping by itself: a few hundred clips of shuffled lengths, mono and stereo, 24-bit
+    input among them, all against the oracle."""
+    from pycricodecs_amd.batch import Job
+    rng = np.random.default_rng(99)
+    uniq = [synth.wav(1800 + k, 32 * int(rng.integers(1, 1500)) + int(rng.integers(0, 32)), 1 + k % 2, 48000) for k in range(20)]
+    uniq.append(synth.wav_typed(1830, 32 * 700, 2, 48000, "s24"))
+    pick = rng.integers(0, len(uniq), 260)
+    job = Job.adx_encode([uniq[k] for k in pick])
+    assert job.dominant_kernel == "k_adx_lane_encode"
+    outs, st = run_job(job)
+    assert not st.any()
+    refs = [O.adx_encode(u) for u in uniq]
+    for i, k in enumerate(pick):
+        assert bytes(outs[i]) == refs[k], i
