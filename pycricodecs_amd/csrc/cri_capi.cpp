@@ -1087,8 +1087,13 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     // (k_adx_lane_encode); few files: a WAVE per (file, segment) on the wave-per-file encoder (k_adx_seg_encode).
     // CRICODECS_ADX_MAPPING = "lane" / "wave" forces one of the two where segments apply.
     const char* map_env = getenv("CRICODECS_ADX_MAPPING");
+    // measured (tools/debug/adx_seg_sweep.py): 10 s files -- wave 1.7 / 3.2 / 5.4 / 12.3 ms at 1 / 128 / 256 / 1000 files, lane 3.8 / 4.7 /
+    // 4.8 / 5.2 ms; 1 s files -- wave 1.4 / 2.1 / 4.6 ms at 64 / 1000 / 4000 files, lane 3.4 / 3.7 / 3.9 ms (6.0 at 20 000): the lane form
+    // has a floor of some 3.5 ms (one segment's rows plus the repair, a row at a time) and takes over from about 8 M blocks
+    uint64_t blocks_total = 0;
+    for (const AdxStream& S : streams) blocks_total += (uint64_t)S.frames * S.channels;
     const bool want_lane = all_std && !streams.empty() && !(map_env && (!strcmp(map_env, "chain") || !strcmp(map_env, "file") || !strcmp(map_env, "wave") || !strcmp(map_env, "seg"))) &&
-                           (streams.size() >= 128 || (map_env && !strcmp(map_env, "lane")));
+                           (blocks_total >= 8000000ull || (map_env && !strcmp(map_env, "lane")));
     if (want_lane) {
         uint64_t chains_total = 0;
         for (const AdxStream& S : streams) chains_total += S.channels;

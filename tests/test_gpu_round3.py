@@ -388,10 +388,11 @@ def test_adx_lane_encode_vs_oracle(cc, monkeypatch, pct, mode, hp):
         assert bytes(o) == r, i
 
 
-def test_adx_lane_encode_many_files_default_mapping(cc):
-    """From 128 files on the encoder takes the lane mapping by itself: a few hundred clips of shuffled lengths, mono and stereo, 24-bit
-    input among them, all against the oracle."""
+def test_adx_lane_encode_many_files(cc, monkeypatch):
+    """A few hundred clips of shuffled lengths, mono and stereo, 24-bit input among them, in the lane mapping (the planner's own choice
+    from about 8 M blocks on), all against the oracle."""
     from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "lane")
     rng = np.random.default_rng(99)
     uniq = [synth.wav(1800 + k, 32 * int(rng.integers(1, 1500)) + int(rng.integers(0, 32)), 1 + k % 2, 48000) for k in range(20)]
     uniq.append(synth.wav_typed(1830, 32 * 700, 2, 48000, "s24"))
