@@ -404,6 +404,9 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][K * 36];
     const AdxStream S = a.streams[a.wpf_order ? a.wpf_order[blockIdx.x] : blockIdx.x];
     const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
+    if (a.seg_flags) {                                     // the segmented decoder's fallback: only files with a flagged chain, from their first block
+        if (C > 2 || !(a.seg_flags[S.first_chain] | (C == 2 ? a.seg_flags[S.first_chain + 1] : 0u))) return;
+    }
     const bool act = half < C;
     const uint32_t chain = S.first_chain + (act ? half : 0);
     int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
@@ -1006,22 +1009,31 @@ __device__ __forceinline__ bool seg_repair(const SegLane& X, uint32_t r_end, int
     return false;
 }
 
-__global__ __launch_bounds__(64) void k_adx_seg_fix(AdxArgs a) {
+// One round of repairs.  rec[0] = the state the segment's stored samples were decoded from, rec[1] / rec[2] = the state they end
+// with before / after the round (the two alternate: a round reads the previous segment's end as the previous round left it, so
+// lanes never read what a neighbour is writing).  A merge takes longer than a segment now and then (clean narrow-band material:
+// 6500 samples at worst against 400 on average); a second and third round settle those chains -- only if the LAST round still moved
+// an end is the chain flagged for the serial pass.
+__global__ __launch_bounds__(64) void k_adx_seg_fix(AdxArgs a, uint32_t round, uint32_t last) {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     SegLane X;
-    if (!seg_locate(a, g, X) || X.k == 0) return;
+    if (!seg_locate(a, g, X)) return;
     uint32_t* rec = a.seg_state + 4 * (uint64_t)g;
-    const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - X.S.channels) + 1];
-    if (prev_end == rec[0]) return;                                  // the speculation was right
+    const uint32_t src = 1 + (round & 1), dst = 1 + ((round + 1) & 1);
+    const uint32_t my_end = rec[src];
+    if (X.k == 0) { rec[dst] = my_end; return; }
+    const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - X.S.channels) + src];
+    if (prev_end == rec[0]) { rec[dst] = my_end; return; }          // decoded from the right state already
     int32_t h1, h2;
     seg_unpack(prev_end, h1, h2);
     const uint32_t stop_row = rec[3], r_end = stop_row < X.r1 ? stop_row : X.r1;
     const bool merged = seg_repair(X, r_end, h1, h2);
-    const uint32_t e = seg_pack(h1, h2);
-    if (!merged && e != rec[1]) { rec[2] = e; atomicOr(&a.seg_flags[X.S.first_chain + X.ch], 1u); }   // the next segment started from a stale state
+    const uint32_t e = merged ? my_end : seg_pack(h1, h2);
+    rec[0] = prev_end; rec[dst] = e;
+    if (last && e != my_end) atomicOr(&a.seg_flags[X.S.first_chain + X.ch], 1u);     // the next segment started from a stale state
 }
 
-__global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a) {
+__global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a, uint32_t fin) {
     const uint32_t chain = blockIdx.x * 64 + threadIdx.x;
     if (chain >= a.chains || !a.seg_flags[chain]) return;
     SegLane X;
@@ -1032,10 +1044,11 @@ __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a) {
         X.S = a.streams[lo];
     }
     const AdxStream& S = X.S;
+    if (S.channels <= 2) return;                                     // (mono / stereo files: the wave-per-file decoder takes flagged ones, see launch_adx_decode_seg)
     X.ch = chain - S.first_chain; X.valid = true;
     X.src = a.in + S.src_offset; X.dst = a.out + S.dst_offset; X.rowb = 18 * S.channels;
     int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
-    uint32_t cur = seg_pack(h1, h2), used = cur;
+    uint32_t cur = seg_pack(h1, h2);
     bool stopped = false;
     for (uint32_t k = 0; k < S.seg_count; k++) {
         const uint64_t g = (uint64_t)S.first_seg + (uint64_t)k * S.channels + X.ch;
@@ -1048,13 +1061,12 @@ __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a) {
             continue;
         }
         const uint32_t stop_row = rec[3], r_end = stop_row < X.r1 ? stop_row : X.r1;
-        uint32_t end = rec[2];
-        if (used != cur) {                                           // the segment's samples were decoded from `used`
+        uint32_t end = rec[fin];                                     // (fin: where the last repair round left the ends)
+        if (rec[0] != cur) {                                         // the segment's samples were decoded from rec[0]
             seg_unpack(cur, h1, h2);
             if (!seg_repair(X, r_end, h1, h2)) end = seg_pack(h1, h2);
         }
         if (stop_row != 0xFFFFFFFFu) stopped = true;
-        used = rec[1];                                               // what passes 1 and 2 decoded the next segment from
         cur = end;
     }
 }
@@ -1149,26 +1161,29 @@ __device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t
     } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
     else word = scale;
     if (!scale) scale = 1;
-    const float rcp = 1.0f / (float)scale, half_rcp = 0.5f * rcp;
-    const int32_t hs = (int32_t)(scale >> 1), cap = 9 * (int32_t)scale, iscale = (int32_t)scale;
+    // The quantiser (adx.cpp:256-261): delta +- scale / 2, C division by scale, clamp to [-8, 7] -- sign(d) * floor((|d| + hs) / scale).
+    // In float, symmetric in the sign so that the chain from one sample to the next has no compare / select pair on it:
+    //   code = clamp(trunc(fma(d, 1 / scale, copysign((hs + 0.5) / scale, d))))
+    // exact wherever it matters: for |d| + hs <= 9 * scale the quotient (|d| + hs + 0.5) / scale is at least 0.5 / 4096 = 1.2e-4 away from
+    // an integer and the float error is below 3e-6 (the same bound as k_adx_encode's form); beyond, both sides are past +-8 and clamp alike.
+    const float rcp = 1.0f / (float)scale, adj = ((float)(scale >> 1) + 0.5f) * rcp;
+    const int32_t iscale = (int32_t)scale;
     int32_t g1 = h1, g2 = h2;
+    int32_t c1g2 = __mul24(c1, g2);
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         uint32_t acc = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {                                // pass B (adx.cpp:254-271)
-            const int32_t v = x[8 * w + i];
-            const int32_t pred = __mul24(c0, g1) + __mul24(c1, g2);
-            const int32_t d = ((int32_t)((uint32_t)v << 12) - pred) >> 12;
-            const bool neg = d < 0;
-            int32_t an = (neg ? -d : d) + hs;
-            an = an < cap ? an : cap;
-            int32_t q = (int32_t)__builtin_fmaf((float)an, rcp, half_rcp);
-            const int32_t qmax = neg ? 8 : 7;
-            q = q < qmax ? q : qmax;
-            const int32_t code = neg ? -q : q;
-            int32_t sim = (int32_t)(((uint32_t)__mul24(code, iscale) << 12) + (uint32_t)pred) >> 12;
+            const int32_t pred = __mul24(c0, g1) + c1g2;
+            const int32_t d = ((int32_t)((uint32_t)x[8 * w + i] << 12) - pred) >> 12;
+            const float df = (float)d;
+            const float sadj = __uint_as_float((__float_as_uint(adj) & 0x7FFFFFFFu) | (__float_as_uint(df) & 0x80000000u));
+            int32_t code = (int32_t)__builtin_fmaf(df, rcp, sadj);
+            code = code > 7 ? 7 : (code < -8 ? -8 : code);
+            int32_t sim = __mul24(code, iscale) + (pred >> 12);       // = ((code * scale << 12) + pred) >> 12: the product has no low bits
             sim = clamp_sym(sim, 0x7FFF);
+            c1g2 = __mul24(c1, g1);
             g2 = g1; g1 = sim;
             acc = (acc << 4) | ((uint32_t)code & 15u);               // first sample in the high nibble of the first byte
         }
@@ -1352,9 +1367,16 @@ void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s) {
 
 void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s) {
     if (!a.seg_lanes) return;
+    constexpr uint32_t ROUNDS = 3;
     hipLaunchKernelGGL(k_adx_seg_decode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_adx_seg_fix, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(k_adx_seg_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
+    for (uint32_t r = 0; r < ROUNDS; r++) hipLaunchKernelGGL(k_adx_seg_fix, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, r, r + 1 == ROUNDS ? 1u : 0u);
+    // Flagged chains.  Histories do not always merge: through digital silence the decoder's state just sits where the last sound left
+    // it (the recurrence has fixed points away from zero: -100, -100 maps to -100), so a file with silent stretches keeps every
+    // segment inside them inconsistent.  Such files are decoded again by the wave-per-file kernel from their first block (8.5 ms for
+    // 10 s: what every file cost before the segments); only layouts it does not take (more than two channels) walk their segments
+    // lane by lane.
+    hipLaunchKernelGGL(k_adx_decode_wpf, dim3(a.n_streams), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_adx_seg_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a, 1 + (ROUNDS & 1));
 }
 
 void launch_adx_decode_wpf(const AdxArgs& a, uint32_t n_streams, hipStream_t s) {

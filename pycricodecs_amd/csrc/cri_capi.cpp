@@ -512,6 +512,8 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
         return any || (e && !strcmp(e, "seg"));
     }
     const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains);
+    const char* se = getenv("CRICODECS_ADX_SEGLEN");             // (developer switch: least segment length in warm-ups)
+    const uint64_t seg_mult = se ? std::max<uint64_t>(1, strtoull(se, nullptr, 10)) : 3;
     bool any = false;
     for (AdxStream& S : streams) {
         const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;     // (mode 2: the slowest of the four static filters)
@@ -519,7 +521,7 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
         S.seg_rows = S.frames; S.seg_count = S.frames ? 1 : 0; S.warm_rows = 0;
         if (g <= 0 || !S.frames) continue;                           // no decay (high-pass 0): one segment, i.e. the plain serial decode
         const uint64_t warm = std::max<uint64_t>(1, (56000ull * warm_pct / 100 / (uint64_t)g + 31) / 32);
-        const uint64_t rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, 3 * warm);
+        const uint64_t rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, seg_mult * warm);
         if (rows >= S.frames) continue;
         S.seg_rows = (uint32_t)rows; S.seg_count = (uint32_t)((S.frames + rows - 1) / rows); S.warm_rows = (uint32_t)warm;
         any = true;

@@ -404,3 +404,27 @@ def test_adx_lane_encode_many_files(cc, monkeypatch):
     refs = [O.adx_encode(u) for u in uniq]
     for i, k in enumerate(pick):
         assert bytes(outs[i]) == refs[k], i
+
+
+def test_adx_segmented_decode_through_silence_and_pure_tones(cc):
+    """Where histories do not merge: digital silence after a sound (the decoder's state sits at a fixed point of the recurrence, a
+    different one for a different history) and noiseless periodic material (limit cycles).  Those chains are flagged and their files
+    decoded again by the wave-per-file kernel; everything else in the job keeps its segments."""
+    from pycricodecs_amd.batch import Job
+    t = np.arange(32 * 4000)[:, None] / 48000.0
+    tone = np.round(0.9 * 32767 * np.sin(2 * np.pi * 997.0 * t + np.array([[0.0, 0.7]]))).astype(np.int16)
+    tone[:512] = (tone[:512] * (np.arange(512)[:, None] / 512.0) ** 2).astype(np.int16)
+    gap = synth.pcm16(1900, 32 * 4000, 2, 48000)
+    gap[32 * 700:32 * 2900] = 0                                 # 1.5 s of digital silence inside
+    gap[32 * 3300:] = 0                                         # and at the end
+    files = [O.adx_encode(synth.wav_bytes(tone, 48000)), O.adx_encode(synth.wav_bytes(gap, 48000)), O.adx_encode(synth.wav(1901, 32 * 4000, 2, 48000)),
+             O.adx_encode(synth.wav_bytes(gap[:, :1].copy(), 48000))]
+    job = Job.adx_decode(files)
+    assert job.dominant_kernel == "k_adx_seg_decode"
+    outs, st = run_job(job)
+    assert not st.any()
+    for i, (o, f) in enumerate(zip(outs, files)):
+        assert bytes(o) == O.adx_decode(f), i
+    enc = Job.adx_encode([synth.wav_bytes(tone, 48000), synth.wav_bytes(gap, 48000)])
+    outs, st = run_job(enc)
+    assert bytes(outs[0]) == files[0] and bytes(outs[1]) == files[1]
