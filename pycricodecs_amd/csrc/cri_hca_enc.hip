@@ -75,10 +75,11 @@ struct EncTab {
     const uint8_t *curve, *clen, *code, *ishuf;                             // [64] [8][16] [8][16] [128] (ishuf[HCA_ENC_SHUFFLE[k]] = k)
     const uint32_t* bnd;                                                    // [16] per resolution: fewest | most << 16 bits one spectrum can take
     const uint32_t* gb;                                                     // [64] bnd[curve[position]]: the bounds straight from the curve position
+    const uint8_t* runend;                                                  // [16] last curve position whose resolution is 15 - r (the curve falls from 15 to 1)
     const int16_t* rowoff;                                                  // [16] resolution r < 8: r * 16 - shiftDown(r), so that clen[rowoff + (int)t] is the code length
                                                                             // of the quantised spectrum t (hca.cpp:2778-2784 without its double arithmetic per band)
 };
-#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32 + 64 + 256 + 32)
+#define ENC_TAB_BYTES (512 + 2048 + 2048 + 288 + 256 + 64 + 64 + 64 + 64 + 128 + 128 + 128 + 192 + 32 + 64 + 256 + 32 + 16)
 __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid, uint32_t nthreads, const uint16_t* crc_mul) {
     float* win = (float*)base; float* esin = win + 128; float* ecos = esin + 512; float* deq = ecos + 512; float* escale = deq + 72;
     float* dead = escale + 64; float* inv = dead + 16; float* ib = inv + 16;
@@ -88,7 +89,13 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
     uint32_t* bnd = (uint32_t*)(sfb + 32);
     uint32_t* gbt = bnd + 16;
     int16_t* rowoff = (int16_t*)(gbt + 64);
-    (void)crc_mul;                                                          // (read by the checksum step itself, a row per lane)
+    uint8_t* runend = (uint8_t*)(rowoff + 16);
+    (void)crc_mul;
+    if (tid < 16) {                                        // resolutions 15 .. 1 are runs of the curve's 59 positions
+        uint32_t last = 0;
+        for (uint32_t i = 0; i < 59; i++) if (HCA_ENC_CURVE_TO_RES[i] == 15 - tid) last = i;
+        runend[tid] = (uint8_t)last;
+    }                                                          // (read by the checksum step itself, a row per lane)
     for (uint32_t i = tid; i < 128; i += nthreads) { win[i] = HCA_WINDOW[i]; shuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     for (uint32_t i = tid; i < 512; i += nthreads) { esin[2 * i] = HCA_ENC_COS[i >> 6][i & 63]; esin[2 * i + 1] = HCA_ENC_SIN[i >> 6][i & 63]; }   // etw[i] = {cos, sin}: a twiddle is one register pair
     for (uint32_t i = tid; i < 64; i += nthreads) { escale[i] = HCA_ENC_SCALE[i]; curve[i] = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0; }
@@ -115,7 +122,7 @@ __device__ __forceinline__ EncTab enc_tables_to_lds(uint8_t* base, uint32_t tid,
         gbt[i] = lo | (hi << 16);
     }
     EncTab T; T.win = win; T.esin = esin; T.ecos = ecos; T.etw = (const f2*)esin; T.deq = deq; T.escale = escale; T.dead = dead; T.inv = inv; T.ibounds = ib;
-    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb; T.bnd = bnd; T.gb = gbt; T.rowoff = rowoff;
+    T.curve = curve; T.clen = clen; T.code = code; T.ishuf = shuf; T.crcmul = cm; T.sfbase = sfb; T.bnd = bnd; T.gb = gbt; T.rowoff = rowoff; T.runend = runend;
     return T;
 }
 
@@ -614,30 +621,74 @@ __global__ __launch_bounds__(64 * ENC_WAVES, ENC_MIN_WAVES) void k_hca_encode(Hc
             int low = 0, high = 255;
             bool over = false;                             // "mid_value > available bits" of the last step (hca.cpp:2806-2815)
             const int hb = header_bits();
+            // The first six levels of the search tree at once.  A band sits at curve position n - kb at noise level n, and the curve is
+            // 15 runs of equal resolution, so the bands of one resolution at level n are those whose kb lies in a window that slides with
+            // n: with H[x] = bands with kb + 2 <= x (a histogram of 5 * scalefactor / 2, prefix-summed), lane l < 63 adds up, for ITS node's
+            // level, 15 window counts times that resolution's fewest / most bits.  What the loop below reads at depth < 6 is two ballots.
+            uint64_t tree_over = 0, tree_fit = 0;
+            if constexpr (CT > 0) {
+                uint32_t* Hs = L.words;                    // [193]: Hs[x + 1] = H[x], x = -1 .. 191 (the frame image is not in use yet)
+                wave_lds_sync();
+                Hs[lane] = 0; Hs[lane + 64] = 0; Hs[lane + 128] = 0; if (lane == 0) Hs[192] = 0;
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < NB; b++) if (live[b]) atomicAdd(&Hs[kb[b] + 2 + 1], 1u);
+                wave_lds_sync();
+                {   // prefix sum over the 192 counters: three per lane, then across the lanes
+                    const uint32_t c0 = Hs[3 * lane + 1], c1 = Hs[3 * lane + 2], c2 = Hs[3 * lane + 3];
+                    const uint32_t incl = wave_incl_scan_dpp(c0 + c1 + c2), before = incl - (c0 + c1 + c2);
+                    wave_lds_sync();
+                    Hs[3 * lane + 1] = before + c0; Hs[3 * lane + 2] = before + c0 + c1; Hs[3 * lane + 3] = incl;
+                }
+                wave_lds_sync();
+                const uint32_t total = Hs[192];
+                const uint32_t node = lane < 63 ? lane : 0, d = 31 - (uint32_t)__clz((int)(node + 1)), jn = node + 1 - (1u << d);
+                const int nmid = (int)(jn << (8 - d)) + (int)(1u << (7 - d)) - 1;
+                uint32_t tot = 0, prevc = total;
+#pragma unroll
+                for (int r = 0; r < 15; r++) {             // resolution 15 - r: positions up to runend[r] that the run before did not take
+                    uint32_t cur = 0;
+                    if (r < 14) { int x = nmid + 1 - (int)T.runend[r]; x = x < -1 ? -1 : (x > 191 ? 191 : x); cur = Hs[x + 1]; }
+                    tot += T.bnd[15 - r] * (prevc - cur);
+                    prevc = cur;
+                }
+                const int least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
+                tree_over = __ballot(lane < 63 && least > avail);
+                tree_fit = __ballot(lane < 63 && most <= avail);
+                wave_lds_sync();
+            }
+            uint32_t tnode = 0, depth = 0;
             while (low != high) {
                 const int mid = (low + high) / 2;
                 ENC_COUNT(16, 1);
                 if constexpr (CT > 0) {
                     // the same decision from per-resolution bounds when they settle it (far from the answer they do): the
                     // fewest / most bits a band of that resolution can take, summed -- no quantisation of the spectra
-                    uint32_t part = 0;
+                    bool settled = false;
+                    if (depth < 6) {
+                        if ((tree_over >> tnode) & 1) { over = true; settled = true; }
+                        else if ((tree_fit >> tnode) & 1) { over = false; settled = true; }
+                    } else {
+                        uint32_t part = 0;
 #pragma unroll
-                    for (int b = 0; b < NB; b++) {                             // bnd[resolution] straight from the curve position
-                        int cp = mid - kb[b];
-                        cp = cp < 0 ? 0 : (cp > 58 ? 58 : cp);
-                        part += live[b] ? T.gb[cp] : 0u;
+                        for (int b = 0; b < NB; b++) {                         // bnd[resolution] straight from the curve position
+                            int cp = mid - kb[b];
+                            cp = cp < 0 ? 0 : (cp > 58 ? 58 : cp);
+                            part += live[b] ? T.gb[cp] : 0u;
+                        }
+                        const uint32_t tot = (uint32_t)wave_sum((int)part);                  // at most 2 * CT * 64 * 12 per half: no carry
+                        const int least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
+                        if (least > avail) { over = true; settled = true; }
+                        else if (most <= avail) { over = false; settled = true; }
                     }
-                    const uint32_t tot = (uint32_t)wave_sum((int)part);                      // at most 2 * CT * 64 * 12 per half: no carry
-                    const int least = hb + 8 * (int)(tot & 0xFFFF), most = hb + 8 * (int)(tot >> 16);
-                    if (least > avail) over = true;
-                    else if (most <= avail) over = false;
-                    else {
+                    if (!settled) {
                         ENC_TIC();
                         over = used_bits(mid, 0) > avail;
                         ENC_TOC(18); ENC_COUNT(17, 1);
                         if (over) { over_noise = mid; _Pragma("unroll") for (int b = 0; b < NB; b++) over_bits[b] = last[b]; }
                         else { fit_noise = mid; _Pragma("unroll") for (int b = 0; b < NB; b++) fit_bits[b] = last[b]; }
                     }
+                    tnode = 2 * tnode + 1 + (over ? 1u : 0u); depth++;
                 } else over = used_bits(mid, 0) > avail;
                 if (over) low = mid + 1; else high = mid;
             }
