@@ -837,12 +837,12 @@ __global__ __launch_bounds__(64) void k_adx_seg_encode(AdxArgs a, uint32_t pass)
 //   1. k_adx_seg_decode   every (segment, channel) is a lane: it decodes `warm_rows` rows before its segment from a zero
 //                         history (nothing stored), records the state it arrives with, decodes and stores its segment and
 //                         records the state it ends with.  Segment 0 starts from the header's history: it is exact;
-//   2. k_adx_seg_fix      lane per segment again: if the state the previous segment ended with is not the state this one
-//                         started from, the segment is decoded again from the right state, row by row, until its state equals
-//                         what the speculative pass stored there (from that row on the stored samples are right already).  A
-//                         repair that reaches the segment's end with a different state than recorded flags its chain;
-//   3. k_adx_seg_serial   lane per (file, channel) chain, for flagged chains only (and chains with an end-of-stream marker):
-//                         walks the segments in order from the header history and repairs what is still inconsistent.
+//   2. k_adx_seg_fix      (three rounds) lane per segment again: if the state the previous segment ended with is not the state
+//                         this one was decoded from, it is decoded again from the right state, row by row, until its state equals
+//                         what is stored there (from that row on the stored samples are right already).  A chain whose ends
+//                         still moved in the last round is flagged;
+//   3. flagged chains     mono / stereo files: k_adx_decode_wpf decodes them again from their first block; other layouts (and
+//                         chains with an end-of-stream marker) walk their segments in k_adx_seg_serial, lane per chain.
 // Every unflagged chain is exact by induction: segment k's samples are the decode from the recorded end state of segment
 // k - 1, and no recorded end state changed.  Flagged chains are exact by construction.  The result never depends on the
 // warm-up length -- only the time does.  One 10 s file becomes some hundred lanes of 150 rows instead of two of 15 000.
