@@ -1349,11 +1349,9 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a) {
 
 void launch_adx_encode_lane(const AdxArgs& a, hipStream_t s) {
     if (!a.seg_lanes) return;
-    const char* e = getenv("CRI_LANE_PASSES");
-    const int m = e ? atoi(e) : 7;
-    if (m & 1) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 0u);
-    if (m & 2) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 1u);
-    if (m & 4) hipLaunchKernelGGL(k_adx_lane_encode_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 0u);
+    hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 1u);
+    hipLaunchKernelGGL(k_adx_lane_encode_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
 }
 
 void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s) {
