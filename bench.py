@@ -205,6 +205,32 @@ def cpu_baseline(kind, sample, frames, seconds=10.0):
 
 
 # ------------------------------------------------------------------------------------------------ device helpers
+def near_the_gpu(dev_index):
+    """Runs this rank on the cores of the socket its GPU hangs off (and so puts what it allocates from here on into that
+    socket's memory): on a two-socket host the PCIe-inclusive lines lose 10-15 % when the buffers sit across the inter-socket
+    link.  Returns what it did, for the bench line; a no-op where sysfs does not say."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev_index)) != 0:
+            return None
+        bdf = buf.value.decode().lower()
+        base = "/sys/bus/pci/devices/%s/" % bdf
+        node = int(open(base + "numa_node").read())
+        cpus = set()
+        for part in open(base + "local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if node < 0 or not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"gpu": bdf, "numa_node": node, "cpus": len(cpus)}
+    except Exception:
+        return None
+
+
 class Dist:
     """torch.distributed plumbing of one rank (world 1: no process group)."""
     def __init__(self):
@@ -220,6 +246,8 @@ class Dist:
         assert dev_index < torch.cuda.device_count(), "rank %d has no GPU: %d visible" % (self.local, torch.cuda.device_count())
         torch.cuda.set_device(dev_index)
         self.dev = "cuda:%d" % dev_index
+        self.affinity0 = os.sched_getaffinity(0)
+        self.numa = near_the_gpu(dev_index)
         if self.world > 1:
             import torch.distributed as dist
             if self.shared:
@@ -552,6 +580,9 @@ def secondary_measurements(args, D):
     n = args.secondary_streams
     uq = min(args.unique, 16)
     out = {}
+    # (first: the 44 GB of device buffers it needs are allocated while the device's memory is still in large pieces -- at the end of
+    #  this list, after dozens of jobs' buffers have come and gone, the same downloads ran 10 % slower)
+    out["hca_decode_host"] = host_path_run(min(args.streams, args.host_streams), uq, args.seconds)
     for label, q, fam in (("hca_decode_sparse_spectra", 1, "sparse"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_noise", 1, "noise"), ("hca_decode_middle", 2, "tonal"),
                           ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
         r = hca_decode_run(D, n, uq, args.seconds, q, fam, 3, 1)
@@ -608,7 +639,6 @@ def secondary_measurements(args, D):
     torch.cuda.empty_cache()
     out["awb_mixed_decode"] = awb_mixed_run(D, args.awb_clips, 3, 1)
     out["single_call_ms"] = single_call_latency(args.seconds)
-    out["hca_decode_host"] = host_path_run(min(args.streams, args.host_streams), uq, args.seconds)
     return out
 
 
@@ -642,38 +672,50 @@ def single_call_latency(seconds):
 
 
 def host_path_run(streams, unique, seconds):
-    """PCIe-inclusive: HCA decode of `streams` encrypted streams from HOST memory to host memory through cri_job_run_host_into (one
-    pageable host blob up, the kernels, the WAVs down into a page-locked buffer) -- what a caller without device buffers sees.
+    """PCIe-inclusive: HCA decode of `streams` encrypted streams from HOST memory to host memory -- what a caller without device
+    buffers sees.  Two forms: the items' own `bytes` objects up (cri_job_run_host_items), WAVs down into a pageable numpy buffer
+    (what Job.run_host() does for a Python caller); and one host blob up, WAVs down into page-locked memory (cri_job_run_host_into).
     Job planning (header parse of every item) is outside the timed call, as for the device-resident line."""
     import numpy as np
     import oracle_lib as O
     from pycricodecs_amd.batch import Job, pinned_array, pinned_release
+    from pycricodecs_amd import _capi
     uniq = make_hca_streams(unique, seconds, 0, 1, "tonal")
     items = tile(uniq, streams)
     job = Job.hca_decode(items, keys=[KEY] * len(items))
-    out = pinned_array(job.output_bytes)
-    job.blob                                                   # the batch as one host blob (built once)
-    job.run_host(out=out, joined=True)
-    best, st = None, None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        outs, st = job.run_host(out=out, joined=True)
-        dt = time.perf_counter() - t0
-        best = dt if best is None or dt < best else best
-    assert not st.any()
     refs = [O.hca_decode(h, KEY) for h in uniq]
     step = max(1, streams // 97)
-    checked = 0
-    for i in list(range(0, streams, step)) + [streams - 1]:
-        assert bytes(outs[i]) == refs[i % len(uniq)], "host path: item %d differs from the oracle" % i
-        checked += 1
-    res = {"workload": "HCA decode of %d x %.0f s encrypted stereo streams, host bytes in (pageable) -> host WAVs out (page-locked), cri_job_run_host_into" % (streams, seconds),
-           "frames_per_s": round(job.units / best, 1), "ms": round(best * 1e3, 2), "frames": job.units,
-           "GBps_in_plus_out": round((job.input_bytes + job.output_bytes) / best / 1e9, 2), "bytes": {"in": job.input_bytes, "out": job.output_bytes},
-           "verified_items": checked, "verified_how": "every %d-th output compared on the host with the oracle's bytes; all statuses zero" % step}
-    del outs
-    pinned_release(out)
-    from pycricodecs_amd import _capi
+
+    def timed(out, joined):
+        job.run_host(out=out, joined=joined)
+        best, st, outs = None, None, None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            outs, st = job.run_host(out=out, joined=joined)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        assert not st.any()
+        checked = 0
+        for i in list(range(0, streams, step)) + [streams - 1]:
+            assert bytes(outs[i]) == refs[i % len(uniq)], "host path: item %d differs from the oracle" % i
+            checked += 1
+        return best, checked
+
+    page = np.zeros(max(job.output_bytes, 1), dtype=np.uint8)
+    t_items, checked = timed(page, False)
+    del page
+    pin = pinned_array(job.output_bytes)
+    job.blob                                                   # the batch as one host blob (built once)
+    t_blob, _ = timed(pin, True)
+    pinned_release(pin)
+    res = {"workload": "HCA decode of %d x %.0f s encrypted stereo streams from host memory to host memory" % (streams, seconds),
+           "frames_per_s": round(job.units / t_items, 1), "ms": round(t_items * 1e3, 2),
+           "form": "the items' own bytes objects (pageable) in, WAVs into a pageable numpy buffer: cri_job_run_host_items",
+           "blob_form": {"frames_per_s": round(job.units / t_blob, 1), "ms": round(t_blob * 1e3, 2),
+                         "form": "one pageable host blob in, WAVs into page-locked memory: cri_job_run_host_into"},
+           "frames": job.units, "GBps_in_plus_out": round((job.input_bytes + job.output_bytes) / t_items / 1e9, 2),
+           "bytes": {"in": job.input_bytes, "out": job.output_bytes}, "link": "PCIe: 57 GB/s each way measured (tools/debug/pcie_duplex.py); the download alone is %.1f ms" % (job.output_bytes / 57e9 * 1e3),
+           "verified_items": checked, "verified_how": "every %d-th output of both forms compared on the host with the oracle's bytes; all statuses zero" % step}
     _capi.lib().cri_release_cache()
     return res
 
@@ -710,7 +752,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
-    ap.add_argument("--host-streams", type=int, default=2500, help="streams of the host-memory secondary (page-locked output: 1.92 MB each)")
+    ap.add_argument("--host-streams", type=int, default=10000, help="streams of the host-memory secondary (host output buffers: 1.92 MB each)")
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -791,7 +833,10 @@ def main():
     rank, world = D.rank, D.world
     if world > 1:
         D.close()                                              # (the other ranks are done; the host-core baseline is rank 0's alone)
+    if D.numa:
+        out["config"]["host"] = dict(D.numa, note="the rank runs on the cores of its GPU's socket (matters to the host-memory lines only)")
     if rank == 0 and not args.no_cpu:
+        os.sched_setaffinity(0, D.affinity0)                   # the host-core baseline gets every core of the box again
         out["cpu_baseline"] = cpu_baseline(*cpu)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -239,12 +239,15 @@ void cri_job_destroy(cri_job* job);
  *                           from a cri_items list WITH caller offsets has no blob form: CRI_ERR_INVALID_ARG, use the next one.
  *   cri_job_run_host_items  for a job created from a cri_items list: every item is uploaded from its own host buffer
  *                           (`items`: the same n items with the same lengths; its offsets are ignored).
- * The library keeps, per device, the device buffers of the last host call (up to 512 MB; larger ones are released when the
- * call returns) and private streams: these calls allocate nothing in the steady state and wait for their own stream only.
- * With page-locked host memory (cri_pinned_alloc, or memory the caller registered with the HIP runtime) the PCIe copies are
- * asynchronous DMA.  (A pipelined order -- upload, kernels and download of successive slices of a large HCA decode job on three
- * streams -- is implemented and tested but off by default: it measured no faster on this runtime; CRICODECS_HOST_SLICE_MIN
- * = job size in bytes turns it on.)  cri_release_cache drops what is kept for the calling thread's current device. */
+ * The library keeps, per device, the device buffers of the last host call (up to a quarter of the device's memory; more is
+ * released when the call returns) and private streams: these calls allocate nothing in the steady state and wait for their
+ * own streams only.  Large single-format HCA decode jobs (64 MB in + out and more; CRICODECS_HOST_SLICE_MIN = bytes moves the
+ * switch, 0 = always) run PIPELINED -- uploads, kernels and downloads of successive slices overlap, the uploads pulled across
+ * the link by a few workgroups so that the downloads have the DMA engines to themselves: 13 M frames/s against 11 M in one
+ * piece on MI355X (PCIe-bound either way).  Any host memory works: page-locked buffers (cri_pinned_alloc, or memory the caller
+ * registered with the HIP runtime) are used in place, a pageable blob or output buffer is page-locked for the duration of the
+ * call, separate items are copied through a page-locked staging ring.  cri_release_cache drops what is kept for the calling
+ * thread's current device. */
 int cri_job_run_host(cri_job* job, const uint8_t* blob, uint8_t** out_blob, int32_t* status);
 int cri_job_run_host_into(cri_job* job, const uint8_t* blob, uint8_t* out, int32_t* status);
 int cri_job_run_host_items(cri_job* job, const cri_items* items, uint8_t* out, int32_t* status);

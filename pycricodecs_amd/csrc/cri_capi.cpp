@@ -1513,21 +1513,72 @@ extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int m
 
 // ------------------------------------------------------------------------------------------------ host buffers in and out
 // What a caller with host memory pays besides the kernels: device allocations, two PCIe crossings, a wait.  The host entry
-// points keep, per device, an ARENA -- the four device buffers of the last call (grown on demand, released again when a call
-// leaves more than HOST_ARENA_KEEP behind: a 40 GB batch should not stay resident because it ran once) and three private,
-// non-blocking streams -- so a single-file call allocates nothing, waits for its own stream only (never hipDeviceSynchronize:
-// the host's other streams are not this library's business) and copies its result straight into the buffer it returns.
-// A PIPELINED order exists for large single-format HCA decode jobs (the group cut into slices of whole parse tiles: slice k's
-// input goes up on the upload stream while slice k-1 is parsed and transformed on the run stream and slice k-2's PCM comes
-// down on the download stream, events ordering the three); it is off by default -- see run_host_core for what it measured.
+// points keep, per device, an ARENA -- the four device buffers of the last call (grown on demand; released when a call leaves
+// more than a quarter of the device's memory behind, or by cri_release_cache: allocating and freeing the 44 GB of a 10 000
+// stream decode took anything between 10 ms and 0.9 s per call) and three private, non-blocking streams -- so a call allocates
+// nothing in the steady state, waits for its own streams only (never hipDeviceSynchronize: the host's other streams are not
+// this library's business) and copies its result straight into the buffer it returns.
+// Large single-format HCA decode jobs are PIPELINED (the group cut into slices of whole parse tiles: slice k's input goes up
+// on the upload stream while slice k-1 is parsed and transformed on the run stream and slice k-2's PCM comes down on the
+// download stream, events ordering the three) -- see run_host_core for what that took.
 namespace {
-const size_t HOST_ARENA_KEEP = 512ull << 20;
+const size_t HOST_ARENA_KEEP_MIN = 512ull << 20;             // kept whatever the device: single-file calls
+const uint64_t HOST_SLICE_MIN = 64ull << 20;                   // jobs moving at least this much (in + out) are pipelined
+const uint64_t HOST_SLICE_BYTES = 128ull << 20;                // ... in slices of about this much traffic
+const uint64_t HOST_STAGE_BYTES = 16ull << 20;                 // page-locked staging ring for pageable input: slots of this size
+const uint32_t HOST_STAGE_SLOTS = 4;
+
+// A caller's host buffer as the device sees it: page-locked memory (hipHostMalloc, hipHostRegister) is used in place, pageable
+// memory is page-locked for the duration of the call (cheap next to the copies: 1-6 ms for 0.6-3 GB of resident memory on the
+// host this was written on); `dev` stays null when neither works and the caller falls back to staged copies.
+std::mutex g_locked_mu;
+std::map<void*, std::pair<size_t, int>> g_locked;            // ranges this library has page-locked: base -> (bytes, calls using it)
+struct PinnedView {
+    void* host = nullptr; void* dev = nullptr; bool counted = false;
+    bool open(void* p, size_t bytes) {
+        host = p;
+        if (!p || !bytes) return false;
+        std::lock_guard<std::mutex> lk(g_locked_mu);
+        auto it = g_locked.find(p);
+        if (it != g_locked.end()) {                            // another call of ours holds it locked: share it if it covers this one
+            if (it->second.first < bytes) return false;
+            it->second.second++; counted = true;
+        } else {
+            hipPointerAttribute_t at;
+            const bool known = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
+            (void)hipGetLastError();
+            if (!known) {
+                if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+                g_locked[p] = std::make_pair(bytes, 1); counted = true;
+            }
+        }
+        if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { dev = nullptr; (void)hipGetLastError(); }
+        return dev != nullptr;
+    }
+    ~PinnedView() {
+        if (!counted) return;
+        std::lock_guard<std::mutex> lk(g_locked_mu);
+        auto it = g_locked.find(host);
+        if (it != g_locked.end() && --it->second.second == 0) { (void)hipHostUnregister(host); g_locked.erase(it); }
+    }
+};
+
 struct HostArena {
     std::mutex mu;
     hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     void* buf[4] = {nullptr, nullptr, nullptr, nullptr};       // in, out, scratch, status
     size_t cap[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> events;
+    void* stage[HOST_STAGE_SLOTS] = {};                         // page-locked staging slots (pipelined path, pageable input)
+    hipEvent_t stage_free[HOST_STAGE_SLOTS] = {};
+    bool stage_busy[HOST_STAGE_SLOTS] = {};
+    bool ensure_stage() {
+        for (uint32_t k = 0; k < HOST_STAGE_SLOTS; k++) {
+            if (!stage[k] && hipHostMalloc(&stage[k], HOST_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) { stage[k] = nullptr; return false; }
+            if (!stage_free[k] && hipEventCreateWithFlags(&stage_free[k], hipEventDisableTiming) != hipSuccess) { stage_free[k] = nullptr; return false; }
+        }
+        return true;
+    }
     bool streams_ok() {
         if (s_run) return true;
         return hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking) == hipSuccess &&
@@ -1547,11 +1598,23 @@ struct HostArena {
         return events[i];
     }
     void release_buffers() { for (int k = 0; k < 4; k++) { if (buf[k]) (void)hipFree(buf[k]); buf[k] = nullptr; cap[k] = 0; } }
-    void trim() { if (cap[0] + cap[1] + cap[2] + cap[3] > HOST_ARENA_KEEP) release_buffers(); }
+    size_t keep = 0;                                            // bytes that may stay allocated between calls
+    void trim() {
+        if (!keep) {
+            size_t fr = 0, total = 0;
+            keep = hipMemGetInfo(&fr, &total) == hipSuccess && total / 4 > HOST_ARENA_KEEP_MIN ? total / 4 : HOST_ARENA_KEEP_MIN;
+        }
+        if (cap[0] + cap[1] + cap[2] + cap[3] > keep) release_buffers();
+    }
     void destroy() {
         release_buffers();
         for (auto e : events) (void)hipEventDestroy(e);
         events.clear();
+        for (uint32_t k = 0; k < HOST_STAGE_SLOTS; k++) {
+            if (stage[k]) (void)hipHostFree(stage[k]);
+            if (stage_free[k]) (void)hipEventDestroy(stage_free[k]);
+            stage[k] = nullptr; stage_free[k] = nullptr; stage_busy[k] = false;
+        }
         if (s_up) (void)hipStreamDestroy(s_up);
         if (s_run) (void)hipStreamDestroy(s_run);
         if (s_down) (void)hipStreamDestroy(s_down);
@@ -1613,13 +1676,21 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
     if (out_copy > j->out_bytes) out_copy = j->out_bytes;
     const bool gaps = src.items && j->n && j->in_bytes;       // an items layout may leave bytes between the items: they are defined as zero
     uint32_t cursor = 0;
-    // The pipelined path is OFF unless CRICODECS_HOST_SLICE_MIN names a job size (bytes in + out) from which to use it: measured on
-    // MI355X / ROCm 7.2 (tools/debug/host_path_time.py, 2000 x 10 s streams, 0.64 GB in, 3.84 GB out) the single-stream order below
-    // takes 86 ms -- upload 11, kernels 4, download 67 at the link's 57 GB/s -- and the sliced order 87-89 ms from a pageable source
-    // and 132-140 ms from a page-locked one, whatever the slice count, the download stream or the queueing order; a replica of the
-    // same three-stream shape in PyTorch (tools/debug/pcie_duplex.py) does overlap the two directions (80 ms for 1 + 4 GB against 94
-    // in sequence), so the overlap exists on this link -- why this path misses it is open.  The tests run both.
-    uint64_t slice_min = ~0ull;
+    // Large single-format HCA decode jobs are PIPELINED (CRICODECS_HOST_SLICE_MIN = the job size, bytes in + out, from which; 0 = always,
+    // a huge value = never).  What it took on MI355X / ROCm 7.2 (2000 x 10 s streams: 0.64 GB in, 3.84 GB out; one stream in order:
+    // 85 ms = upload 11 + kernels 4 + download 67 at the link's 57 GB/s):
+    //  * with hipMemcpyAsync in both directions the sliced order took 130 ms: the runtime picks the DMA engine of a copy by what is idle
+    //    when it is queued, a download queued while uploads are in flight lands on another engine than the uploads', and those run the
+    //    host link at 30 GB/s (AMD_LOG_LEVEL=4 shows the engine per copy; from pageable memory the uploads are synchronous and nothing
+    //    overlaps at all: 88 ms);
+    //  * so the uploads do not use the DMA engines: a few workgroups pull the input across the link with plain loads from page-locked
+    //    memory (k_pull_host) -- 8 workgroups, 19 GB/s: enough to stay ahead of a decoder whose output is 3.5-12x its input, and the
+    //    downloads, alone on the engines, keep the 57 GB/s beside it (with 128 workgroups they drop to a fifth while a pull runs);
+    //  * pageable input is made page-locked for the call (a blob: hipHostRegister, ~1 ms per 0.6 GB) or copied through a ring of
+    //    page-locked staging slots by this thread (items: 26 GB/s on one core, beside the DMA); a pageable output buffer is locked for
+    //    the call as well.
+    // 72 ms for the same job (12.9 M frames/s; the download alone is 67).  The tests run both orders.
+    uint64_t slice_min = HOST_SLICE_MIN;
     if (const char* e = getenv("CRICODECS_HOST_SLICE_MIN")) slice_min = strtoull(e, nullptr, 10);
     const bool sliced = hca_decode_sliceable(j) && out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
     if (!sliced) {
@@ -1630,51 +1701,83 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, A.s_run);
         if (!rc && out_copy) ok(hipMemcpyAsync(out, d_out, out_copy, hipMemcpyDeviceToHost, A.s_run));
     } else {
+        // ---- pipelined: the group cut into slices of whole parse tiles; three streams, two events per slice
         const HcaDecArgs base = j->hca_dec[0];
         const auto& S = j->hca_streams_host;
         const uint32_t tiles = (base.frames + 63) / 64, ns = (uint32_t)S.size();
-        // slices of whole tiles, about 256 MB of PCIe traffic each (at least 4, at most 64)
-        uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) >> 28);
+        uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) / HOST_SLICE_BYTES);
         K = K < 4 ? 4 : (K > 64 ? 64 : K);
-        if (const char* e = getenv("CRICODECS_HOST_SLICES")) K = (uint32_t)strtoul(e, nullptr, 10);   // (developer switch)
-        if (K < 1) K = 1;
         if (K > tiles) K = tiles;
-        const uint32_t TS = (tiles + K - 1) / K;
-        if (gaps && !j->items_packed) ok(hipMemsetAsync(d_in, 0, j->in_bytes, A.s_up));
+        const uint32_t TS = (tiles + K - 1) / K, nslices = (tiles + TS - 1) / TS;
+        for (uint32_t k = 0; k < 2 * nslices + 2; k++) if (!A.event(k)) rc = CRI_ERR_HIP;
+        // Page-locked views of the caller's buffers (see the comment above): what is page-locked already is used as it is, a pageable
+        // blob or output buffer is locked for the duration of the call, anything else goes through the staging ring.
+        PinnedView vin, vout;
+        const uint8_t* pull_src = nullptr;
+        if (src.blob && vin.open((void*)src.blob, j->in_bytes)) pull_src = (const uint8_t*)vin.dev;
+        vout.open(out, j->out_bytes);
+        if (!pull_src && !A.ensure_stage()) rc = CRI_ERR_HIP;
+        uint64_t piece_max = HOST_STAGE_BYTES;                    // (tests cut the pieces small: items then straddle them)
+        if (const char* e = getenv("CRICODECS_HOST_STAGE_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 64 && v < piece_max) piece_max = v; }
         ok(hipMemsetAsync(d_out, 0, j->out_bytes, A.s_run));
         if (d_st) launch_fill_i32(d_st, 0, j->n, A.s_run);
         if (j->n_images)
             launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, d_out, A.s_run);
         uint64_t in_pos = 0, out_pos = 0;
-        uint32_t s_need = 0, s_done = 0, ev = 0;                 // streams whose input is up / whose PCM is down
-        hipStream_t s_dn = A.s_down;
-        // Page-locked source: all uploads are queued first (asynchronous DMA), then the kernels and downloads -- the order in which the
-        // two copy directions overlap on this runtime; a pageable source is staged on this thread, chunk by chunk between the launches.
-        bool src_pinned = false;
-        if (src.blob) {
-            hipPointerAttribute_t at;
-            src_pinned = hipPointerGetAttributes(&at, src.blob) == hipSuccess && at.type == hipMemoryTypeHost;
-            (void)hipGetLastError();
-        }
-        auto slice_upload = [&](uint32_t t1, hipEvent_t e_up) {
-            const uint64_t frames_end = (uint64_t)t1 * 64 < base.frames ? (uint64_t)t1 * 64 : base.frames;
-            while (s_need < ns && S[s_need].first_frame < frames_end) s_need++;      // every stream that has a frame below frames_end
-            const uint64_t in_end = s_need == ns ? j->in_bytes : j->in_offsets[S[s_need].item];
-            const int r = upload_range(j, src, d_in, in_pos, in_end, cursor, A.s_up);
-            in_pos = in_end > in_pos ? in_end : in_pos;
-            ok(hipEventRecord(e_up, A.s_up));
-            return r;
+        uint32_t s_need = 0, s_done = 0;                         // streams whose input is up / whose PCM is down
+        uint32_t slot = 0;
+        // device-input bytes [lo, hi) go up on the upload stream
+        auto upload = [&](uint64_t lo, uint64_t hi) {
+            if (pull_src) { launch_pull_host(d_in + lo, pull_src + lo, hi - lo, A.s_up); return; }
+            while (lo < hi && !rc) {
+                const uint64_t n = hi - lo < piece_max ? hi - lo : piece_max;
+                uint8_t* st = (uint8_t*)A.stage[slot];
+                if (A.stage_busy[slot]) ok(hipEventSynchronize(A.stage_free[slot]));     // the pull that last read this slot
+                if (src.blob) memcpy(st, src.blob + lo, n);
+                else {                                            // the items that overlap [lo, lo + n), zeros between them
+                    uint64_t at = lo;
+                    while (cursor < j->n && j->in_offsets[cursor] < lo + n) {
+                        const uint64_t b = j->in_offsets[cursor], e = b + src.items->lens[cursor];
+                        const uint64_t cb = b > at ? b : at, ce = e < lo + n ? e : lo + n;
+                        if (cb > at) memset(st + (at - lo), 0, cb - at);
+                        if (ce > cb) { memcpy(st + (cb - lo), src.items->ptrs[cursor] + (cb - b), ce - cb); at = ce; } else if (cb > at) at = cb;
+                        if (e > lo + n) break;                    // the rest of this item belongs to the next piece
+                        cursor++;
+                    }
+                    if (at < lo + n) memset(st + (at - lo), 0, lo + n - at);
+                }
+                launch_pull_host(d_in + lo, st, n, A.s_up);
+                ok(hipEventRecord(A.stage_free[slot], A.s_up));
+                A.stage_busy[slot] = true;
+                slot = (slot + 1) % HOST_STAGE_SLOTS;
+                lo += n;
+            }
         };
-        const uint32_t nslices = (tiles + TS - 1) / TS;
-        for (uint32_t k = 0; k < 2 * nslices + 1; k++) if (!A.event(k)) rc = CRI_ERR_HIP;
-        if (src_pinned && !rc)
-            for (uint32_t k = 0, t0 = 0; t0 < tiles && !rc; k++, t0 += TS) rc = slice_upload(t0 + TS < tiles ? t0 + TS : tiles, A.event(2 * k));
+        // A download is queued when the one before it has finished: the runtime picks the engine by what is idle at that moment
+        // (see above), and only the first engine runs the link at full rate.  What the wait costs is the gap between two copies.
+        hipEvent_t e_down = A.event(2 * nslices + 1);
+        bool down_pending = false;
+        auto download = [&](uint64_t lo, uint64_t hi) {
+            if (down_pending) ok(hipEventSynchronize(e_down));
+            ok(hipMemcpyAsync(out + lo, d_out + lo, hi - lo, hipMemcpyDeviceToHost, A.s_down));
+            ok(hipEventRecord(e_down, A.s_down));
+            down_pending = true;
+        };
+        // the input of slice u: every stream that has a frame below the slice's end
+        auto slice_up = [&](uint32_t u) {
+            const uint64_t t1 = (uint64_t)(u + 1) * TS < tiles ? (uint64_t)(u + 1) * TS : tiles;
+            const uint64_t frames_end = t1 * 64 < base.frames ? t1 * 64 : base.frames;
+            while (s_need < ns && S[s_need].first_frame < frames_end) s_need++;
+            const uint64_t in_end = s_need == ns ? j->in_bytes : j->in_offsets[S[s_need].item];
+            if (in_end > in_pos) { upload(in_pos, in_end); in_pos = in_end; }
+            ok(hipEventRecord(A.event(2 * u), A.s_up));
+        };
+        if (!rc) slice_up(0);
         for (uint32_t k = 0, t0 = 0; t0 < tiles && !rc; k++, t0 += TS) {
             const uint32_t t1 = t0 + TS < tiles ? t0 + TS : tiles;
             const uint64_t frames_end = (uint64_t)t1 * 64 < base.frames ? (uint64_t)t1 * 64 : base.frames;
             hipEvent_t e_up = A.event(2 * k), e_run = A.event(2 * k + 1);
-            if (!src_pinned) rc = slice_upload(t1, e_up);
-            ev = 2 * nslices;
+            if (k + 1 < nslices) slice_up(k + 1);                 // one slice ahead: its upload has a whole download's time
             ok(hipStreamWaitEvent(A.s_run, e_up, 0));
             HcaDecArgs a = base;
             a.in = d_in; a.out = d_out; a.scratch = d_scr; a.status = d_st;
@@ -1682,7 +1785,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
             a.cipher_tables = (const uint8_t*)j->d_cipher.p; a.ath_tables = (const uint8_t*)j->d_ath.p; a.float_out = nullptr;
             a.tile_begin = t0; a.tile_count = t1 - t0;
             launch_hca_parse(a, A.s_run);
-            // transform: the streams whose frames are all parsed now
+            // transform and download: the streams whose frames are all parsed now
             uint32_t s_to = s_done;
             while (s_to < ns && (uint64_t)S[s_to].first_frame + S[s_to].frames <= frames_end) s_to++;
             if (s_to > s_done) {
@@ -1690,19 +1793,20 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
                 if (r1 > r0) { a.run_begin = r0; a.run_count = r1 - r0; launch_hca_transform(a, A.s_run); }
                 ok(hipEventRecord(e_run, A.s_run)); ok(hipStreamWaitEvent(A.s_down, e_run, 0));
                 const uint64_t out_end = s_to == ns ? j->out_bytes : j->out_offsets[S[s_to].item];
-                if (out_end > out_pos) ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, out_end - out_pos, hipMemcpyDeviceToHost, s_dn));
+                if (out_end > out_pos) download(out_pos, out_end);
                 out_pos = out_end > out_pos ? out_end : out_pos;
                 s_done = s_to;
             }
         }
         if (!rc && hipGetLastError() != hipSuccess) rc = CRI_ERR_HIP;
         if (!rc && out_pos < j->out_bytes) {                       // (streams without frames at the end: their headers only)
-            hipEvent_t e = A.event(ev++);
-            if (e) { ok(hipEventRecord(e, A.s_run)); ok(hipStreamWaitEvent(A.s_down, e, 0)); }
-            ok(hipMemcpyAsync(out + out_pos, d_out + out_pos, j->out_bytes - out_pos, hipMemcpyDeviceToHost, s_dn));
+            hipEvent_t e = A.event(2 * nslices);
+            ok(hipEventRecord(e, A.s_run)); ok(hipStreamWaitEvent(A.s_down, e, 0));
+            download(out_pos, j->out_bytes);
         }
         ok(hipStreamSynchronize(A.s_up));
         ok(hipStreamSynchronize(A.s_down));
+        for (uint32_t k = 0; k < HOST_STAGE_SLOTS; k++) A.stage_busy[k] = false;
     }
     std::vector<int32_t> st(j->n ? j->n : 1, 0);
     if (status && j->n) ok(hipMemcpyAsync(st.data(), d_st, (size_t)j->n * sizeof(int32_t), hipMemcpyDeviceToHost, A.s_run));

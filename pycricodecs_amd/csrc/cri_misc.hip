@@ -1,6 +1,7 @@
 // cri_misc.hip -- header scatter, status fill and the HCA crypt kernel (gfx950).
 //   k_hca_crypt      HcaCrypt frame loop /root/reference/CriCodecs/hca.cpp:3322-3327.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "cri_kernels.h"
 #include "cri_device.h"
 #include "../../include/cricodecs_hip.h"
@@ -15,6 +16,30 @@ __global__ void k_fill_i32(int32_t* p, int32_t v, uint32_t n) {
 }
 void launch_fill_i32(int32_t* p, int32_t v, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+}
+
+// Host memory -> HBM by the compute units: a few workgroups pull page-locked host memory across the link with 16-byte loads
+// (source-aligned; the head and tail bytes singly).  Used by the pipelined host path for the uploads, so that the downloads have
+// the DMA engines to themselves (cri_capi.cpp, run_host_core).
+__global__ void __launch_bounds__(256) k_pull_host(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t bytes) {
+    const uint64_t head = bytes < 16 ? bytes : ((16 - ((uintptr_t)src & 15)) & 15);
+    const uint64_t words = (bytes - head) >> 4, tail0 = head + (words << 4);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
+    const uint4* s16 = (const uint4*)(src + head);
+    for (uint64_t w = tid; w < words; w += nthr) {
+        const uint4 v = s16[w];
+        uint8_t* d = dst + head + (w << 4);
+        if (((uintptr_t)d & 3) == 0) { uint32_t* d4 = (uint32_t*)d; d4[0] = v.x; d4[1] = v.y; d4[2] = v.z; d4[3] = v.w; }
+        else { const uint32_t q[4] = {v.x, v.y, v.z, v.w}; for (int k = 0; k < 16; k++) d[k] = (uint8_t)(q[k >> 2] >> (8 * (k & 3))); }
+    }
+    if (tid < head) dst[tid] = src[tid];
+    if (tid < bytes - tail0) dst[tail0 + tid] = src[tail0 + tid];
+}
+void launch_pull_host(uint8_t* dst, const uint8_t* src, uint64_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    uint64_t wg = (bytes / 16 + 255) / 256 / 8;
+    wg = wg < 1 ? 1 : (wg > 8 ? 8 : wg);    // 8 workgroups: 19 GB/s, and the downloads beside it keep their rate (cri_capi.cpp, run_host_core)
+    hipLaunchKernelGGL(k_pull_host, dim3((uint32_t)wg), dim3(256), 0, s, dst, src, bytes);
 }
 
 __global__ void k_scatter_images(const uint8_t* img, const uint64_t* img_off, const uint64_t* dst_off, uint32_t n, uint8_t* out) {

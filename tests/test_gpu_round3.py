@@ -154,21 +154,28 @@ def _ragged_hca_batch():
     return uniq, items
 
 
-@pytest.mark.parametrize("slice_min", [None, "0"])
-def test_run_host_equals_device_resident_run(cc, monkeypatch, slice_min):
-    """cri_job_run_host_items (every item from its own host buffer, the arena's private streams; with
-    CRICODECS_HOST_SLICE_MIN=0 the pipelined path: upload / kernels / download of tile slices overlapped) gives the bytes and
-    statuses of the device-resident cri_job_run, and those are the oracle's."""
+@pytest.mark.parametrize("order", ["default", "pipelined", "pipelined-small-pieces", "one-piece"])
+def test_run_host_equals_device_resident_run(cc, monkeypatch, order):
+    """cri_job_run_host_items / _into (host buffers in and out, the arena's private streams) give the bytes and statuses of the
+    device-resident cri_job_run, and those are the oracle's -- in one piece and pipelined (CRICODECS_HOST_SLICE_MIN=0: tile slices,
+    uploads pulled by k_pull_host from page-locked or staged memory, downloads beside them), from separate items (staged; with
+    CRICODECS_HOST_STAGE_PIECE=1000 every item straddles several staging pieces), from a pageable blob (locked for the call), from
+    a page-locked blob, into pageable and into page-locked memory."""
+    import ctypes as C
+    from pycricodecs_amd import _capi
     from pycricodecs_amd.batch import Job, pinned_array, pinned_release
-    if slice_min is not None:
-        monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", slice_min)
+    if order != "default":
+        monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", str(1 << 62) if order == "one-piece" else "0")
+    if order == "pipelined-small-pieces":
+        monkeypatch.setenv("CRICODECS_HOST_STAGE_PIECE", "1000")
     uniq, items = _ragged_hca_batch()
     job = Job.hca_decode(items, keys=[KEY] * len(items))
     assert job.host_status[17] != 0
     want, st_dev = run_job(job)
+    st_want = np.where(job.host_status != 0, job.host_status, st_dev)
     for rep in range(2):                                        # (the second call runs on the cached arena)
         outs, st = job.run_host()
-        assert (st == np.where(job.host_status != 0, job.host_status, st_dev)).all()
+        assert (st == st_want).all()
         for i, (a, b) in enumerate(zip(outs, want)):
             assert bytes(a) == bytes(b), (rep, i)
     refs = {id(u): O.hca_decode(u, KEY) for u in uniq}
@@ -180,8 +187,54 @@ def test_run_host_equals_device_resident_run(cc, monkeypatch, slice_min):
     outs, st = job.run_host(out=buf)
     for i, (a, b) in enumerate(zip(outs, want)):
         assert bytes(a) == bytes(b), i
+    # the blob form: a pageable blob, then the same bytes in page-locked memory at an odd address
+    blob = job.blob
+    status = (C.c_int32 * job.n)()
+    buf[:] = 0xEE
+    assert _capi.lib().cri_job_run_host_into(job._h, blob, buf.ctypes.data, status) == 0
+    assert (np.array(status[:job.n]) == st_want).all()
+    for i, (a, b) in enumerate(zip(job.split(memoryview(buf)), want)):
+        assert bytes(a) == bytes(b), i
+    pin_in = pinned_array(len(blob))
+    pin_in[:] = np.frombuffer(blob, dtype=np.uint8)
+    page_out = np.full(job.output_bytes, 0xEE, dtype=np.uint8)
+    assert _capi.lib().cri_job_run_host_into(job._h, pin_in.ctypes.data, page_out.ctypes.data, status) == 0
+    for i, (a, b) in enumerate(zip(job.split(memoryview(page_out)), want)):
+        assert bytes(a) == bytes(b), i
+    # bytes no kernel writes are zero, in every order (alignment gaps between the items)
+    o = job.output_offsets
+    for i in range(job.n - 1):
+        end = int(o[i]) + len(want[i])
+        assert not page_out[end:int(o[i + 1])].any(), i
     del outs
-    pinned_release(buf)
+    pinned_release(buf); pinned_release(pin_in)
+
+
+@pytest.mark.parametrize("order", ["pipelined", "pipelined-small-pieces", "one-piece"])
+def test_run_host_items_at_caller_offsets(cc, monkeypatch, order):
+    """HCA streams placed at caller offsets with gaps between them (the gaps are zero on the device whatever the staging slots
+    held before), decoded from the items' own buffers."""
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", str(1 << 62) if order == "one-piece" else "0")
+    if order == "pipelined-small-pieces":
+        monkeypatch.setenv("CRICODECS_HOST_STAGE_PIECE", "777")
+    uniq, items = _ragged_hca_batch()
+    items = [it for k, it in enumerate(items) if k != 17][:40]
+    offs = np.zeros(len(items) + 1, dtype=np.uint64)
+    for i, it in enumerate(items):
+        offs[i + 1] = (int(offs[i]) + len(it) + 1000 + 37 * i) // 64 * 64
+    big = Job.hca_decode([uniq[0]] * 3, keys=[KEY] * 3)         # leaves non-zero bytes in the arena's input buffer and staging slots
+    big.run_host()
+    job = Job.hca_decode(items, keys=[KEY] * len(items), offsets=offs)
+    want, st_dev = run_job(job)
+    outs, st = job.run_host()
+    assert (st == np.where(job.host_status != 0, job.host_status, st_dev)).all()
+    for i, (a, b) in enumerate(zip(outs, want)):
+        assert bytes(a) == bytes(b), i
+    refs = {id(u): O.hca_decode(u, KEY) for u in uniq}
+    for i, it in enumerate(items):
+        if id(it) in refs:
+            assert bytes(outs[i]) == refs[id(it)], i
 
 
 def test_run_host_blob_form_and_items_with_offsets(cc):
