@@ -590,12 +590,12 @@ def secondary_measurements(args, D):
                       "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
                       "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "record_forms": census_text(r["census"]),
                       "verified_items": r["verified"]["items"]}
-    # the other transform kernels of the decode path: k_hca_transform<PLAIN, 6 | 8> (wide layouts), k_hca_transform<false, 2> with the
-    # v3.0 noise fill (a v2.0 stream re-headed as v3.0 with min_resolution 0: every band below the noise level is reconstructed),
-    # k_hca_transform_generic (3 channels: a stereo pair that does not start on an even channel)
+    # the other layouts of the decode path: 6, 8 and 3 channels (plain formats: k_hca_transform_plain's wide form, a wave per four
+    # channels), and k_hca_transform<false, 2> with the v3.0 noise fill (a v2.0 stream re-headed as v3.0 with min_resolution 0: every
+    # band below the noise level is reconstructed)
     import hca_forge
     nw = max(1, n // 4)
-    for label, ch, v3 in (("hca_decode_6ch", 6, False), ("hca_decode_8ch", 8, False), ("hca_decode_v3_noise_fill", 2, True), ("hca_decode_3ch_generic", 3, False)):
+    for label, ch, v3 in (("hca_decode_6ch", 6, False), ("hca_decode_8ch", 8, False), ("hca_decode_v3_noise_fill", 2, True), ("hca_decode_3ch", 3, False)):
         plain = [O.hca_encode(family_wav(8000 + 10 * ch + u, args.seconds, "tonal", ch=ch), 1) for u in range(4)]
         if v3:
             plain = [hca_forge.forge_v3(h, 0) for h in plain]

@@ -416,7 +416,7 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         if (a.noise_fill) a.plain = 0;                                 // noise reconstruction lives in the general variant of the transform
         // int8 lines are read by k_hca_transform_plain<1>, <2>, <4> and (joint stereo / HFR formats) k_hca_transform<false, 1>,
         // <false, 2>; v3.0 noise fill and the wider layouts keep int16
-        a.narrow = (!a.noise_fill && (a.channels <= 2 || (a.channels == 4 && a.plain))) ? 1 : 0;
+        a.narrow = (!a.noise_fill && (a.channels <= 2 || a.plain)) ? 1 : 0;         // (plain formats of any channel count: k_hca_transform_plain in channel groups)
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
         a.inlane = (!a.plain && !a.noise_fill && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) ? 1 : 0;
@@ -1651,7 +1651,7 @@ bool hca_decode_sliceable(const cri_job* j) {
     if (j->kind != CRI_JOB_HCA_DECODE || j->hca_dec.size() != 1 || j->convert_total) return false;
     const HcaDecArgs& a = j->hca_dec[0];
     if (a.noise_fill || !a.frames || !a.runs) return false;
-    const bool in_regs = a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    const bool in_regs = a.plain || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
     if (!in_regs) return false;
     const auto& S = j->hca_streams_host;
     if (S.size() != (size_t)(a.stream_end - a.stream_begin)) return false;

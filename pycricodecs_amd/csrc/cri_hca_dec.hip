@@ -1558,6 +1558,7 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
 // eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of HCA_RUN
 // frames, but its 4 slots ("units") are 4/C groups x C channels: each group takes a contiguous part of the run and walks
 // it frame by frame, subframe by subframe, after one halo pass (the subframe before its first one).
+#define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
 struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
 #ifndef CRI_PLAIN_WAVES
@@ -1569,13 +1570,27 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t sf2[4]; };   // s
 // JOINT: the format has high-frequency reconstruction and / or intensity stereo (a stereo pair is an even channel and the next one,
 // i.e. two neighbouring units of one group): each pass stages the units' dequantised lines in LDS, a reconstructed band reads its
 // source band there, a secondary reads its primary's row.
-template <int C, bool FLT, bool JOINT>
-__global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// WIDE (C = 4 only): a plain format with CT = 3, 5, 6, 7 or 8 channels.  Plain channels do not depend on each other, so the
+// workgroup is (CT + 3) / 4 waves that each take four channels of the SAME run through the same steps (channels past CT - 1 are
+// dummies: they follow the last channel and their PCM goes to a dump slot), stage their PCM into one shared [128][CT] piece and,
+// after a barrier, store it as whole sample frames -- 16 contiguous bytes per thread.  (A launch per channel group, each
+// storing its 2C-byte pieces a sample frame apart, spent as long on those stores as on everything else: 7.8 ms against 3.9
+// for 1000 eight-channel streams.)
+template <int C, bool FLT, bool JOINT, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
+    static_assert(!WIDE || (C == 4 && !JOINT), "the wide form is four channels per wave of a plain format");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
+    const uint32_t CT = WIDE ? a.channels : (uint32_t)C;   // channels of the records, the line tiles and the PCM interleave
+    const uint32_t wv = WIDE ? threadIdx.x >> 6 : 0u, CB = 4 * wv;
+    uint8_t* smem = smem_all + wv * HCA_PLAIN_LDS_BYTES;
+    uint16_t* pcmw = (uint16_t*)(smem_all + (WIDE ? (blockDim.x >> 6) * HCA_PLAIN_LDS_BYTES : 0u));      // WIDE: the shared [128][CT] piece, then 128 B of dump
     constexpr bool NW = true;                              // int8 lines (HCA_REC_NARROW) are read by all three instances
     const Fmt F = load_fmt(a.formats + a.format);
-    const uint32_t lane = threadIdx.x, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
+    const uint32_t lane = threadIdx.x & 63, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
+    auto chan_of = [&](uint32_t v) { return WIDE ? (CB + v < CT ? CB + v : CT - 1) : v % C; };      // channel of unit v
+    const uint32_t cc = chan_of(u);
+    const bool ch_live = !WIDE || CB + c < CT;
     float* G = (float*)smem;                               // [4][128] gains of each unit's frame
     uint16_t* pcm = (uint16_t*)(G + 512);                  // [NG][128][C] one pass of PCM16
     float* scale = (float*)(pcm + 512); float* range = scale + 64; uint8_t* curve = (uint8_t*)(range + 16);   // 80 bytes
@@ -1600,6 +1615,12 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     for (int j = 0; j < 4; j++) {
         const uint32_t k = ((j < 2 ? dlogp.x : dlogp.y) >> (16 * (j & 1))) & 0xFF;      // register 2j: k < 64 (register 2j+1: 127 - k)
         wtab[2 * j] = HCA_WINDOW[63 - k]; wtab[2 * j + 1] = HCA_WINDOW[64 + k];
+        if (WIDE) {
+            uint8_t* dump = (uint8_t*)pcmw + 2048 + lane * 2;
+            potab[j] = lds_address(ch_live ? (uint8_t*)pcmw + ((64 + k) * CT + CB + c) * 2 : dump);
+            potab[4 + j] = lds_address(ch_live ? (uint8_t*)pcmw + ((63 - k) * CT + CB + c) * 2 : dump);
+            continue;
+        }
         const uint32_t po = ((g * 128 + 64 + k) * C + c) * 2;
         potab[j] = lds_address((uint8_t*)pcm + po); potab[4 + j] = lds_address((uint8_t*)pcm + (((2 * g * 128 + 127) * C + 2 * c) * 2 - po));
     }
@@ -1661,7 +1682,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         }
     }
     const uint32_t ath2 = ((const uint16_t*)(a.ath_tables + F.ath_index * 128))[lane];
-    const bool dword_ok = ((st.delay * C * 2) & 3) == 0;
+    const bool dword_ok = ((st.delay * CT * 2) & 3) == 0;
     uint8_t* dst = a.out + st.dst_offset;
 
     // unit v (any lane can name it: the setup works on all four): first frame, frame count
@@ -1678,7 +1699,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         PlainPre p;
         {
             bool live; const uint32_t f = unit_frame(lane & 3, s, live);
-            const uint32_t* tail = (const uint32_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_TAIL(C));
+            const uint32_t* tail = (const uint32_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_TAIL(CT));
             p.ps = *(const uint2*)tail; p.fl = NW ? tail[2] : 0u;
             p.ps.y = live ? p.ps.y : 0u;
         }
@@ -1691,7 +1712,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
             bool live; const uint32_t f = unit_frame(v, s, live);
-            p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(C, v % C)))[lane];
+            p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(CT, chan_of(v))))[lane];
         }
         return p;
     };
@@ -1714,7 +1735,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         }
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
-            const uint32_t packed = __builtin_amdgcn_readlane(p.ps.x, v), sf2 = p.sf2[v], coded = F.coded(v % C);
+            const uint32_t packed = __builtin_amdgcn_readlane(p.ps.x, v), sf2 = p.sf2[v], coded = F.coded(chan_of(v));
             const bool neg = NW && (__builtin_amdgcn_readlane(p.fl, v) & HCA_REC_NARROW) != 0;      // negated lines: negated gains (exact)
             float gn[2];
 #pragma unroll
@@ -1770,11 +1791,11 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     // this lane's bands l16*8 .. +7 sit in a row: 16 bytes of int16 (quarter l16 / 4) or 8 bytes of int8 (quarter l16 / 8)
     // (as a 32-bit offset from the tile of the frame before the run's first one: the run and its halo span at most two tiles)
     const uint32_t g_run = st.first_frame + f0 - (f0 > 0 ? 1 : 0);
-    const uint8_t* rec_run = a.scratch + a.qc_offset + (uint64_t)(g_run >> 6) * HCA_QC_TILE(C);
+    const uint8_t* rec_run = a.scratch + a.qc_offset + (uint64_t)(g_run >> 6) * HCA_QC_TILE(CT);
     auto row0 = [&](int s) {
         bool live; const uint32_t f = unit_frame(u, s, live);
         const uint32_t g = st.first_frame + f;
-        return ((g >> 6) - (g_run >> 6)) * HCA_QC_TILE(C) + (g & 63) * 64 + HCA_QC_ROW(C, 0, c);
+        return ((g >> 6) - (g_run >> 6)) * HCA_QC_TILE(CT) + (g & 63) * 64 + HCA_QC_ROW(CT, 0, cc);
     };
     auto lane_off = [&](bool narrow) { return narrow ? (l16 >> 3) * HCA_QC_QUARTER + (l16 & 7) * 8 : (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16; };
     // (step_narrow: all four units' frames are int8 -- wave-uniform; mine: this lane's is)
@@ -1817,7 +1838,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
     uint32_t rows = row0(-1);                              // rows of the current step's frame
     uint4 q = make_uint4(0, 0, 0, 0);
     {   // (the one load of a run that waits for a flag first)
-        const uint8_t* p = rec_run + (rows + HCA_QC_ROW(C, 7, 0) + lane_off(my_narrow(pre)));
+        const uint8_t* p = rec_run + (rows + HCA_QC_ROW(CT, 7, 0) + lane_off(my_narrow(pre)));
         if (NW && all_narrow(pre)) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
     }
     const uint32_t last_count = unit_count(3);             // frames of the last group: steps below it have every group at work
@@ -1828,6 +1849,17 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
         if (pend_n00 == 0xFFFFFFFFu) return;
         typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
         const uint32_t gk = lane / (16 * C), wi = 4 * lane - gk * 64 * C;
+        if (WIDE) {                                        // the workgroup's 256 * CT bytes: 16 per thread
+            if (threadIdx.x * 16 < 256 * CT) {
+                const uint4 vw = ((const uint4*)pcmw)[threadIdx.x];
+#ifdef HCA_ABL_NOPCM
+                if (vw.x == 0x12345678u && vw.y == 0x9abcdef0u)
+#endif
+                *(u4u*)((uint32_t*)(dst + (uint64_t)(pend_n00 - st.delay) * CT * 2) + 4 * threadIdx.x) = u4u{vw.x, vw.y, vw.z, vw.w};
+            }
+            pend_n00 = 0xFFFFFFFFu;
+            return;
+        }
         const uint4 v = ((const uint4*)pcm)[lane];
 #ifdef HCA_ABL_NOPCM
         if (v.x == 0x12345678u && v.y == 0x9abcdef0u)      // (timing experiment: the stores practically never happen)
@@ -1856,7 +1888,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             flush_pcm();                                   // the previous pass's PCM (staged in LDS since)
             {   // (8 bytes per lane when the whole step reads int8 lines: 16 would reach into the unused half of the row's 256 B)
                 const uint8_t* p; bool ld8;
-                if (sf < 7) { p = rec_run + (rows + HCA_QC_ROW(C, sf + 1, 0) + loff); ld8 = NW && step_narrow; }
+                if (sf < 7) { p = rec_run + (rows + HCA_QC_ROW(CT, sf + 1, 0) + loff); ld8 = NW && step_narrow; }
                 else {                                     // the next step's first row, laid out by that frame's own flag (it came with `pre` seven passes ago)
                     const bool more = s + 1 < (int)h;
                     p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);
@@ -1869,6 +1901,7 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
             }
             __builtin_amdgcn_sched_barrier(0);             // (keep the load here: the compiler would sink it behind most of the DCT)
             dct4_inplace(x, L);
+            if (WIDE) __syncthreads();                     // (every wave has taken the previous pass's PCM out of the shared piece)
             if (s < 0) {
                 bool live; unit_frame(u, -1, live);
 #pragma unroll
@@ -1891,10 +1924,10 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                 o[j] = wv * f2{32768.0f, 32768.0f};
                 if (FLT) {
                     bool live; const uint32_t ff = unit_frame(u, s, live);
-                    if (live) {
+                    if (live && ch_live) {
                         const uint32_t k = ((j < 2 ? dlogp.x : dlogp.y) >> (16 * (j & 1))) & 0xFF;
-                        float* fo = a.float_out + st.float_offset + ((uint64_t)ff * 1024 + sf * 128) * C + c;
-                        fo[(uint64_t)(63 - k) * C] = wv.x; fo[(uint64_t)(64 + k) * C] = wv.y;
+                        float* fo = a.float_out + st.float_offset + ((uint64_t)ff * 1024 + sf * 128) * CT + cc;
+                        fo[(uint64_t)(63 - k) * CT] = wv.x; fo[(uint64_t)(64 + k) * CT] = wv.y;
                     }
                 }
                 prev[j] = x[j].x;
@@ -1921,13 +1954,19 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                     *(lds_u16*)(uintptr_t)po[j] = (uint16_t)pk.y;
                 }
             }
-            wave_lds_sync();
+            if (WIDE) __syncthreads(); else wave_lds_sync();
             // 256*C contiguous bytes per group; delay / length trim of hca.cpp:3392-3425
             const uint32_t n00 = (f0 + (uint32_t)s) * 1024 + sf * 128;   // first sample (per channel) of group 0's subframe
             if (dword_ok && (uint32_t)s < last_count && n00 >= st.delay && n00 + (NG - 1) * h * 1024 + 128 - st.delay <= st.samples) {
                 // one 16-byte store per lane, issued by the next pass (flush_pcm): the staging area is the groups' 256*C-byte pieces back
                 // to back (the output address is only dword-aligned: the WAV header is 44 bytes)
                 pend_n00 = n00;
+            } else if (WIDE) {                             // (a frame cut by the delay or the length trim, or an odd alignment)
+                const uint32_t n0 = (f0 + (uint32_t)s) * 1024 + sf * 128;
+                for (uint32_t e = threadIdx.x; e < 128 * CT; e += blockDim.x) {
+                    const uint32_t n = n0 + e / CT;
+                    if (n >= st.delay && n - st.delay < st.samples) *(uint16_t*)(dst + ((uint64_t)(n - st.delay) * CT + e % CT) * 2) = pcmw[e];
+                }
             } else {
 #pragma unroll 1
                 for (uint32_t k = 0; k < 4; k++) {
@@ -1948,14 +1987,14 @@ __global__ __launch_bounds__(64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void
                     }
                 }
             }
-            wave_lds_sync();
+            if (WIDE) __syncthreads(); else wave_lds_sync();
         }
         rows = next_rows;
     }
     flush_pcm();
 }
 
-#define HCA_PLAIN_LDS (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
+#define HCA_PLAIN_LDS HCA_PLAIN_LDS_BYTES
 #define HCA_PLAIN_JOINT_LDS (HCA_PLAIN_LDS + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
@@ -1965,7 +2004,7 @@ size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
-    const bool in_regs = a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    const bool in_regs = a.plain || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
     if (in_regs) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
         const bool flt = a.float_out != nullptr;
@@ -1980,7 +2019,12 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
             case 1: CRI_LAUNCH_PL(1); break;
             case 2: CRI_LAUNCH_PL(2); break;
             case 4: CRI_LAUNCH_PL(4); break;
-            case 6: CRI_LAUNCH_TR(true, 6); break; default: CRI_LAUNCH_TR(true, 8); break;
+            default: {                                     // 3, 5, 6, 7, 8 channels: a wave per four channels, whole sample frames out
+                const uint32_t nw = (a.channels + 3) / 4;
+                const size_t wlds = nw * HCA_PLAIN_LDS + 2048 + 128;
+                if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
+                else hipLaunchKernelGGL((k_hca_transform_plain<4, false, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
+            } break;
         } else if (a.inlane) switch (a.channels) {
             case 1: CRI_LAUNCH_PJ(1); break; case 2: CRI_LAUNCH_PJ(2); break; default: CRI_LAUNCH_PJ(4); break;
         } else switch (a.channels) {
