@@ -1105,6 +1105,21 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
         uint32_t lanes = 0, chains = 0; uint64_t rounds = 0;
         std::vector<int16_t> hist2;
         bool usable = true;
+        // Lanes in order of decreasing length: the 64 lanes of a wave run as long as its longest segment, and a bank of ragged clips
+        // in item order pairs 0.05 s clips with 2 s ones (the segmented decoder sorts the same way).  `first_chain` still names the
+        // file's entries in `history`, which is re-packed below in the new order.
+        {
+            auto seg_len = [&](const AdxStream& S) {
+                const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
+                if (g <= 0 || !S.frames) return (uint64_t)S.frames;
+                const uint64_t lmin = std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4);
+                const uint64_t rows = (std::max<uint64_t>((S.frames + p_target - 1) / p_target, lmin) + 3) / 4 * 4;
+                return std::min<uint64_t>(rows, S.frames);
+            };
+            bool wide = false;
+            for (const AdxStream& S : streams) wide = wide || S.channels > 2;
+            if (!wide) std::stable_sort(streams.begin(), streams.end(), [&](const AdxStream& x, const AdxStream& y) { return seg_len(x) > seg_len(y); });
+        }
         for (AdxStream& S : streams) {
             const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
             // a segment has to be longer than the encoder's merge time (600 rows at worst for tonal material, 2200 for sparse, at g = 39)
