@@ -184,3 +184,13 @@ def frame_size_stream(hca: bytes, frame_size: int, nfr: int, seed: int) -> bytes
         fr = b"\xff\xff" + rng.integers(0, 256, frame_size - 4, dtype=np.uint8).tobytes()
         body += fr + struct.pack(">H", crc16(fr))
     return bytes(h[:hs]) + body
+
+
+def forge_trim(hca: bytes, delay: int, padding: int) -> bytes:
+    """Rewrite encoder_delay / encoder_padding of the fmt chunk (hca.cpp:662-687: bytes 0x14-0x17 of a stream whose fmt chunk
+    follows the signature) and fix the header CRC: the decoder drops `delay` samples at the start and `padding` at the end."""
+    b = bytearray(hca)
+    assert bytes(x & 0x7F for x in b[8:12]) == b"fmt\0"
+    b[0x14:0x18] = struct.pack(">HH", delay, padding)
+    fix_header_crc(b)
+    return bytes(b)

@@ -481,3 +481,26 @@ def test_adx_segmented_decode_through_silence_and_pure_tones(cc):
     enc = Job.adx_encode([synth.wav_bytes(tone, 48000), synth.wav_bytes(gap, 48000)])
     outs, st = run_job(enc)
     assert bytes(outs[0]) == files[0] and bytes(outs[1]) == files[1]
+
+
+# ------------------------------------------------------------------------------------------------ wide layouts on the in-lane transform
+@pytest.mark.parametrize("ch", [3, 5, 6, 7, 8])
+def test_wide_plain_layouts_trims_and_alignments(cc, ch):
+    """k_hca_transform_plain's wide form (a wave per four channels, whole sample frames stored from a shared staging piece):
+    3, 5, 6, 7 and 8 channels against the oracle, with the delay / padding trims that decide how the PCM leaves -- an even
+    delay (16-byte stores), an odd delay on an odd channel count (the sample-by-sample path for every frame), trims inside the
+    first and the last frame, a trim longer than a frame, encrypted and plain, streams that end inside a run of eight frames."""
+    import hca_forge
+    from pycricodecs_amd.batch import Job
+    items, keys = [], []
+    for k, (n, delay, pad) in enumerate([(9000, 128, 0), (9000, 1, 0), (12000, 127, 77), (2048 * 5, 1029, 1500), (700, 0, 3), (1024 * 9, 2, 1)]):
+        h = O.hca_encode(synth.wav(2100 + 10 * ch + k, n, ch, 48000), 1)
+        h = hca_forge.forge_trim(h, delay, pad)
+        if k % 2:
+            h = O.hca_crypt(h, 1, 56, KEY)
+        items.append(h); keys.append(KEY if k % 2 else 0)
+    job = Job.hca_decode(items, keys=keys)
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, h, key) in enumerate(zip(outs, items, keys)):
+        assert bytes(o) == O.hca_decode(h, key), (ch, i)

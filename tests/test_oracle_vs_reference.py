@@ -323,3 +323,13 @@ def test_hca_crypt_extreme_frame_sizes(fs):
     assert e is not None
     assert both(lambda: O.hca_crypt(e, 0, 0, KEY), lambda: R.hca_crypt(e, 0, 0, KEY)) == s
     both(lambda: O.hca_crypt(s, 1, 1, 0), lambda: R.hca_crypt(s, 1, 1, 0))
+
+
+@pytest.mark.parametrize("ch", [1, 2, 3, 5, 6, 7, 8])
+def test_hca_delay_and_padding_trims(ch):
+    """The delay / padding trims of the decode loop (hca.cpp:3392-3425) on forged fmt chunks: odd delays, a delay longer than
+    a frame, a padding that reaches into the second-to-last frame -- every channel count the transform kernels are
+    instantiated for (tests/test_gpu_round3.py decodes the same streams on the device)."""
+    for k, (n, delay, pad) in enumerate([(9000, 128, 0), (9000, 1, 0), (12000, 127, 77), (2048 * 5, 1029, 1500), (700, 0, 3), (1024 * 9, 2, 1)]):
+        h = hca_forge.forge_trim(O.hca_encode(synth.wav(2100 + 10 * ch + k, n, ch, 48000), 1), delay, pad)
+        both(lambda: O.hca_decode(h), lambda: R.hca_decode(h))
