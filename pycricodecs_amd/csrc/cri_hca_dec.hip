@@ -314,6 +314,10 @@ __device__ __forceinline__ uint32_t band_meta(uint32_t res) {
     return bits | (t << 4);
 }
 
+// The sixteen description bytes hashed into 32 table slots (as a byte offset into a float table): k_hca_transform_plain finds
+// a band's dequantiser range by the description the parse left, not by computing the resolution again.
+__device__ __forceinline__ uint32_t desc_key(uint32_t meta) { return ((meta * 69u) >> 4) & 0x7Cu; }
+
 // Symbol values of the prefix codes: entry [T / 2][next four bits of the stream] = -value & 0xFF, the byte an int8 record line
 // holds (HCA_REC_NARROW).  In a block of 16 bands in which no frame of the wave has a longer code (parse_block path below)
 // a symbol's LENGTH is one compare against T -- the only thing the next symbol waits for -- and its value is a table read
@@ -1625,8 +1629,12 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         potab[j] = lds_address((uint8_t*)pcm + po); potab[4 + j] = lds_address((uint8_t*)pcm + (((2 * g * 128 + 127) * C + 2 * c) * 2 - po));
     }
     scale[lane] = HCA_DEQ_SCALE[lane];
-    if (lane < 16) range[lane] = HCA_DEQ_RANGE[lane];
-    curve[lane] = HCA_CURVE_TO_RES[lane]; if (lane < 2) curve[64 + lane] = HCA_CURVE_TO_RES[64 + lane];
+    // A band's resolution is not computed again here (calculate_resolution, hca.cpp:1450-1488: ATH, noise level, curve, clamps): the
+    // parse has left its code description byte in scratch (band_meta: one value per resolution), and desc_key() hashes the sixteen
+    // values into 32 slots of the dequantiser's range table (the 144 bytes the range and curve tables used to take)
+    if (lane < 32) range[lane] = 0.0f;
+    wave_lds_sync();
+    if (lane < 16) range[desc_key(band_meta(lane)) >> 2] = HCA_DEQ_RANGE[lane];
     // JOINT only: S[4][128] the pass's dequantised lines, hconv[4][128] HFR scale of a reconstructed band (per unit's frame),
     // conv[128], iratio[16], zero[4], ratio[4][8] intensity ratio of the unit's pair per subframe, sfb[4][128] scalefactor bytes,
     // hlow[128] / hgrp[128] source band and HFR group of a reconstructed band (format constants)
@@ -1681,7 +1689,8 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             if (shared && (from_prev || tc == CRI_CH_PRIMARY)) ratio_mask |= 1u << r;
         }
     }
-    const uint32_t ath2 = ((const uint16_t*)(a.ath_tables + F.ath_index * 128))[lane];
+    // this lane's two bands (2 * lane, 2 * lane + 1) in a frame's code descriptions: [tile][channel][block of 16 bands][frame 64][16 B]
+    const uint8_t* desc0 = a.scratch + a.resg_offset + (lane >> 3) * 1024 + (lane & 7) * 2;
     const bool dword_ok = ((st.delay * CT * 2) & 3) == 0;
     uint8_t* dst = a.out + st.dst_offset;
 
@@ -1712,7 +1721,9 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
             bool live; const uint32_t f = unit_frame(v, s, live);
-            p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(CT, chan_of(v))))[lane];
+            const uint32_t gf = st.first_frame + f;
+            const uint32_t d2 = *(const uint16_t*)(desc0 + (((uint64_t)(gf >> 6) * CT + chan_of(v)) * 8 * 64 + (gf & 63)) * 16);
+            p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(CT, chan_of(v))))[lane] | d2 << 16;      // scalefactors | descriptions << 16
         }
         return p;
     };
@@ -1735,20 +1746,13 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         }
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
-            const uint32_t packed = __builtin_amdgcn_readlane(p.ps.x, v), sf2 = p.sf2[v], coded = F.coded(chan_of(v));
+            const uint32_t sf2 = p.sf2[v], coded = F.coded(chan_of(v));
             const bool neg = NW && (__builtin_amdgcn_readlane(p.fl, v) & HCA_REC_NARROW) != 0;      // negated lines: negated gains (exact)
             float gn[2];
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
-                const uint32_t i = 2 * lane + hh, sv = (sf2 >> (8 * hh)) & 0xFF;
-                const int noise = (int)((ath2 >> (8 * hh)) & 0xFF) + (int)((packed + i) >> 8);
-                const int cp = noise + 1 - (int)((5 * sv) >> 1);
-                const int cpc = cp < 0 ? 0 : (cp > 65 ? 65 : cp);
-                uint32_t res = curve[cpc];
-                res = cp < 0 ? 15u : (cp > 65 ? 0u : res);
-                res = res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
-                res = sv > 0 ? res : 0u;
-                const float gain = scale[sv & 63] * range[res & 15];
+                const uint32_t i = 2 * lane + hh, sv = (sf2 >> (8 * hh)) & 0xFF, ds = (sf2 >> (16 + 8 * hh)) & 0xFF;
+                const float gain = scale[sv & 63] * *(const float*)((const uint8_t*)range + desc_key(ds));
                 gn[hh] = i < coded ? (neg ? -gain : gain) : 0.0f;
             }
             *(float2*)(G + v * 128 + 2 * lane) = make_float2(gn[0], gn[1]);
