@@ -29,7 +29,8 @@ CMDS[adx_roundtrip]="python bench.py --workload adx_roundtrip --no-cpu --no-veri
 CMDS[awb_mixed]="python bench.py --workload awb_mixed --no-verify"
 CMDS[hca_crypt]="python tools/debug/crypt_time.py"
 CMDS[secondaries_1000]="python bench.py --streams 1000 --no-cpu --no-verify --steps 2 --warmup 1 --host-streams 500"
-for w in hca_decode hca_encode adx_roundtrip awb_mixed hca_crypt secondaries_1000; do
+CMDS[wide_layouts]="python tools/debug/wide_layouts.py 1000"
+for w in hca_decode hca_encode adx_roundtrip awb_mixed hca_crypt secondaries_1000 wide_layouts; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/t_$w -o t -- ${CMDS[$w]} > $OUT/trace_$w.log 2>&1
   find $RAW/t_$w -name "*kernel_stats.csv" -exec cp {} $OUT/${w}_kernel_stats.csv \;
 done
@@ -73,4 +74,4 @@ python tools/debug/enc_phases.py > $OUT/hca_encode_phases.txt 2>&1
 python -m pycricodecs_amd.build --force > /dev/null 2>&1
 tail -20 $OUT/hca_encode_phases.txt
 fi
-for w in hca_decode hca_encode adx_roundtrip awb_mixed secondaries_1000; do echo "== $w"; head -8 $OUT/${w}_kernel_stats.csv; done
+for w in hca_decode hca_encode adx_roundtrip awb_mixed secondaries_1000 wide_layouts; do echo "== $w"; head -8 $OUT/${w}_kernel_stats.csv; done
