@@ -20,7 +20,7 @@ def short(k):
 def main(tag):
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
-    for w in ("hca_decode", "hca_encode", "adx_roundtrip", "awb_mixed", "hca_crypt", "secondaries_1000"):
+    for w in ("hca_decode", "hca_encode", "adx_roundtrip", "awb_mixed", "hca_crypt", "secondaries_1000", "wide_layouts"):
         p = os.path.join(src, w + "_kernel_stats.csv")
         if os.path.exists(p):
             rows = list(csv.reader(open(p)))
