@@ -1562,8 +1562,18 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
 // eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of HCA_RUN
 // frames, but its 4 slots ("units") are 4/C groups x C channels: each group takes a contiguous part of the run and walks
 // it frame by frame, subframe by subframe, after one halo pass (the subframe before its first one).
+// k steps of the decoder's generator as one affine map, k = 0 .. 128: r_k = v[k].x * r + v[k].y
+struct LcgMap { uint32_t x, y; };
+struct LcgPow { LcgMap v[130]; };
+constexpr LcgPow make_lcg_pow() {
+    LcgPow t{};
+    uint32_t m = 1, c = 0;
+    for (int k = 0; k < 130; k++) { t.v[k].x = m; t.v[k].y = c; c = c * 0x343FDu + 0x269EC3u; m = m * 0x343FDu; }
+    return t;
+}
+__device__ const LcgPow HCA_LCG_POW = make_lcg_pow();
 #define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
-struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
+struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
 #ifndef CRI_PLAIN_WAVES
 #define CRI_PLAIN_WAVES 4
@@ -1580,9 +1590,16 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t sf2[4]; };   // s
 // after a barrier, store it as whole sample frames -- 16 contiguous bytes per thread.  (A launch per channel group, each
 // storing its 2C-byte pieces a sample frame apart, spent as long on those stores as on everything else: 7.8 ms against 3.9
 // for 1000 eight-channel streams.)
-template <int C, bool FLT, bool JOINT, bool WIDE = false>
+// NOISE (with JOINT): v3.0 streams with min_resolution 0 -- a band whose resolution came out 0 is filled, subframe by subframe, with
+// a randomly chosen coded band of its channel, scaled by the difference of their scalefactors (reconstruct_noise, hca.cpp:1602-1635),
+// before HFR and intensity stereo read the spectrum.  The generator runs on through a stream's frames, channels and subframes:
+// k_hca_noise_scan has left the draws before each frame in its record, a frame's start state is one O(log n) jump from the seed
+// (on the scalar unit: it is the same for the whole unit), the step from one subframe to the next is one affine map per frame, and a
+// lane reaches its first noise band of a subframe through a table of the generator's powers (HCA_LCG_POW).
+template <int C, bool FLT, bool JOINT, bool WIDE = false, bool NOISE = false>
 __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     static_assert(!WIDE || (C == 4 && !JOINT), "the wide form is four channels per wave of a plain format");
+    static_assert(!NOISE || JOINT, "noise fill stages the spectrum like the joint form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
     const uint32_t CT = WIDE ? a.channels : (uint32_t)C;   // channels of the records, the line tiles and the PCM interleave
@@ -1640,6 +1657,9 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
     // hlow[128] / hgrp[128] source band and HFR group of a reconstructed band (format constants)
     float* S = (float*)(curve + 80 + 2048 + 2048); float* hconv = S + 512; float* conv = hconv + 512; float* iratio = conv + 128;
     float* ratio = iratio + 16; float* zero = ratio + 32; uint8_t* sfb = (uint8_t*)(zero + 4); uint8_t* hlow = sfb + 512; uint8_t* hgrp = hlow + 128;
+    // NOISE only: nrank[4][128] rank of a band among its unit's noise bands (0xFF: not one), vlist[4][128] the unit's coded bands in
+    // ascending order, nmeta[4][4] = {coded bands, draws per subframe, generator state of the unit's next subframe, -}
+    uint8_t* nrank = hgrp + 128; uint8_t* vlist = nrank + 512; uint32_t* nmeta = (uint32_t*)(vlist + 512);
     constexpr uint32_t ZERO_IDX = 512 + 512 + 128 + 16 + 32;            // (index of `zero` from S)
     int nproc = 0;                                         // bands reconstructed by HFR (hca.cpp:1650-1676), as in k_hca_transform
     if (JOINT) {
@@ -1711,6 +1731,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             const uint32_t* tail = (const uint32_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_TAIL(CT));
             p.ps = *(const uint2*)tail; p.fl = NW ? tail[2] : 0u;
             p.ps.y = live ? p.ps.y : 0u;
+            p.dr = NOISE ? tail[3] : 0u;
         }
         p.ib = 0;
         if (JOINT) {                                       // lane < 32: intensity byte (lane & 7) of unit lane >> 3's pair (its secondary's entry)
@@ -1738,6 +1759,11 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         return (__builtin_amdgcn_readlane(p.fl, 0) & __builtin_amdgcn_readlane(p.fl, 1) & __builtin_amdgcn_readlane(p.fl, 2) & __builtin_amdgcn_readlane(p.fl, 3) & HCA_REC_NARROW) != 0;
     };
     // gains of the four units' frames (hca.cpp:1444-1507), two bands per lane; false if one of the frames is bad
+    // NOISE: per-lane state of the unit's generator (set by setup for each step, advanced by every pass)
+    uint32_t noise_vc[4] = {0, 0, 0, 0}, noise_nd[4] = {0, 0, 0, 0};
+    uint32_t noise_am = 1, noise_ac = 0, noise_ja = 1, noise_jc = 0, noise_cur = 0, noise_vcu = 0;
+    uint2 noise_rk = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    bool noise_mine = false;
     auto setup = [&](const PlainPre& p, int cur_step) {
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
@@ -1757,8 +1783,53 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             }
             *(float2*)(G + v * 128 + 2 * lane) = make_float2(gn[0], gn[1]);
             if (JOINT) ((uint16_t*)sfb)[v * 64 + lane] = (uint16_t)sf2;
+            if (NOISE) {                                   // the unit's noise / coded band lists (hca.cpp:1489-1497), two bands per lane
+                bool isn[2], isv[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) {
+                    const uint32_t i = 2 * lane + hh, sv = (sf2 >> (8 * hh)) & 0xFF, ds = (sf2 >> (16 + 8 * hh)) & 0xFF;
+                    const bool live = i < coded && sv > 0;
+                    isn[hh] = live && ds == 0; isv[hh] = live && ds != 0;      // (description 0 = resolution 0)
+                }
+                const uint64_t below = (1ull << lane) - 1;
+                const uint64_t bn0 = __ballot(isn[0]), bn1 = __ballot(isn[1]), bv0 = __ballot(isv[0]), bv1 = __ballot(isv[1]);
+                const uint32_t nc = __popcll(bn0) + __popcll(bn1), vc = __popcll(bv0) + __popcll(bv1);
+                const uint32_t rn = __popcll(bn0 & below) + __popcll(bn1 & below), rv = __popcll(bv0 & below) + __popcll(bv1 & below);
+                nrank[v * 128 + 2 * lane] = isn[0] ? (uint8_t)rn : (uint8_t)0xFF;
+                nrank[v * 128 + 2 * lane + 1] = isn[1] ? (uint8_t)(rn + (isn[0] ? 1 : 0)) : (uint8_t)0xFF;
+                if (isv[0]) vlist[v * 128 + rv] = (uint8_t)(2 * lane);
+                if (isv[1]) vlist[v * 128 + rv + (isv[0] ? 1 : 0)] = (uint8_t)(2 * lane + 1);
+                noise_vc[v] = vc; noise_nd[v] = (nc > 0 && vc > 0) ? nc : 0u;
+            }
+        }
+        if (NOISE) {
+            // generator state at the start of each unit's next subframe: its frame's draws before it (k_hca_noise_scan), the whole
+            // subframes before it (the halo step starts at subframe 7) and the channels below it -- all wave-uniform, scalar work
+            const uint32_t sf0 = cur_step < 0 ? 7u : 0u;
+#pragma unroll
+            for (uint32_t v = 0; v < 4; v++) {
+                const uint32_t gv = v / C;
+                uint32_t per_sf = 0, below_c = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < 4; w++) if (w / C == gv) { per_sf += noise_nd[w]; if (w < v) below_c += noise_nd[w]; }
+                const uint32_t st = lcg_jump(1u, __builtin_amdgcn_readlane(p.dr, v) + sf0 * per_sf + below_c);
+                uint32_t am = 0x343FDu, ac = 0x269EC3u, rm = 1, rc = 0;      // the map of per_sf steps (lcg_jump's loop, the map kept)
+                for (uint32_t n = per_sf; n; n >>= 1) { if (n & 1) { rm *= am; rc = rc * am + ac; } ac = (am + 1) * ac; am *= am; }
+                if (lane == 0) { nmeta[v * 4] = noise_vc[v]; nmeta[v * 4 + 1] = noise_nd[v]; nmeta[v * 4 + 2] = st; }
+                if (u == v) { noise_am = rm; noise_ac = rc; }
+            }
         }
         wave_lds_sync();
+        if (NOISE) {                                       // this lane's bands: ranks, and the jump to its first noise band's draw
+            noise_rk = *(const uint2*)(nrank + u * 128 + l16 * 8);
+            uint32_t kfirst = 0xFF;
+#pragma unroll
+            for (int r = 7; r >= 0; r--) { const uint32_t kk = ((r < 4 ? noise_rk.x : noise_rk.y) >> (8 * (r & 3))) & 0xFF; kfirst = kk != 0xFF ? kk : kfirst; }
+            noise_mine = nmeta[u * 4 + 1] > 0 && kfirst != 0xFF;
+            const LcgMap jp = HCA_LCG_POW.v[(kfirst & 0x7F) + 1];
+            noise_ja = jp.x; noise_jc = jp.y;
+            noise_cur = nmeta[u * 4 + 2]; noise_vcu = nmeta[u * 4];
+        }
         if (JOINT) {
             if (F.bands_per_hfr_group > 0) {               // HFR scale of every reconstructed band (hca.cpp:1638-1683), as tr_setup_frame
                 const int start = (int)(F.stereo_bands + F.base_bands), groups = (int)F.hfr_group_count;
@@ -1824,6 +1895,32 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             *(float4*)(srow + l16 * 8) = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
             *(float4*)(srow + l16 * 8 + 4) = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
             wave_lds_sync();
+            if (NOISE) {                                   // reconstruct_noise, hca.cpp:1602-1635: rank k of (subframe, channel) takes draw k + 1
+                if (__any(noise_mine)) {
+                    float own[8] = {x[0].x, x[0].y, x[1].x, x[1].y, x[2].x, x[2].y, x[3].x, x[3].y};
+                    uint32_t rcur = noise_ja * noise_cur + noise_jc;
+                    bool started = false;
+                    const uint8_t* sfu = sfb + u * 128;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const uint32_t bnd = l16 * 8 + r, kk = ((r < 4 ? noise_rk.x : noise_rk.y) >> (8 * (r & 3))) & 0xFF;
+                        const bool isn = noise_mine && kk != 0xFF;
+                        const uint32_t rnext = rcur * 0x343FDu + 0x269EC3u;
+                        rcur = (isn && started) ? rnext : rcur;
+                        started = started || isn;
+                        const uint32_t vi = vlist[u * 128 + ((noise_vcu - 1 - (((rcur & 0x7FFF) * noise_vcu) >> 15)) & 127)];
+                        int sc = (int)sfu[bnd] - (int)sfu[vi & 127] + 62;
+                        sc = sc & ~(sc >> 31);
+                        const float nv = conv[sc & 127] * srow[vi & 127];
+                        own[r] = isn ? nv : own[r];
+                    }
+                    wave_lds_sync();                       // (coded bands are never rewritten: the reads above saw coded values)
+                    *(float4*)(srow + l16 * 8) = make_float4(own[0], own[1], own[2], own[3]);
+                    *(float4*)(srow + l16 * 8 + 4) = make_float4(own[4], own[5], own[6], own[7]);
+                    wave_lds_sync();
+                }
+                noise_cur = noise_am * noise_cur + noise_ac;           // the unit's next subframe
+            }
             const float rl = ratio[u * 8 + sf];
             const float rm = (F.type(c) == CRI_CH_SECONDARY) ? 2.0f - rl : rl;
             const float4 h0 = *(const float4*)(hconv + u * 128 + l16 * 8), h1 = *(const float4*)(hconv + u * 128 + l16 * 8 + 4);
@@ -2000,6 +2097,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 
 #define HCA_PLAIN_LDS HCA_PLAIN_LDS_BYTES
 #define HCA_PLAIN_JOINT_LDS (HCA_PLAIN_LDS + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
+#define HCA_PLAIN_NOISE_LDS (HCA_PLAIN_JOINT_LDS + 512 + 512 + 64)
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
     return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + ((C * 8 + 15) & ~15) + (C * 4 + 4) * 4 + 2 * C * 128 + 64;
@@ -2019,6 +2117,8 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
                                else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, false>), dim3(nruns), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
 #define CRI_LAUNCH_PJ(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true>), dim3(nruns), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); \
                                else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); } while (0)
+#define CRI_LAUNCH_PN(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_NOISE_LDS, s, a); \
+                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_NOISE_LDS, s, a); } while (0)
         if (a.plain) switch (a.channels) {
             case 1: CRI_LAUNCH_PL(1); break;
             case 2: CRI_LAUNCH_PL(2); break;
@@ -2029,6 +2129,8 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
                 if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
                 else hipLaunchKernelGGL((k_hca_transform_plain<4, false, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
             } break;
+        } else if (a.inlane && a.noise_fill) switch (a.channels) {
+            case 1: CRI_LAUNCH_PN(1); break; case 2: CRI_LAUNCH_PN(2); break; default: CRI_LAUNCH_PN(4); break;
         } else if (a.inlane) switch (a.channels) {
             case 1: CRI_LAUNCH_PJ(1); break; case 2: CRI_LAUNCH_PJ(2); break; default: CRI_LAUNCH_PJ(4); break;
         } else switch (a.channels) {
@@ -2038,6 +2140,7 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
 #undef CRI_LAUNCH_TR
 #undef CRI_LAUNCH_PL
 #undef CRI_LAUNCH_PJ
+#undef CRI_LAUNCH_PN
     } else {
         size_t lds = (size_t)a.channels * (2 * 128 + 2 * TR_DSTRIDE) * 4 + a.channels * 256 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);
