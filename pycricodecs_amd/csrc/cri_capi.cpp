@@ -421,7 +421,7 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
         a.inlane = (!a.plain && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) ? 1 : 0;      // (noise fill: its NOISE instance)
         if (a.inlane && getenv("CRI_NO_INLANE")) a.inlane = 0;             // (developer switch: the general transform instead)
-        if (a.channels == 4 && a.inlane && !a.noise_fill) a.narrow = 1;
+        if (a.inlane) a.narrow = 1;                                        // (every in-lane instance reads either form, noise fill included)
         if (a.channels == 4 && !a.inlane && !a.plain) a.narrow = 0;         // k_hca_transform<false, 4> reads int16 lines only
         j->hca_dec.push_back(a);
         j->hca_group_first_record.push_back(streams[b].scratch_offset);
