@@ -504,3 +504,39 @@ def test_wide_plain_layouts_trims_and_alignments(cc, ch):
     assert not st.any() and not job.host_status.any()
     for i, (o, h, key) in enumerate(zip(outs, items, keys)):
         assert bytes(o) == O.hca_decode(h, key), (ch, i)
+
+
+# ------------------------------------------------------------------------------------------------ the general transform kernel stays covered
+@pytest.mark.parametrize("ch,q,v3", [(1, 2, False), (2, 2, False), (2, 4, False), (4, 2, False), (4, 3, False), (2, 1, True), (2, 2, True), (1, 1, True), (4, 1, True)])
+def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, monkeypatch, ch, q, v3):
+    """Joint-stereo / HFR / noise-fill formats of 1, 2 and 4 channels run on k_hca_transform_plain's joint and noise instances;
+    k_hca_transform<false, C> -- what 6 / 8 channel joint formats and odd pairings still use -- is forced onto the same streams
+    here (CRI_NO_INLANE, read when the job is created): floats and PCM equal to the oracle's, bit for bit."""
+    import hca_forge
+    import torch
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRI_NO_INLANE", "1")
+    items = []
+    for seed, n in ((50, 5000), (51, 9000), (52, 1024)):
+        h = O.hca_encode(synth.wav(seed + ch, n, ch, 48000), q)
+        items.append(hca_forge.forge_v3(h, 0) if v3 else h)
+    job = Job.hca_decode(items)
+    bufs = job.alloc("cuda:0")
+    d_f, offs = job.run_floats(*bufs)
+    torch.cuda.synchronize()
+    outs = job.split(bytes(bufs[1].cpu().numpy()))
+    status = bufs[3].cpu().numpy()[:job.n]
+    fl = d_f.cpu().numpy()
+    good = 0
+    for i, h in enumerate(items):
+        try:
+            ref = O.hca_decode_float(h)
+        except O.OracleError:                                  # (a forged v3.0 header on frames of another layout: both sides reject it)
+            assert status[i] != 0, i
+            continue
+        assert status[i] == 0, i
+        good += 1
+        mine = fl[int(offs[i]):int(offs[i + 1])]
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), i
+        assert bytes(outs[i]) == O.hca_decode(h), i
+    assert good >= 2
