@@ -1102,14 +1102,21 @@ __device__ __forceinline__ bool enc_lane_locate(const AdxArgs& a, uint32_t g, En
     return X.valid;
 }
 // this lane's channel of row `row`: 32 samples.  A stereo pair loads the row's 128 bytes once (64 per lane) and trades halves.
-__device__ __forceinline__ void enc_lane_load(const EncLane& X, uint32_t row, int32_t (&x)[32]) {
+// A row's samples in two steps, so that the kernel can ask for the next row's before it encodes this one (a lane has one row in
+// flight and less than one wave shares its SIMD: without that, every row waited a full memory latency for its samples).
+// enc_lane_fetch: the raw words of a whole row of a mono / stereo file (false: a row cut by the end of the input, or another
+// layout -- enc_lane_load then reads it sample by sample); enc_lane_unpack: this lane's 32 samples out of them.
+__device__ __forceinline__ bool enc_lane_fetch(const EncLane& X, uint32_t row, uint32_t (&own)[16]) {
     const uint32_t C = X.S.channels;
     const bool whole = (uint64_t)(row + 1) * 32 <= X.S.samples;      // (samples past the input are zero padding, adx.cpp:453-456)
-    if (whole && C == 2) {
-        const uint4* p = (const uint4*)(X.pcm + ((uint64_t)row * 32 + 16 * X.ch) * 4);
-        uint32_t own[16];
+    if (!whole || C > 2) return false;
+    const uint8_t* p = C == 2 ? X.pcm + ((uint64_t)row * 32 + 16 * X.ch) * 4 : X.pcm + (uint64_t)row * 64;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { uint4 v; __builtin_memcpy(&v, p + j, 16); own[4 * j] = v.x; own[4 * j + 1] = v.y; own[4 * j + 2] = v.z; own[4 * j + 3] = v.w; }
+    for (int j = 0; j < 4; j++) { uint4 v; __builtin_memcpy(&v, p + 16 * j, 16); own[4 * j] = v.x; own[4 * j + 1] = v.y; own[4 * j + 2] = v.z; own[4 * j + 3] = v.w; }
+    return true;
+}
+__device__ __forceinline__ void enc_lane_unpack(const EncLane& X, const uint32_t (&own)[16], int32_t (&x)[32]) {
+    if (X.S.channels == 2) {
         // lane ch 0 holds samples 0..15 of both channels, lane ch 1 samples 16..31: one permute per dword makes {x[i], x[16 + i]} of MY channel
         const uint32_t sel = X.ch ? 0x03020706u : 0x05040100u;       // ch 0: own.lo | partner.lo << 16;  ch 1: partner.hi | own.hi << 16
 #pragma unroll
@@ -1120,17 +1127,13 @@ __device__ __forceinline__ void enc_lane_load(const EncLane& X, uint32_t row, in
         }
         return;
     }
-    if (whole && C == 1) {
-        const uint8_t* p = X.pcm + (uint64_t)row * 64;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint4 v; __builtin_memcpy(&v, p + 16 * j, 16);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) { x[8 * j + 2 * q] = (int32_t)(int16_t)(w[q] & 0xFFFF); x[8 * j + 2 * q + 1] = (int32_t)w[q] >> 16; }
-        }
-        return;
-    }
+    for (int i = 0; i < 16; i++) { x[2 * i] = (int32_t)(int16_t)(own[i] & 0xFFFF); x[2 * i + 1] = (int32_t)own[i] >> 16; }
+}
+__device__ __forceinline__ void enc_lane_load(const EncLane& X, uint32_t row, int32_t (&x)[32]) {
+    const uint32_t C = X.S.channels;
+    uint32_t own[16];
+    if (enc_lane_fetch(X, row, own)) { enc_lane_unpack(X, own, x); return; }
 #pragma unroll
     for (int i = 0; i < 32; i++) {
         const uint64_t idx = (uint64_t)row * 32 + i;
@@ -1216,7 +1219,13 @@ __device__ __forceinline__ void enc_lane_store(const EncLane& X, uint32_t row, u
     for (int w = 0; w < 4; w++) { const uint16_t lo = (uint16_t)cw[w], hi = (uint16_t)(cw[w] >> 16); __builtin_memcpy(q + 2 + 4 * w, &lo, 2); __builtin_memcpy(q + 4 + 4 * w, &hi, 2); }
 }
 
-// pass 0: every segment from a guessed history; pass 1: again from the recorded end of the previous one, until merged
+// pass 0: every segment from a guessed history (the raw samples before it).  pass r >= 1, a repair round: a segment whose bytes
+// were not encoded from the end state its predecessor has NOW is encoded again from that state until its histories meet the
+// recorded checkpoints (from there on the bytes are right already) or it ends; a segment that ends differently than before makes
+// its successor stale, which the next round repairs -- the end states live in two slots written alternately (rec[1 + (r & 1)]),
+// so a round reads what the round before left while it writes its own.  A file in which an end state still moved in the last
+// round is flagged (seg_flags = rounds) and walked in order by k_adx_lane_encode_serial.
+//   rec[0] = the state the segment's bytes were encoded from, rec[1] / rec[2] = its end state after the even / odd rounds
 __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass) {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     EncLane X;
@@ -1228,23 +1237,42 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass
     uint32_t* ck = a.seg_ckpt + ((uint64_t)S.rows_avail * 2 + X.ch);
     int32_t h1 = 0, h2 = 0;
     bool run = X.valid && X.r1 > X.r0;
-    uint32_t want_end = 0;
+    uint32_t want_end = 0, new_start = 0, warm_from = 0;
+    const uint32_t slot_r = 1 + ((pass - 1) & 1), slot_w = 1 + (pass & 1);      // (rounds: the slot read, the slot written)
     if (pass == 0) {
         if (X.valid) {
-            if (X.k == 0) { h1 = a.history[2 * chain]; h2 = a.history[2 * chain + 1]; }
+            // the warm-up: `warm_rows` rows before the segment are encoded from the raw samples before THEM as history, nothing
+            // stored -- the encoder's reconstruction has usually found the true trajectory by the segment's first row (a warm-up
+            // that reaches the file's start begins with the header's history and is exact)
+            const uint32_t w0 = X.k == 0 ? 0 : (X.r0 > S.warm_rows ? X.r0 - S.warm_rows : 0);
+            if (w0 == 0) { h1 = a.history[2 * chain]; h2 = a.history[2 * chain + 1]; }
             else {
                 auto raw = [&](uint64_t idx) { int16_t v = 0; if (idx < S.samples) __builtin_memcpy(&v, X.pcm + (idx * C + X.ch) * 2, 2); return (int32_t)v; };
-                h1 = raw((uint64_t)X.r0 * 32 - 1); h2 = raw((uint64_t)X.r0 * 32 - 2);
+                h1 = raw((uint64_t)w0 * 32 - 1); h2 = raw((uint64_t)w0 * 32 - 2);
             }
-            rec[0] = seg_pack(h1, h2);
+            warm_from = w0;
         }
+        // (the pair's lanes warm up over the same rows: enc_lane_load's exchange needs both)
+        uint32_t wn = X.valid && X.r1 > X.r0 ? X.r0 - warm_from : 0, wmax = wn;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)wmax, o); wmax = t > wmax ? t : wmax; }
+        for (uint32_t t = 0; t < wmax; t++) {
+            if (t < wn) {
+                int32_t x[32];
+                enc_lane_load(X, warm_from + t, x);
+                uint32_t word, cw[4];
+                enc_lane_block(S, x, h1, h2, word, cw);
+            }
+        }
+        if (X.valid) rec[0] = seg_pack(h1, h2);
     } else {
         bool mis = false;
+        if (X.valid) want_end = rec[slot_r];
         if (X.valid && X.k > 0) {
-            const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - C) + 1];
+            const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - C) + slot_r];
             mis = prev_end != rec[0];
             seg_unpack(prev_end, h1, h2);
-            want_end = rec[1];
+            new_start = prev_end;
         }
         // (the exchange runs in every lane, outside any condition on `mis`: a lane that is masked off reads as 0)
         const bool partner_mis = __builtin_amdgcn_update_dpp(0, (int)mis, 0xB1, 0xF, 0xF, true) != 0;
@@ -1255,13 +1283,18 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
     bool merged = false;
+    uint32_t cur[16] = {};                                           // the current row's raw words, fetched one row ahead
+    bool cur_ok = nrows > 0 && enc_lane_fetch(X, X.r0, cur);
     for (uint32_t t = 0; t < nmax; t++) {
         const bool act = run && t < nrows && !merged;
         if (__builtin_expect(!__any(act), 0)) break;
         if (act) {
             const uint32_t row = X.r0 + t;
             int32_t x[32];
-            enc_lane_load(X, row, x);
+            if (cur_ok) enc_lane_unpack(X, cur, x); else enc_lane_load(X, row, x);
+            // (the next row's words are asked for AFTER this row's have been taken out of their registers: the compiler waits for every
+            //  outstanding load at that point, and these must not be among them)
+            cur_ok = t + 1 < nrows && enc_lane_fetch(X, row + 1, cur);
             uint32_t word, cw[4];
             enc_lane_block(S, x, h1, h2, word, cw);
             enc_lane_store(X, row, word, cw, pair);
@@ -1281,11 +1314,16 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass
     if (!X.valid) return;
     const uint32_t e = seg_pack(h1, h2);
     if (pass == 0) { rec[1] = e; rec[2] = e; rec[3] = 0; }
-    else if (run && !merged && e != want_end) { rec[2] = e; a.seg_flags[X.stream] = 1u; }   // the next segment started from a stale state
+    else {
+        const uint32_t now_end = run && !merged ? e : want_end;
+        rec[slot_w] = now_end;
+        if (run) rec[0] = new_start;
+        if (now_end != want_end) a.seg_flags[X.stream] = pass;       // the next segment started from a stale state: the next round's work
+    }
 }
 
 // pass 2: flagged files, a lane (pair) per file, the segments in order
-__global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a) {
+__global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a, uint32_t rounds) {
     const uint32_t chain = blockIdx.x * 64 + threadIdx.x;
     EncLane X;
     X.valid = chain < a.chains;
@@ -1299,11 +1337,12 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a) {
     X.pcm = (S.src_in_scratch ? a.scratch : a.in) + S.src_offset; X.dst = a.out + S.dst_offset;
     const uint32_t C = S.channels;
     const bool pair = C == 2;
-    const bool go = X.valid && a.seg_flags[lo] != 0;
+    const bool go = X.valid && a.seg_flags[lo] == rounds;            // an end state moved in the last round
+    const uint32_t slot = 1 + (rounds & 1);                          // (the slot the last round wrote)
     if (!__any(go)) return;
     int32_t h1 = 0, h2 = 0;
     if (go) { h1 = a.history[2 * cc]; h2 = a.history[2 * cc + 1]; }
-    uint32_t cur = seg_pack(h1, h2), used = cur;
+    uint32_t cur = seg_pack(h1, h2);
     uint32_t* ck = a.seg_ckpt + ((uint64_t)S.rows_avail * 2 + X.ch);
     uint32_t kmax = go ? S.seg_count : 0;
 #pragma unroll
@@ -1311,11 +1350,11 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a) {
     for (uint32_t k = 0; k < kmax; k++) {
         const bool on = go && k < S.seg_count;
         uint32_t* rec = a.seg_state + 4 * ((uint64_t)S.first_seg + (uint64_t)(on ? k : 0) * C + X.ch);
-        uint32_t end = on ? rec[2] : 0;
-        bool mis = on && used != cur;
+        uint32_t end = on ? rec[slot] : 0;
+        bool mis = on && rec[0] != cur;                              // the segment's bytes were encoded from rec[0]
         const bool partner_mis = __builtin_amdgcn_update_dpp(0, (int)mis, 0xB1, 0xF, 0xF, true) != 0;
         const bool pmis = mis || (pair && partner_mis);
-        const bool run = on && pmis;                                 // the segment's blocks were encoded from `used`
+        const bool run = on && pmis;
         X.k = k; X.r0 = k * S.seg_rows; X.r1 = X.r0 + S.seg_rows < S.frames ? X.r0 + S.seg_rows : S.frames;
         uint32_t nrows = run ? X.r1 - X.r0 : 0, nmax = nrows;
 #pragma unroll
@@ -1343,15 +1382,15 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a) {
             }
         }
         if (run && !merged) end = seg_pack(h1, h2);
-        if (on) { used = rec[1]; cur = end; }
+        if (on) cur = end;
     }
 }
 
 void launch_adx_encode_lane(const AdxArgs& a, hipStream_t s) {
     if (!a.seg_lanes) return;
-    hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 0u);
-    hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, 1u);
-    hipLaunchKernelGGL(k_adx_lane_encode_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a);
+    constexpr uint32_t ROUNDS = 4;
+    for (uint32_t pass = 0; pass <= ROUNDS; pass++) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, pass);
+    hipLaunchKernelGGL(k_adx_lane_encode_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a, ROUNDS);
 }
 
 void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s) {

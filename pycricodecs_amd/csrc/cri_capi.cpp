@@ -1102,6 +1102,27 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
         const char* we = getenv("CRICODECS_ADX_WARM");
         const uint64_t pct = we ? strtoull(we, nullptr, 10) : 100;
         const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains_total);
+        const char* se = getenv("CRICODECS_ADX_SEGLEN");
+        const uint64_t seg_pct = se ? std::max<uint64_t>(1, strtoull(se, nullptr, 10)) : 50;      // a segment's least length, in percent of the warm-up
+        // Two regimes.  Lanes enough at long segments (1024 rows: longer than the encoder's merge time; 1.5 waves per SIMD and more): no
+        // warm-up, every segment is encoded from the raw samples before it and repaired where that was wrong -- the least work.  Fewer
+        // lanes (1000 files of 10 s): the kernel is bound by the latency of one row after the other in a lane, ~3 us, and a lane's rows are
+        // what counts -- a warm-up of 640 rows (the merge time) before segments of 320 gives three times the lanes, each with 960 rows
+        // instead of 1024 + up to 600 of repair, at 2.4 times the instructions (4.45 -> 3.4 ms; 4000 files of 10 s would go 8.7 -> 9.2).
+        bool short_segments = true;
+        {
+            uint64_t lanes_long = 0;
+            for (const AdxStream& S : streams) {
+                const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
+                if (g <= 0 || !S.frames) { lanes_long += S.channels; continue; }
+                const uint64_t rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, std::max<uint64_t>(4, 1024ull * 39 * pct / 100 / (uint64_t)g));
+                lanes_long += (uint64_t)S.channels * ((S.frames + rows - 1) / rows);
+            }
+            if (lanes_long >= 98304) short_segments = false;
+        }
+        auto lane_warm = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (640ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4) : (uint64_t)0; };
+        auto lane_lmin = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (lane_warm(g) * seg_pct / 100 + 3) / 4 * 4)
+                                                                 : std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4); };
         uint32_t lanes = 0, chains = 0; uint64_t rounds = 0;
         std::vector<int16_t> hist2;
         bool usable = true;
@@ -1112,9 +1133,9 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
             auto seg_len = [&](const AdxStream& S) {
                 const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
                 if (g <= 0 || !S.frames) return (uint64_t)S.frames;
-                const uint64_t lmin = std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4);
+                const uint64_t warm = lane_warm(g), lmin = lane_lmin(g);
                 const uint64_t rows = (std::max<uint64_t>((S.frames + p_target - 1) / p_target, lmin) + 3) / 4 * 4;
-                return std::min<uint64_t>(rows, S.frames);
+                return std::min<uint64_t>(rows, S.frames) + (rows < S.frames ? warm : 0);      // (a lane's rows: warm-up + segment)
             };
             bool wide = false;
             for (const AdxStream& S : streams) wide = wide || S.channels > 2;
@@ -1122,16 +1143,18 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
         }
         for (AdxStream& S : streams) {
             const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
-            // a segment has to be longer than the encoder's merge time (600 rows at worst for tonal material, 2200 for sparse, at g = 39)
-            uint64_t rows = S.frames;
+            // the warm-up covers the encoder's merge time (600 rows at worst for tonal material at g = 39; sparse material takes up to 2200:
+            // its segments are repaired by the rounds); a segment is half a warm-up long unless the job has lanes enough with longer ones
+            uint64_t rows = S.frames, warm = 0;
             if (g > 0 && S.frames) {
-                const uint64_t lmin = std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4);
+                warm = lane_warm(g);
+                const uint64_t lmin = lane_lmin(g);
                 rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, lmin);
                 rows = (rows + 3) / 4 * 4;
                 if (rows > S.frames) rows = S.frames;
             }
             if (S.channels > 2) usable = false;
-            S.seg_rows = (uint32_t)rows; S.seg_count = S.frames ? (uint32_t)((S.frames + rows - 1) / rows) : 0; S.warm_rows = 0;
+            S.seg_rows = (uint32_t)rows; S.seg_count = S.frames ? (uint32_t)((S.frames + rows - 1) / rows) : 0; S.warm_rows = (uint32_t)warm;
             if (S.channels == 2 && (lanes & 1)) lanes++;
             if (S.channels == 2 && (chains & 1)) { chains++; hist2.push_back(0); hist2.push_back(0); }
             S.first_seg = lanes; S.rows_avail = (uint32_t)rounds;
