@@ -1184,7 +1184,10 @@ __device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t
             const float sadj = __uint_as_float((__float_as_uint(adj) & 0x7FFFFFFFu) | (__float_as_uint(df) & 0x80000000u));
             int32_t code = (int32_t)__builtin_fmaf(df, rcp, sadj);
             code = code > 7 ? 7 : (code < -8 ? -8 : code);
-            int32_t sim = __mul24(code, iscale) + (pred >> 12);       // = ((code * scale << 12) + pred) >> 12: the product has no low bits
+            // = ((code * scale << 12) + pred) >> 12: the product has no low bits.  (As v_mad_i32_i24 by hand: knowing code's range the compiler
+            //  drops the 24-bit form and takes v_mad_u64_u32, a quarter-rate instruction, onto the chain from one sample to the next.)
+            int32_t sim;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(sim) : "v"(code), "v"(iscale), "v"(pred >> 12));
             sim = clamp_sym(sim, 0x7FFF);
             c1g2 = __mul24(c1, g1);
             g2 = g1; g1 = sim;
