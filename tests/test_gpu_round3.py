@@ -540,3 +540,34 @@ def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, monkeyp
         assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), i
         assert bytes(outs[i]) == O.hca_decode(h), i
     assert good >= 2
+
+
+def test_run_host_from_two_threads_at_once(cc, monkeypatch):
+    """Two threads in the pipelined host path at the same time (one works on the device's arena, the other on buffers, streams
+    and staging slots of its own for the call), both from the same items and into their own buffers, several times over."""
+    import threading
+    from pycricodecs_amd.batch import Job
+    monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", "0")
+    monkeypatch.setenv("CRICODECS_HOST_STAGE_PIECE", "4096")
+    uniq, items = _ragged_hca_batch()
+    items = [it for k, it in enumerate(items) if k != 17]
+    refs = {id(u): O.hca_decode(u, KEY) for u in uniq}
+    errors = []
+
+    def work(seed):
+        try:
+            order = list(np.random.default_rng(seed).permutation(len(items)))
+            mine = [items[i] for i in order]
+            job = Job.hca_decode(mine, keys=[KEY] * len(mine))
+            for rep in range(4):
+                outs, st = job.run_host()
+                for i, it in enumerate(mine):
+                    if id(it) in refs and bytes(outs[i]) != refs[id(it)]:
+                        errors.append((seed, rep, i)); return
+        except Exception as e:                                  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in (1, 2, 3)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors[:3]
