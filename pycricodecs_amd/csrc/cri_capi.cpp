@@ -419,7 +419,8 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         a.narrow = (!a.noise_fill && (a.channels <= 2 || a.plain)) ? 1 : 0;         // (plain formats of any channel count: k_hca_transform_plain in channel groups)
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
-        a.inlane = (!a.plain && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) ? 1 : 0;      // (noise fill: its NOISE instance)
+        a.inlane = (!a.plain && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4 ||
+                                                    ((a.channels == 6 || a.channels == 8) && !a.noise_fill))) ? 1 : 0;      // (noise fill: the NOISE instance; 6 / 8: the wide joint form)
         if (a.inlane && getenv("CRI_NO_INLANE")) a.inlane = 0;             // (developer switch: the general transform instead)
         if (a.inlane) a.narrow = 1;                                        // (every in-lane instance reads either form, noise fill included)
         if (a.channels == 4 && !a.inlane && !a.plain) a.narrow = 0;         // k_hca_transform<false, 4> reads int16 lines only

@@ -1573,6 +1573,7 @@ constexpr LcgPow make_lcg_pow() {
 }
 __device__ const LcgPow HCA_LCG_POW = make_lcg_pow();
 #define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
+#define HCA_PLAIN_JOINT_LDS_BYTES (HCA_PLAIN_LDS_BYTES + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
 struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
 #ifndef CRI_PLAIN_WAVES
@@ -1598,14 +1599,15 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[
 // lane reaches its first noise band of a subframe through a table of the generator's powers (HCA_LCG_POW).
 template <int C, bool FLT, bool JOINT, bool WIDE = false, bool NOISE = false>
 __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
-    static_assert(!WIDE || (C == 4 && !JOINT), "the wide form is four channels per wave of a plain format");
+    static_assert(!WIDE || (C == 4 && !NOISE), "the wide form is four channels per wave");
     static_assert(!NOISE || JOINT, "noise fill stages the spectrum like the joint form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
     const uint32_t CT = WIDE ? a.channels : (uint32_t)C;   // channels of the records, the line tiles and the PCM interleave
     const uint32_t wv = WIDE ? threadIdx.x >> 6 : 0u, CB = 4 * wv;
-    uint8_t* smem = smem_all + wv * HCA_PLAIN_LDS_BYTES;
-    uint16_t* pcmw = (uint16_t*)(smem_all + (WIDE ? (blockDim.x >> 6) * HCA_PLAIN_LDS_BYTES : 0u));      // WIDE: the shared [128][CT] piece, then 128 B of dump
+    constexpr uint32_t WAVE_LDS = JOINT ? HCA_PLAIN_JOINT_LDS_BYTES : HCA_PLAIN_LDS_BYTES;
+    uint8_t* smem = smem_all + wv * WAVE_LDS;
+    uint16_t* pcmw = (uint16_t*)(smem_all + (WIDE ? (blockDim.x >> 6) * WAVE_LDS : 0u));      // WIDE: the shared [128][CT] piece, then 128 B of dump
     constexpr bool NW = true;                              // int8 lines (HCA_REC_NARROW) are read by all three instances
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x & 63, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
@@ -1691,7 +1693,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
     uint32_t src_off[8];                                   // byte offsets into S
     uint32_t ratio_mask = 0;                               // bit r: line r takes the pair's ratio
     if (JOINT) {
-        const uint32_t tc = F.type(c);
+        const uint32_t tc = F.type(cc);                    // (WIDE: a pair never straddles two waves -- pairs start on even channels, a wave on a multiple of four)
         const bool secondary = tc == CRI_CH_SECONDARY && c > 0, stereo = F.stereo_bands > 0, hfr = F.bands_per_hfr_group > 0;
         const int start = (int)(F.stereo_bands + F.base_bands);
 #pragma unroll
@@ -1699,7 +1701,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             const uint32_t bnd = l16 * 8 + r;
             const bool shared = stereo && bnd >= F.base_bands && bnd < F.total_bands;
             const bool from_prev = secondary && shared;
-            const uint32_t us = from_prev ? u - 1 : u, cs = from_prev ? c - 1 : c;
+            const uint32_t us = from_prev ? u - 1 : u, cs = from_prev ? cc - 1 : cc;
             const bool cs_hfr = hfr && F.type(cs) != CRI_CH_SECONDARY;
             uint32_t idx = ZERO_IDX;
             if (cs_hfr && (int)bnd == start + nproc - 1) idx = ZERO_IDX;                   // hca.cpp:1681 (with nothing reconstructed this is a coded band)
@@ -1735,9 +1737,9 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         }
         p.ib = 0;
         if (JOINT) {                                       // lane < 32: intensity byte (lane & 7) of unit lane >> 3's pair (its secondary's entry)
-            const uint32_t v = (lane >> 3) & 3, cv = v % C, cs = (F.type(cv) == CRI_CH_SECONDARY || cv + 1 >= (uint32_t)C) ? cv : cv + 1;
+            const uint32_t v = (lane >> 3) & 3, cv = chan_of(v), cs = (F.type(cv) == CRI_CH_SECONDARY || v % C + 1 >= (uint32_t)C || cv + 1 >= CT) ? cv : cv + 1;
             bool live; const uint32_t f = unit_frame(v, s, live);
-            p.ib = rec0[(uint64_t)f * F.record_bytes + HCA_REC_INT(C, cs) + (lane & 7)];
+            p.ib = rec0[(uint64_t)f * F.record_bytes + HCA_REC_INT(CT, cs) + (lane & 7)];
         }
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
@@ -1835,8 +1837,8 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
                 const int start = (int)(F.stereo_bands + F.base_bands), groups = (int)F.hfr_group_count;
 #pragma unroll
                 for (uint32_t v = 0; v < 4; v++) {
-                    if (F.type(v % C) == CRI_CH_SECONDARY) continue;
-                    const bool pair = v % C + 1 < (uint32_t)C && F.type(v % C + 1) == CRI_CH_SECONDARY;      // the next unit takes these bands from this one
+                    if (F.type(chan_of(v)) == CRI_CH_SECONDARY) continue;
+                    const bool pair = v % C + 1 < (uint32_t)C && chan_of(v) + 1 < CT && F.type(chan_of(v) + 1) == CRI_CH_SECONDARY;      // the next unit takes these bands from this one
                     const uint8_t* sb = sfb + v * 128;
 #pragma unroll
                     for (int hh = 0; hh < 2; hh++) {
@@ -1852,10 +1854,10 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
                 }
             }
             if (lane < 32) {                               // intensity ratio per (unit, subframe): hca.cpp:1361-1441, 1696-1714
-                const uint32_t v = lane >> 3, cv = v % C, tv = F.type(cv);
-                const uint32_t cs = (tv == CRI_CH_SECONDARY || cv + 1 >= (uint32_t)C) ? cv : cv + 1;
+                const uint32_t v = lane >> 3, cv = chan_of(v), tv = F.type(cv);
+                const uint32_t cs = (tv == CRI_CH_SECONDARY || v % C + 1 >= (uint32_t)C || cv + 1 >= CT) ? cv : cv + 1;
                 bool live; const uint32_t f = unit_frame(v, cur_step, live);
-                const uint8_t iv = intensity_walk_back(F, rec0, f, C, cs, lane & 7, (uint8_t)p.ib);
+                const uint8_t iv = intensity_walk_back(F, rec0, f, CT, cs, lane & 7, (uint8_t)p.ib);
                 ratio[lane] = (F.stereo_bands > 0 && (tv == CRI_CH_SECONDARY || tv == CRI_CH_PRIMARY)) ? iratio[iv & 15] : 1.0f;
             }
             wave_lds_sync();
@@ -1922,7 +1924,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
                 noise_cur = noise_am * noise_cur + noise_ac;           // the unit's next subframe
             }
             const float rl = ratio[u * 8 + sf];
-            const float rm = (F.type(c) == CRI_CH_SECONDARY) ? 2.0f - rl : rl;
+            const float rm = (F.type(cc) == CRI_CH_SECONDARY) ? 2.0f - rl : rl;
             const float4 h0 = *(const float4*)(hconv + u * 128 + l16 * 8), h1 = *(const float4*)(hconv + u * 128 + l16 * 8 + 4);
             const f2 hm[4] = {f2{h0.x, h0.y}, f2{h0.z, h0.w}, f2{h1.x, h1.y}, f2{h1.z, h1.w}};
 #pragma unroll
@@ -2096,7 +2098,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 }
 
 #define HCA_PLAIN_LDS HCA_PLAIN_LDS_BYTES
-#define HCA_PLAIN_JOINT_LDS (HCA_PLAIN_LDS + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
+#define HCA_PLAIN_JOINT_LDS HCA_PLAIN_JOINT_LDS_BYTES
 #define HCA_PLAIN_NOISE_LDS (HCA_PLAIN_JOINT_LDS + 512 + 512 + 64)
 size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     const size_t base = (size_t)C * 128 * 4 + (C > 4 ? 16 : 8) * TR_DSTRIDE * 4 + (C > 4 ? C * 512 : 1024) + 512 + 256 + 64 + 80;
@@ -2129,6 +2131,11 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
                 if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
                 else hipLaunchKernelGGL((k_hca_transform_plain<4, false, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
             } break;
+        } else if (a.inlane && a.channels > 4) {           // 6 / 8 channels with joint stereo / HFR: the wide form, a wave per four channels
+            const uint32_t nw = (a.channels + 3) / 4;
+            const size_t wlds = nw * HCA_PLAIN_JOINT_LDS + 2048 + 128;
+            if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, true, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
+            else hipLaunchKernelGGL((k_hca_transform_plain<4, false, true, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
         } else if (a.inlane && a.noise_fill) switch (a.channels) {
             case 1: CRI_LAUNCH_PN(1); break; case 2: CRI_LAUNCH_PN(2); break; default: CRI_LAUNCH_PN(4); break;
         } else if (a.inlane) switch (a.channels) {
