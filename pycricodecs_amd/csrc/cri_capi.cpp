@@ -419,8 +419,15 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         a.narrow = (!a.noise_fill && (a.channels <= 2 || a.plain)) ? 1 : 0;         // (plain formats of any channel count: k_hca_transform_plain in channel groups)
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
-        a.inlane = (!a.plain && a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4 ||
-                                                    ((a.channels == 6 || a.channels == 8) && !a.noise_fill))) ? 1 : 0;      // (noise fill: the NOISE instance; 6 / 8: the wide joint form)
+        // in-lane instances: 1 / 2 / 4 channels with pairs on even channels (joint, or noise fill); every other joint layout without
+        // noise fill goes to the wide joint form -- groups of up to four consecutive channels, cut so that no pair is split
+        a.inlane = (!a.plain && ((a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) || (a.channels >= 3 && !a.noise_fill))) ? 1 : 0;
+        a.wide_waves = 0;
+        for (uint32_t cb = 0; cb < F.channels; a.wide_waves++) {
+            uint32_t n = F.channels - cb < 4 ? F.channels - cb : 4;
+            if (n == 4 && cb + 4 < F.channels && F.type[cb + 3] == CRI_CH_PRIMARY && F.type[cb + 4] == CRI_CH_SECONDARY) n = 3;
+            cb += n;
+        }
         if (a.inlane && getenv("CRI_NO_INLANE")) a.inlane = 0;             // (developer switch: the general transform instead)
         if (a.inlane) a.narrow = 1;                                        // (every in-lane instance reads either form, noise fill included)
         if (a.channels == 4 && !a.inlane && !a.plain) a.narrow = 0;         // k_hca_transform<false, 4> reads int16 lines only
@@ -1690,7 +1697,7 @@ bool hca_decode_sliceable(const cri_job* j) {
     if (j->kind != CRI_JOB_HCA_DECODE || j->hca_dec.size() != 1 || j->convert_total) return false;
     const HcaDecArgs& a = j->hca_dec[0];
     if (a.noise_fill || !a.frames || !a.runs) return false;
-    const bool in_regs = a.plain || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    const bool in_regs = a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
     if (!in_regs) return false;
     const auto& S = j->hca_streams_host;
     if (S.size() != (size_t)(a.stream_end - a.stream_begin)) return false;

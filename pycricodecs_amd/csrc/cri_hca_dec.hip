@@ -1598,22 +1598,32 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[
 // (on the scalar unit: it is the same for the whole unit), the step from one subframe to the next is one affine map per frame, and a
 // lane reaches its first noise band of a subframe through a table of the generator's powers (HCA_LCG_POW).
 template <int C, bool FLT, bool JOINT, bool WIDE = false, bool NOISE = false>
-__global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
+__global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
     static_assert(!WIDE || (C == 4 && !NOISE), "the wide form is four channels per wave");
     static_assert(!NOISE || JOINT, "noise fill stages the spectrum like the joint form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
     const uint32_t CT = WIDE ? a.channels : (uint32_t)C;   // channels of the records, the line tiles and the PCM interleave
-    const uint32_t wv = WIDE ? threadIdx.x >> 6 : 0u, CB = 4 * wv;
+    const uint32_t wv = WIDE ? threadIdx.x >> 6 : 0u;
     constexpr uint32_t WAVE_LDS = JOINT ? HCA_PLAIN_JOINT_LDS_BYTES : HCA_PLAIN_LDS_BYTES;
     uint8_t* smem = smem_all + wv * WAVE_LDS;
     uint16_t* pcmw = (uint16_t*)(smem_all + (WIDE ? (blockDim.x >> 6) * WAVE_LDS : 0u));      // WIDE: the shared [128][CT] piece, then 128 B of dump
     constexpr bool NW = true;                              // int8 lines (HCA_REC_NARROW) are read by all three instances
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x & 63, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
-    auto chan_of = [&](uint32_t v) { return WIDE ? (CB + v < CT ? CB + v : CT - 1) : v % C; };      // channel of unit v
+    // WIDE: this wave's channels CB .. CB + CN - 1 -- groups of up to four, cut so that no stereo pair is split (5 channels: 3 + 2)
+    uint32_t CB = 0, CN = C;
+    if (WIDE) {
+        for (uint32_t w = 0;; w++) {
+            CN = CT - CB < 4 ? CT - CB : 4;
+            if (CN == 4 && CB + 4 < CT && F.type(CB + 3) == CRI_CH_PRIMARY && F.type(CB + 4) == CRI_CH_SECONDARY) CN = 3;
+            if (w == wv) break;
+            CB += CN;
+        }
+    }
+    auto chan_of = [&](uint32_t v) { return WIDE ? (v < CN ? CB + v : CB + CN - 1) : v % C; };      // channel of unit v
     const uint32_t cc = chan_of(u);
-    const bool ch_live = !WIDE || CB + c < CT;
+    const bool ch_live = !WIDE || c < CN;
     float* G = (float*)smem;                               // [4][128] gains of each unit's frame
     uint16_t* pcm = (uint16_t*)(G + 512);                  // [NG][128][C] one pass of PCM16
     float* scale = (float*)(pcm + 512); float* range = scale + 64; uint8_t* curve = (uint8_t*)(range + 16);   // 80 bytes
@@ -1737,7 +1747,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         }
         p.ib = 0;
         if (JOINT) {                                       // lane < 32: intensity byte (lane & 7) of unit lane >> 3's pair (its secondary's entry)
-            const uint32_t v = (lane >> 3) & 3, cv = chan_of(v), cs = (F.type(cv) == CRI_CH_SECONDARY || v % C + 1 >= (uint32_t)C || cv + 1 >= CT) ? cv : cv + 1;
+            const uint32_t v = (lane >> 3) & 3, cv = chan_of(v), cs = (F.type(cv) == CRI_CH_SECONDARY || v % C + 1 >= CN) ? cv : cv + 1;
             bool live; const uint32_t f = unit_frame(v, s, live);
             p.ib = rec0[(uint64_t)f * F.record_bytes + HCA_REC_INT(CT, cs) + (lane & 7)];
         }
@@ -1838,7 +1848,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 #pragma unroll
                 for (uint32_t v = 0; v < 4; v++) {
                     if (F.type(chan_of(v)) == CRI_CH_SECONDARY) continue;
-                    const bool pair = v % C + 1 < (uint32_t)C && chan_of(v) + 1 < CT && F.type(chan_of(v) + 1) == CRI_CH_SECONDARY;      // the next unit takes these bands from this one
+                    const bool pair = v % C + 1 < CN && F.type(chan_of(v) + 1) == CRI_CH_SECONDARY;      // the next unit takes these bands from this one
                     const uint8_t* sb = sfb + v * 128;
 #pragma unroll
                     for (int hh = 0; hh < 2; hh++) {
@@ -1855,7 +1865,7 @@ __global__ __launch_bounds__(WIDE ? 128 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             }
             if (lane < 32) {                               // intensity ratio per (unit, subframe): hca.cpp:1361-1441, 1696-1714
                 const uint32_t v = lane >> 3, cv = chan_of(v), tv = F.type(cv);
-                const uint32_t cs = (tv == CRI_CH_SECONDARY || v % C + 1 >= (uint32_t)C || cv + 1 >= CT) ? cv : cv + 1;
+                const uint32_t cs = (tv == CRI_CH_SECONDARY || v % C + 1 >= CN) ? cv : cv + 1;
                 bool live; const uint32_t f = unit_frame(v, cur_step, live);
                 const uint8_t iv = intensity_walk_back(F, rec0, f, CT, cs, lane & 7, (uint8_t)p.ib);
                 ratio[lane] = (F.stereo_bands > 0 && (tv == CRI_CH_SECONDARY || tv == CRI_CH_PRIMARY)) ? iratio[iv & 15] : 1.0f;
@@ -2108,7 +2118,7 @@ size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
-    const bool in_regs = a.plain || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    const bool in_regs = a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
     if (in_regs) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
         const bool flt = a.float_out != nullptr;
@@ -2126,13 +2136,13 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
             case 2: CRI_LAUNCH_PL(2); break;
             case 4: CRI_LAUNCH_PL(4); break;
             default: {                                     // 3, 5, 6, 7, 8 channels: a wave per four channels, whole sample frames out
-                const uint32_t nw = (a.channels + 3) / 4;
+                const uint32_t nw = a.wide_waves;
                 const size_t wlds = nw * HCA_PLAIN_LDS + 2048 + 128;
                 if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
                 else hipLaunchKernelGGL((k_hca_transform_plain<4, false, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
             } break;
-        } else if (a.inlane && a.channels > 4) {           // 6 / 8 channels with joint stereo / HFR: the wide form, a wave per four channels
-            const uint32_t nw = (a.channels + 3) / 4;
+        } else if (a.inlane && !a.noise_fill && (a.channels == 3 || a.channels > 4 || !a.pairs_even)) {      // the wide joint form: a wave per group of channels
+            const uint32_t nw = a.wide_waves;
             const size_t wlds = nw * HCA_PLAIN_JOINT_LDS + 2048 + 128;
             if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, true, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
             else hipLaunchKernelGGL((k_hca_transform_plain<4, false, true, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);

@@ -30,7 +30,8 @@ struct HcaDecArgs {
     uint32_t noise_fill;           // 1: min_resolution == 0 (v3.0): k_hca_noise_scan + noise reconstruction in the transform
     uint32_t pairs_even;           // 1: every stereo pair starts on an even channel (a pair then shares a transform pass)
     uint32_t narrow;               // 1: k_hca_transform_plain reads this format's records: int8 lines where the values allow it
-    uint32_t inlane;               // 1: joint-stereo / HFR format (no noise fill) of 1, 2 or 4 channels with pairs_even: k_hca_transform_plain<C, ., true>
+    uint32_t inlane;               // 1: joint-stereo / HFR / noise-fill format that k_hca_transform_plain's joint, noise or wide joint instance takes
+    uint32_t wide_waves;           // wide forms: waves per workgroup = groups of up to four consecutive channels that keep every stereo pair together
     uint64_t in_bytes;             // size of the input blob (the intake's 16-byte loads stop there)
     uint64_t qc_offset;            // scratch byte offset of this group's quantised lines (tile-major, cri_types.h)
     uint64_t resg_offset;          // scratch byte offset of this group's band code descriptions: [tile][C][8 blocks][64 lanes] uint4 (16 bands x 1 byte)

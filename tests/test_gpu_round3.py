@@ -507,12 +507,12 @@ def test_wide_plain_layouts_trims_and_alignments(cc, ch):
 
 
 # ------------------------------------------------------------------------------------------------ the general transform kernel stays covered
-@pytest.mark.parametrize("ch,q,v3", [(1, 2, False), (2, 2, False), (2, 4, False), (4, 2, False), (4, 3, False), (6, 2, False), (8, 3, False), (2, 1, True), (2, 2, True),
-                                      (1, 1, True), (4, 1, True)])
+@pytest.mark.parametrize("ch,q,v3", [(1, 2, False), (2, 2, False), (2, 4, False), (4, 2, False), (4, 3, False), (6, 2, False), (8, 3, False), (3, 2, False), (5, 2, False), (7, 3, False),
+                                      (2, 1, True), (2, 2, True), (1, 1, True), (4, 1, True), (3, 1, True), (5, 1, True)])
 def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, monkeypatch, ch, q, v3):
     """Joint-stereo / HFR / noise-fill formats of 1, 2, 4 (and, without noise fill, 6 and 8) channels run on k_hca_transform_plain's
-    joint, wide and noise instances; k_hca_transform<false, C> -- what noise fill on 6 / 8 channels and odd pairings still use --
-    is forced onto the same streams here (CRI_NO_INLANE, read when the job is created): floats and PCM equal to the oracle's,
+    joint, wide and noise instances; k_hca_transform<false, C> and k_hca_transform_generic -- what noise fill on 3 and 5 to 8
+    channels still uses -- are forced onto the same streams here (CRI_NO_INLANE, read when the job is created): floats and PCM equal to the oracle's,
     bit for bit."""
     import hca_forge
     import torch

@@ -7,7 +7,7 @@ import oracle_lib as O
 from pycricodecs_amd.batch import Job
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 250
 for q in (2, 3):
-    for ch in (2, 4, 6, 8):
+    for ch in (2, 3, 4, 5, 6, 7, 8):
         uniq = [O.hca_crypt(O.hca_encode(B.family_wav(8300 + 10 * ch + u, 10.0, "tonal", ch=ch), q), 1, 56, B.KEY) for u in range(4)]
         job = Job.hca_decode(B.tile(uniq, N), keys=[B.KEY] * N)
         bufs = job.alloc("cuda:0"); job.enable_events(True)
