@@ -595,12 +595,13 @@ def secondary_measurements(args, D):
     # band below the noise level is reconstructed)
     import hca_forge
     nw = max(1, n // 4)
-    for label, ch, v3 in (("hca_decode_6ch", 6, False), ("hca_decode_8ch", 8, False), ("hca_decode_v3_noise_fill", 2, True), ("hca_decode_3ch", 3, False)):
-        plain = [O.hca_encode(family_wav(8000 + 10 * ch + u, args.seconds, "tonal", ch=ch), 1) for u in range(4)]
+    for label, ch, v3, q in (("hca_decode_6ch", 6, False, 1), ("hca_decode_8ch", 8, False, 1), ("hca_decode_v3_noise_fill", 2, True, 1), ("hca_decode_3ch", 3, False, 1),
+                             ("hca_decode_6ch_middle", 6, False, 2), ("hca_decode_5ch_middle", 5, False, 2)):      # (Middle: joint stereo + HFR, the wide joint form)
+        plain = [O.hca_encode(family_wav(8000 + 10 * ch + u, args.seconds, "tonal", ch=ch), q) for u in range(4)]
         if v3:
             plain = [hca_forge.forge_v3(h, 0) for h in plain]
-        r = hca_decode_run(D, nw, 4, args.seconds, 1, "tonal", 3, 1, uniq=[O.hca_crypt(h, 1, 56, KEY) for h in plain])
-        out[label] = {"workload": "HCA decode, %d x %.0f s encrypted %d-channel streams, quality High%s" % (nw, args.seconds, ch, ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""),
+        r = hca_decode_run(D, nw, 4, args.seconds, q, "tonal", 3, 1, uniq=[O.hca_crypt(h, 1, 56, KEY) for h in plain])
+        out[label] = {"workload": "HCA decode, %d x %.0f s encrypted %d-channel streams, quality %s%s" % (nw, args.seconds, ch, QNAME[q], ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""),
                       "transform_kernel": r["job"].dominant_kernel, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
                       "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "verified_items": r["verified"]["items"]}
     r = hca_encode_run(D, n, uq, args.seconds, 1, "tonal", 3, 1)
