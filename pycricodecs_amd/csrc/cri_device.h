@@ -35,6 +35,14 @@ template <int B> __device__ __forceinline__ float cvt_f32_i8(uint32_t w) {
     return r;
 }
 
+// (float)(int16_t)(w >> 16*H) in one instruction
+template <int H> __device__ __forceinline__ float cvt_f32_i16(uint32_t w) {
+    float r;
+    if (H == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(w));
+    else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(r) : "v"(w));
+    return r;
+}
+
 // LDS address of a pointer into shared memory, and 16-bit stores through such an address (no base to add per access)
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p; }

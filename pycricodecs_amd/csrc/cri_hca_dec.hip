@@ -1766,6 +1766,10 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         const uint32_t z0 = __builtin_amdgcn_readlane(p.fl, 0), z1 = __builtin_amdgcn_readlane(p.fl, 1), z2 = __builtin_amdgcn_readlane(p.fl, 2), z3 = __builtin_amdgcn_readlane(p.fl, 3);
         return (((u & 2) ? ((u & 1) ? z3 : z2) : ((u & 1) ? z1 : z0)) & HCA_REC_NARROW) != 0;
     };
+    auto none_narrow = [&](const PlainPre& p) {
+        if (!NW) return true;
+        return ((__builtin_amdgcn_readlane(p.fl, 0) | __builtin_amdgcn_readlane(p.fl, 1) | __builtin_amdgcn_readlane(p.fl, 2) | __builtin_amdgcn_readlane(p.fl, 3)) & HCA_REC_NARROW) == 0;
+    };
     auto all_narrow = [&](const PlainPre& p) {
         if (!NW) return false;
         return (__builtin_amdgcn_readlane(p.fl, 0) & __builtin_amdgcn_readlane(p.fl, 1) & __builtin_amdgcn_readlane(p.fl, 2) & __builtin_amdgcn_readlane(p.fl, 3) & HCA_REC_NARROW) != 0;
@@ -1886,7 +1890,7 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
     };
     auto lane_off = [&](bool narrow) { return narrow ? (l16 >> 3) * HCA_QC_QUARTER + (l16 & 7) * 8 : (l16 >> 2) * HCA_QC_QUARTER + (l16 & 3) * 16; };
     // (step_narrow: all four units' frames are int8 -- wave-uniform; mine: this lane's is)
-    auto lines_to_spectra = [&](const uint4& q, bool step_narrow, bool mine, uint32_t sf, f2 x[4]) {
+    auto lines_to_spectra = [&](const uint4& q, bool step_narrow, bool step_wide, bool mine, uint32_t sf, f2 x[4]) {
         const float4 g0 = *(const float4*)(G + u * 128 + l16 * 8), g1 = *(const float4*)(G + u * 128 + l16 * 8 + 4);
         const f2 gg[4] = {f2{g0.x, g0.y}, f2{g0.z, g0.w}, f2{g1.x, g1.y}, f2{g1.z, g1.w}};
         const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
@@ -1894,7 +1898,10 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 #pragma unroll
             for (int k = 0; k < 4; k++)                        // gains are 0 past the coded bands
                 x[k] = gg[k] * (k & 1 ? f2{cvt_f32_i8<2>(qw[k >> 1]), cvt_f32_i8<3>(qw[k >> 1])} : f2{cvt_f32_i8<0>(qw[k >> 1]), cvt_f32_i8<1>(qw[k >> 1])});
-        } else {                                           // a frame with wide lines among the four (rare): either form per lane
+        } else if (!NW || __builtin_expect(step_wide, 1)) {    // all four units' frames have int16 lines (material with high-resolution bands)
+#pragma unroll
+            for (int k = 0; k < 4; k++) x[k] = gg[k] * f2{cvt_f32_i16<0>(qw[k]), cvt_f32_i16<1>(qw[k])};
+        } else {                                           // narrow and wide frames among the four (rare): either form per lane
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t w = qw[k >> 1] >> (16 * (k & 1));
@@ -1984,10 +1991,10 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 #pragma unroll 1
     for (int s = -1; s < (int)h; s++) {
         const uint32_t next_rows = s + 1 < (int)h ? row0(s + 1) : rows;
-        bool step_narrow, mine; uint32_t loff;
+        bool step_narrow, step_wide, mine; uint32_t loff;
         {
             const PlainPre cur = pre;
-            step_narrow = all_narrow(cur); mine = my_narrow(cur); loff = lane_off(mine);
+            step_narrow = all_narrow(cur); step_wide = none_narrow(cur); mine = my_narrow(cur); loff = lane_off(mine);
             if (s + 1 < (int)h) pre = load_pre(s + 1);
             wave_lds_sync();                               // (the previous pass has read G)
             if (!setup(cur, s)) { flush_pcm(); return; }                   // (a group's halo frame is one of the run's own, except the first group's)
@@ -1995,7 +2002,7 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 #pragma unroll 1
         for (uint32_t sf = s < 0 ? 7 : 0; sf < 8; sf++) {
             f2 x[4];
-            lines_to_spectra(q, step_narrow, mine, sf, x);
+            lines_to_spectra(q, step_narrow, step_wide, mine, sf, x);
             // the next pass's lines, requested as soon as this pass's are in registers as floats, i.e. a whole DCT ahead of their use
             // (the next step's first row is laid out by that frame's own flag, which came with `pre` seven passes ago)
             flush_pcm();                                   // the previous pass's PCM (staged in LDS since)
