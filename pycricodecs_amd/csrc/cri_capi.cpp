@@ -103,10 +103,10 @@ struct cri_job {
     // device metadata (one allocation: MetaPool)
     MetaPool meta;
     DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
-        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert, d_segs, d_crcmul, d_seg_chain;
+        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert, d_segs, d_crcmul, d_seg_chain, d_enctab;
     cri_job() {
         for (DevBuf* b : {&d_formats, &d_streams, &d_cipher, &d_ath, &d_img, &d_img_off, &d_img_dst, &d_chain_stream, &d_history, &d_stale,
-                          &d_frame_sizes, &d_first_frame, &d_adx_streams, &d_adx_order, &d_crc_off, &d_convert, &d_segs, &d_crcmul, &d_seg_chain}) b->pool = &meta;
+                          &d_frame_sizes, &d_first_frame, &d_adx_streams, &d_adx_order, &d_crc_off, &d_convert, &d_segs, &d_crcmul, &d_seg_chain, &d_enctab}) b->pool = &meta;
     }
     std::vector<ConvertItem> convert;            // WAV items whose samples are converted to PCM16 in scratch before encoding
     uint64_t convert_total = 0;
@@ -1391,8 +1391,12 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
     if (formats.empty()) { HcaFormat F; memset(&F, 0, sizeof F); formats.push_back(F); }
     if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (crcmul.empty()) crcmul.assign(1024, 0);
-    int rc = 0;
-    if ((rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
+    static std::vector<uint8_t> enctab;                       // the same for every job: built once
+    static std::once_flag enctab_once; static int enctab_rc = 0;
+    std::call_once(enctab_once, [] { enctab_rc = hca_enc_build_tables(enctab); });
+    int rc = enctab_rc;
+    if (rc) { delete j; return rc; }
+    if ((rc = j->d_enctab.upload(enctab)) || (rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
@@ -1471,6 +1475,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
                 a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.crc_mul = (const uint16_t*)j->d_crcmul.p + j->hca_enc_crc_off[k];
+                a.tables = (const uint8_t*)j->d_enctab.p;
                 j->mark(0, true, s); launch_hca_encode(a, s); j->mark(0, false, s);
             }
             break;

@@ -551,4 +551,106 @@ void hca_pack_header(const HcaEncSetup& e, uint8_t* o) {      // hca.cpp:3109-31
     put_be16(o + e.header_size - 2, crc16(o, e.header_size - 2));
 }
 
+// ------------------------------------------------------------------------------------------------ encoder tables
+// The rate loop (CalculateUsedBits, hca.cpp:2763-2790) costs a spectrum x of a band with resolution r as
+//   r >= 8:  (r - 3) - 1 bits, one more when |x| >= QuantizerDeadZone[r]
+//   r <  8:  QuantizeSpectrumBits[r][(int)(x * inv + (inv + 1)) - (int)(inv + 0.5 - 8)]
+// and every row of QuantizeSpectrumBits is "shortest code near zero, one bit more from some |q| on" (plus entries of 0 past
+// the row's ends).  (int)(fl(fl(x * inv) + up)) is monotone in x, so the bits of x are
+//   shortest[r] + (x >= t_plus[r]) + (x <= -t_minus[r])
+// for two floats found here by bisection over the float bit patterns with the reference's own expression; the one
+// exception is x = 0.9999999f (ScaleSpectra's clamp): at resolutions 2, 4 and 5 the sum rounds up to the next integer,
+// the index runs one past the row's codes and the entry there is 0 -- no bits at all.  The kernel counts those values per
+// band once and takes their bits back out ("anomaly").  Everything is derived from the tables and checked: a table of
+// another shape makes this function fail instead of producing wrong bytes.
+static float f32_from_bits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static int enc_len_of(int r, float x) {
+    const float inv = HCA_ENC_INV_STEP[r], up = inv + 1;
+    const int down = (int)((double)inv + 0.5 - 8);
+    volatile float m = x * inv;                            // two roundings, as the reference's build (no FMA)
+    volatile float t = m + up;
+    const int idx = (int)t - down;
+    return (idx >= 0 && idx < 16) ? HCA_ENC_CODE_LEN[r][idx] : 0;
+}
+int hca_enc_build_tables(std::vector<uint8_t>& blob) {
+    blob.assign(HCA_ET_BYTES, 0);
+    float* win = (float*)(blob.data() + HCA_ET_WIN);
+    float* tw = (float*)(blob.data() + HCA_ET_TW);
+    float* deq = (float*)(blob.data() + HCA_ET_DEQ);
+    float* escale = (float*)(blob.data() + HCA_ET_ESCALE);
+    uint32_t* cp = (uint32_t*)(blob.data() + HCA_ET_CP);
+    float* inv = (float*)(blob.data() + HCA_ET_INV);
+    float* ib = (float*)(blob.data() + HCA_ET_IBOUNDS);
+    uint8_t* sfbase = blob.data() + HCA_ET_SFBASE;
+    uint8_t* clen = blob.data() + HCA_ET_CLEN;
+    uint8_t* code = blob.data() + HCA_ET_CODE;
+    uint8_t* ishuf = blob.data() + HCA_ET_ISHUF;
+    for (int i = 0; i < 128; i++) { win[i] = HCA_WINDOW[i]; ishuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
+    {
+        int k = 0;
+        const int rows[7] = {7, 5, 4, 3, 2, 1, 0}, count[7] = {64, 32, 16, 8, 4, 2, 1};
+        for (int j = 0; j < 7; j++) for (int i = 0; i < count[j]; i++, k++) { tw[2 * k] = HCA_ENC_COS[rows[j]][i]; tw[2 * k + 1] = HCA_ENC_SIN[rows[j]][i]; }
+    }
+    for (int i = 0; i < 72; i++) deq[i] = i < 63 ? HCA_DEQ_SCALE[i] : f32_from_bits(0x7FC00000u);   // NaN padding never compares <=
+    for (int i = 0; i < 64; i++) escale[i] = HCA_ENC_SCALE[i];
+    for (int j = 0; j < 32; j++) {                         // entries 0..62 that are <= 2^(j - 25) (hca.cpp:2611-2623 by exponent)
+        const float thr = f32_from_bits((uint32_t)(j + 102) << 23);
+        int n = 0;
+        for (int k = 0; k < 63; k++) n += HCA_DEQ_SCALE[k] <= thr ? 1 : 0;
+        sfbase[j] = (uint8_t)n;
+    }
+    for (int i = 0; i < 16; i++) { inv[i] = HCA_ENC_INV_STEP[i]; ib[i] = i < 14 ? HCA_ENC_INTENSITY_BOUNDS[i] : 0.0f; }
+    // per resolution: shortest code, thresholds, anomaly
+    uint32_t tplus[16], tminus[16], shortest[16], anomaly[16];
+    tplus[0] = tminus[0] = 0x7F800000u; shortest[0] = 0; anomaly[0] = 0;   // resolution 0: nothing is written
+    for (int r = 1; r < 16; r++) {
+        anomaly[r] = 0;
+        if (r >= 8) { uint32_t u; memcpy(&u, &HCA_ENC_DEAD_ZONE[r], 4); tplus[r] = tminus[r] = u; shortest[r] = (uint32_t)r - 4; continue; }
+        const int l0 = enc_len_of(r, 0.0f);
+        shortest[r] = (uint32_t)l0;
+        for (int sign = 0; sign < 2; sign++) {
+            // smallest magnitude whose code is not the shortest one
+            uint32_t lo = 0, hi = HCA_ENC_CLAMP_BITS;
+            const float s = sign ? -1.0f : 1.0f;
+            if (enc_len_of(r, s * f32_from_bits(hi)) == l0) return CRI_ERR_INVALID_ARG;
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (enc_len_of(r, s * f32_from_bits(mid)) != l0) hi = mid; else lo = mid + 1; }
+            (sign ? tminus : tplus)[r] = lo;
+            // from there on: one bit more, up to the clamp -- except (positive side only) the clamp value itself, which may cost nothing
+            const uint32_t probes[6] = {lo, lo + 1, lo + (HCA_ENC_CLAMP_BITS - lo) / 3, lo + (HCA_ENC_CLAMP_BITS - lo) / 2, HCA_ENC_CLAMP_BITS - 1, HCA_ENC_CLAMP_BITS};
+            for (int k = 0; k < 6; k++) {
+                const int l = enc_len_of(r, s * f32_from_bits(probes[k]));
+                if (l == l0 + 1) continue;
+                if (!sign && probes[k] == HCA_ENC_CLAMP_BITS && l == 0) { anomaly[r] = 1; continue; }
+                return CRI_ERR_INVALID_ARG;
+            }
+        }
+        // exact check of the step structure: every index step of the quantiser (at most 16 per side) changes the length as the rule says
+        for (int sign = 0; sign < 2; sign++) {
+            const float s = sign ? -1.0f : 1.0f;
+            uint32_t at = 0;
+            while (at < HCA_ENC_CLAMP_BITS) {                // next magnitude where the length changes
+                const int l = enc_len_of(r, s * f32_from_bits(at));
+                uint32_t lo = at, hi = HCA_ENC_CLAMP_BITS;
+                if (enc_len_of(r, s * f32_from_bits(hi)) == l) {
+                    // no length change up to the clamp -- but the index may step without changing the length; walk the steps
+                    break;
+                }
+                while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (enc_len_of(r, s * f32_from_bits(mid)) != l) hi = mid; else lo = mid + 1; }
+                const uint32_t expect = (sign ? tminus : tplus)[r];
+                if (lo != expect && !(lo == HCA_ENC_CLAMP_BITS && !sign && anomaly[r])) return CRI_ERR_INVALID_ARG;
+                at = lo;
+            }
+        }
+    }
+    for (int i = 0; i < 60; i++) {
+        const int r = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0;
+        cp[4 * i + 0] = tplus[r];
+        cp[4 * i + 1] = tminus[r] ^ 0x80000000u;              // -t_minus: the test is x <= -t_minus
+        cp[4 * i + 2] = 8 * shortest[r] | anomaly[r] << 8 | (uint32_t)r << 16;
+        cp[4 * i + 3] = 0;
+    }
+    cp[4 * 59 + 1] = 0xFF800000u;                             // -inf: nothing is <= it
+    return 0;
+}
+
 }  // namespace cri

@@ -87,5 +87,8 @@ struct HcaEncSetup {
 void hca_enc_setup_loop(HcaEncSetup& e, uint32_t loop_start, uint32_t loop_end, uint32_t column_size);
 int hca_enc_setup(uint32_t channels, uint32_t rate, uint32_t samples_per_channel, uint32_t quality, HcaEncSetup& e);
 void hca_pack_header(const HcaEncSetup& e, uint8_t* out);
+// the table blob k_hca_encode copies into LDS (layout: HCA_ET_* in cri_kernels.h); 0 or CRI_ERR_INVALID_ARG when the
+// code-length tables do not have the one-threshold shape the kernel's rate loop relies on (they do; checked, not assumed)
+int hca_enc_build_tables(std::vector<uint8_t>& blob);
 
 }  // namespace cri

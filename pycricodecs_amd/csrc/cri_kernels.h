@@ -44,13 +44,15 @@ void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);
 
 struct HcaEncArgs {
     const uint8_t* in; uint8_t* out; int32_t* status;
+    const uint8_t* tables;         // HCA_ET_* blob
     const uint8_t* scratch;        // converted PCM16 (HcaStream::pad0 != 0 -> src_offset is relative to scratch)
     const HcaFormat* formats;
     const HcaStream* streams;      // sorted by format; src_offset = first PCM byte, dst_offset = first frame byte
     const uint16_t* crc_mul;       // [64][16]: (x^bit * x^(8 * crc_chunk * (63 - lane))) mod P: a lane's chunk remainder times its place in the frame
     uint32_t format, stream_begin, stream_end, frames, channels, frame_size;
     uint32_t crc_chunk;            // bytes of the (front-padded) frame each lane checksums
-    uint32_t lds_per_wave;         // LDS bytes of one frame's working set (set by launch_hca_encode)
+    uint32_t lds_per_frame;        // LDS bytes of one frame's working set (set by launch_hca_encode)
+    uint32_t frames_per_group;     // frames per workgroup (set by launch_hca_encode)
 };
 size_t hca_encode_lds_bytes(uint32_t channels, uint32_t frame_size);
 void launch_hca_encode(const HcaEncArgs& a, hipStream_t s);

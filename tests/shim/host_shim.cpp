@@ -38,3 +38,12 @@ extern "C" int shim_adx_parse_header(const uint8_t* d, size_t len, uint32_t out[
     memcpy(out, f, sizeof f);
     return 0;
 }
+
+extern "C" int shim_hca_enc_tables(uint8_t* out, size_t cap) {   // the encoder's LDS table blob (HCA_ET_* layout, cri_types.h)
+    std::vector<uint8_t> blob;
+    const int rc = hca_enc_build_tables(blob);
+    if (rc) return rc;
+    if (blob.size() > cap) return -1;
+    memcpy(out, blob.data(), blob.size());
+    return (int)blob.size();
+}
