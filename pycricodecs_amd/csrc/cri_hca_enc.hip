@@ -14,9 +14,9 @@
 // Shape.  A channel's 8 x 128 spectra are 16 per lane -- band pair (2 * lane, 2 * lane + 1), the order of the bit stream -- and
 // stay in registers from ScaleSpectra to the last bit written.  Channels meet in three places only: intensity stereo (a pair's
 // spectra, through LDS), the rate loop's bit totals and the bit positions of the pack (a few words through LDS and a workgroup
-// barrier each).  The rate loop never quantises: the bits of a spectrum at resolution r are shortest[r] + (x >= t_plus[r]) +
-// (x <= -t_minus[r]) (cri_host.cpp, hca_enc_build_tables), so a search step is two compares per spectrum whose lane masks are
-// counted on the scalar unit.
+// barrier each).  The rate loop never quantises: the bits of a spectrum at resolution r are shortest[r] + (its class reaches
+// rank[r]) (cri_host.cpp, hca_enc_build_tables) -- every spectrum is classed once, a band's eight classes are eight bytes, and a
+// search step costs a band two adds, two ands and two popcounts.
 //
 // Everything the reference evaluates in floating point is evaluated here with the same single IEEE operations in the
 // same order (sequential sums stay sequential, on one lane); bit allocation is integer work; the bit stream is assembled
@@ -28,6 +28,17 @@
 #include "../../include/cricodecs_hip.h"
 
 namespace cri {
+
+// Developer instrumentation (-DCRI_ENC_PROFILE through CRI_HIPCC_EXTRA; never in the shipped build): wave cycles per phase of
+// k_hca_encode, summed over all waves
+#ifdef CRI_ENC_PROFILE
+__device__ unsigned long long g_enc_prof[1024][16];       // spread over 1024 slots so the atomics do not serialise on one address
+#define ENC_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
+#define ENC_PROF_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_enc_prof[(g * C + c) & 1023][k_], prof_acc[k_]); } while (0)
+#else
+#define ENC_MARK(k) do {} while (0)
+#define ENC_PROF_FLUSH() do {} while (0)
+#endif
 
 // inclusive prefix sum over the 64 lanes with DPP adds: row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast 15 / 31
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
@@ -51,7 +62,8 @@ __device__ __forceinline__ uint32_t crc16_step_enc(uint32_t crc, uint32_t b) {
 struct EncTab {            // views into the LDS copy of the table blob (HCA_ET_*, cri_types.h)
     const float *win, *deq, *escale, *inv, *ibounds;
     const f2* tw;
-    const uint4* cp;
+    const uint2* cp;
+    const uint4* cls;
     const uint8_t *sfbase, *clen, *code, *ishuf;
 };
 
@@ -77,14 +89,13 @@ __device__ __forceinline__ f2 enc_rot(f2 u, f2 tw) {
     return pk_add_neg_hi(p, q);
 }
 
-// MSB-first write of `len` bits of v at absolute bit position p of the frame (words are big-endian 32-bit)
+// MSB-first write of the `len` bits v (v < 2^len, len <= 26) at absolute bit position p of the frame (words are big-endian
+// 32-bit): the bits land in one word or straddle two -- one 64-bit shift serves both cases
 __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v, uint32_t len) {
-    if (!len) return;
-    v &= len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1);
-    const uint32_t w = p >> 5;
-    const int shift = 32 - (int)(p & 31) - (int)len;
-    if (shift >= 0) atomicOr(&words[w], v << shift);
-    else { atomicOr(&words[w], v >> (-shift)); atomicOr(&words[w + 1], v << (32 + shift)); }
+    const uint64_t t = (uint64_t)v << ((64u - (p & 31) - len) & 63);
+    const uint32_t hi = (uint32_t)(t >> 32), lo = (uint32_t)t;
+    if (hi) atomicOr(&words[p >> 5], hi);
+    if (lo) atomicOr(&words[(p >> 5) + 1], lo);
 }
 
 // ---- LDS of one frame.  Exchange words first, then the frame image, then one region per channel.
@@ -140,13 +151,16 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const uint8_t
     hbits = min_len; dbits = min_db;
 }
 
+#ifndef ENC_MIN_WAVES_PER_SIMD
+#define ENC_MIN_WAVES_PER_SIMD 4   // register budget (measured: held to 5 waves the kernel spills and loses 6 %)
+#endif
 #ifndef ENC_MAX_WAVES
 #define ENC_MAX_WAVES 4      // waves of a workgroup when a frame has fewer channels than that (mono: 4 frames, stereo: 2)
 #endif
 
 // CT = channels of the format (1 .. 8); workgroup = FPG frames x CT waves
 template <int CT>
-__global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT)) void k_hca_encode(HcaEncArgs a) {
+__global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT), ENC_MIN_WAVES_PER_SIMD) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t C = CT;
     constexpr bool XCH = C > 1;                            // the frame's waves exchange through LDS, a workgroup barrier each time
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     for (uint32_t i = tid; i < HCA_ET_BYTES / 16; i += blockDim.x) ((uint4*)smem_all)[i] = ((const uint4*)a.tables)[i];
     EncTab T;
     T.win = (const float*)(smem_all + HCA_ET_WIN); T.tw = (const f2*)(smem_all + HCA_ET_TW); T.deq = (const float*)(smem_all + HCA_ET_DEQ);
-    T.escale = (const float*)(smem_all + HCA_ET_ESCALE); T.cp = (const uint4*)(smem_all + HCA_ET_CP); T.inv = (const float*)(smem_all + HCA_ET_INV);
+    T.escale = (const float*)(smem_all + HCA_ET_ESCALE); T.cp = (const uint2*)(smem_all + HCA_ET_CP); T.cls = (const uint4*)(smem_all + HCA_ET_CLS); T.inv = (const float*)(smem_all + HCA_ET_INV);
     T.ibounds = (const float*)(smem_all + HCA_ET_IBOUNDS); T.sfbase = smem_all + HCA_ET_SFBASE; T.clen = smem_all + HCA_ET_CLEN;
     T.code = smem_all + HCA_ET_CODE; T.ishuf = smem_all + HCA_ET_ISHUF;
 
@@ -180,6 +194,9 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     uint8_t* sfac = chb + ENC_CH_SFAC;
     float* havg = (float*)(chb + ENC_CH_HAVG); int* hfrs = (int*)(chb + ENC_CH_HFRS); float* ratio_l = (float*)(chb + ENC_CH_RATIO);
     const uint32_t tidf = c * 64 + lane;                   // thread within the frame
+#ifdef CRI_ENC_PROFILE
+    unsigned long long prof_acc[16] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     for (uint32_t i = tidf; i < nwords; i += 64 * C) words[i] = 0;
 
     // frame -> stream
@@ -234,81 +251,87 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             }
         }
     }
+    ENC_MARK(0);
     __syncthreads();                                       // tables, zeroed frame image, staged samples
+    ENC_MARK(1);
 
-    // ---- MDCT of the channel's 8 subframes: hca.cpp:2529-2553 (window + fold), 2481-2527 (DCT-IV), in registers.
-    // Four transforms at a time: slot = lane >> 4 picks the transform, its 16 lanes hold the 64 complex points of the
-    // reference's in-place radix-2 network, point j = 4 * lane16 + r in f2 z[r].  Stages on bits 5..2 of j exchange with
-    // lane16 ^ 8, 4, 2, 1 (DPP), stages on bits 1, 0 pair registers.  The lane that holds the lower point of a pair keeps
-    // the sum, the other one rotates the difference; the sum/difference is fma(z, +-1, partner) (exact product).
+    // ---- MDCT of the channel's 8 subframes: hca.cpp:2529-2553 (window + fold), 2481-2527 (DCT-IV), all eight at once in registers.
+    // Subframe = lane >> 3; its 8 lanes hold the 64 complex points of the reference's in-place radix-2 network, 8 per lane.
+    // First as point j = l8 + 8 * r in z[r]: the stages on bits 5, 4, 3 of j pair registers; then the points change places
+    // through LDS (j = 8 * l8 + r) and the stages on bits 2, 1, 0 pair registers again -- no stage exchanges between lanes.
+    // A stage keeps the sum in the lower point and rotates the difference into the upper one (twiddle row = bit, index = the
+    // bits of j below it).  The window is held times 2^-15 (PcmToFloat's scale, hca.cpp:2470-2479: a power of two commutes with
+    // the rounding of the product).
     {
-        const uint32_t l16 = lane & 15, slot = lane >> 4;
-        // window coefficients and sample positions (within the 256 samples [n0-128, n0+128)) of the lane's 8 folded inputs
-        float wA[8], wB[8]; int mA[8], mB[8];
+        const uint32_t l8 = lane & 7, sfm = lane >> 3;
+        const int16_t* sw = stg + sfm * 128;               // the subframe's 256 samples [n0 - 128, n0 + 128)
+        f2 z[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int r = q & 3, odd = q >> 2;
-            const int k = odd ? 127 - 8 * (int)l16 - 2 * r : 8 * (int)l16 + 2 * r;
-            const bool low = k < 64;
-            mA[q] = low ? 192 + k : k - 64; mB[q] = 191 - k;
-            const float w = T.win[low ? 63 - k : k - 64];
-            wA[q] = low ? -w : w;                             // hca.cpp:2532: window * -sample
-            wB[q] = T.win[low ? 64 + k : 191 - k];
+        for (int r = 0; r < 8; r++) {
+            // folded inputs k = 2j (even) and 127 - 2j (odd) of point j: hca.cpp:2532-2547
+            float in[2];
+#pragma unroll
+            for (int odd = 0; odd < 2; odd++) {
+                const bool low = (r < 4) != (odd != 0);    // k < 64
+                const int k = odd ? 127 - 2 * (int)l8 - 16 * r : 2 * (int)l8 + 16 * r;
+                const int ma = low ? 192 + k : k - 64, mb = 191 - k;
+                const float wa = T.win[low ? 63 - k : k - 64], wb = T.win[low ? 64 + k : 191 - k];
+                const float xa = (float)(int)sw[ma], xb = (float)(int)sw[mb];
+                const float pa = (low ? -wa : wa) * xa, pb = wb * xb;      // hca.cpp:2532: window * -sample in the lower half
+                in[odd] = pa + pb;
+            }
+            z[r] = enc_rot(f2{in[0], in[1]}, T.tw[l8 + 8 * r]);
         }
-        const float sg8 = l16 & 8 ? -1.0f : 1.0f, sg4 = l16 & 4 ? -1.0f : 1.0f, sg2 = l16 & 2 ? -1.0f : 1.0f, sg1 = l16 & 1 ? -1.0f : 1.0f;
-        uint32_t opos[8];                                      // where the lane's 8 outputs go in the spectrum (inverse of the final shuffle)
+#define ENC_BFLY(LO, HI, TW) { const f2 d_ = z[LO] - z[HI]; z[LO] = z[LO] + z[HI]; z[HI] = enc_rot(d_, TW); }
+        {   // bit 5: (z[r], z[r + 4]), twiddle [5][l8 + 8 r]
 #pragma unroll
-        for (int q = 0; q < 8; q++) opos[q] = T.ishuf[8 * l16 + q];
-#pragma unroll 1
-        for (uint32_t pass = 0; pass < 2; pass++) {
-            const uint32_t sf = pass * 4 + slot;
-            float in[8];
-            {
-                const int16_t* sw = stg + sf * 128;
+            for (int r = 0; r < 4; r++) ENC_BFLY(r, r + 4, T.tw[64 + l8 + 8 * r])
+        }
+        {   // bit 4: (z[r], z[r + 2]), twiddle [4][l8 + 8 (r & 1)]
+            const f2 t0 = T.tw[96 + l8], t1 = T.tw[96 + l8 + 8];
+            ENC_BFLY(0, 2, t0) ENC_BFLY(1, 3, t1) ENC_BFLY(4, 6, t0) ENC_BFLY(5, 7, t1)
+        }
+        {   // bit 3: (z[r], z[r + 1]), twiddle [3][l8]
+            const f2 t0 = T.tw[112 + l8];
+            ENC_BFLY(0, 1, t0) ENC_BFLY(2, 3, t0) ENC_BFLY(4, 5, t0) ENC_BFLY(6, 7, t0)
+        }
+        // change of places: point j sits at slot j + (j >> 3) of the subframe's 72 (the padding keeps both the stores --
+        // l8 + 9 r -- and the loads -- 9 l8 + r -- off each other's banks).  The buffer lies over the channel's spectra and
+        // staging rows: every sample has been read by now, and the spectra are stored after the last load below.
+        f2* tb = (f2*)chb + sfm * 72;
+        wave_lds_sync();
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const float xa = (float)(int)sw[mA[q]] * (float)(1.0f / 32768.0f), xb = (float)(int)sw[mB[q]] * (float)(1.0f / 32768.0f);   // PcmToFloat, hca.cpp:2470-2479
-                    const float pa = wA[q] * xa, pb = wB[q] * xb;
-                    in[q] = pa + pb;                           // a - b with b = -(w*x)
-                }
-            }
-            f2 z[4];
-            {
-                const float4 ta = *(const float4*)(T.tw + 4 * l16), tb = *(const float4*)(T.tw + 4 * l16 + 2);
-                const f2 tw[4] = {f2{ta.x, ta.y}, f2{ta.z, ta.w}, f2{tb.x, tb.y}, f2{tb.z, tb.w}};
+        for (int r = 0; r < 8; r++) tb[l8 + 9 * r] = z[r];
+        wave_lds_sync();
 #pragma unroll
-                for (int r = 0; r < 4; r++) z[r] = enc_rot(f2{in[r], in[4 + r]}, tw[r]);
-            }
-#define ENC_CROSS(X, TB, SG) { \
-                const uint32_t ti = TB + ((l16 & (X - 1)) << 2); \
-                const float4 ta = *(const float4*)(T.tw + ti), tb = *(const float4*)(T.tw + ti + 2); \
-                const f2 tw[4] = {f2{ta.x, ta.y}, f2{ta.z, ta.w}, f2{tb.x, tb.y}, f2{tb.z, tb.w}}; \
-                const bool hi = (l16 & X) != 0; \
-                _Pragma("unroll") for (int r = 0; r < 4; r++) { \
-                    const f2 u = __builtin_elementwise_fma(z[r], f2{SG, SG}, lane16_xor2<X>(z[r])); \
-                    const f2 w = enc_rot(u, tw[r]); \
-                    z[r] = f2{hi ? w.x : u.x, hi ? w.y : u.y}; \
-                } }
-            ENC_CROSS(8, 64, sg8) ENC_CROSS(4, 96, sg4) ENC_CROSS(2, 112, sg2) ENC_CROSS(1, 120, sg1)
-#undef ENC_CROSS
-            {   // bit 1 of j: (z0, z2) with twiddle [1][0], (z1, z3) with [1][1]
-                const float4 t1 = *(const float4*)(T.tw + 124);
-                const f2 d0 = z[0] - z[2], d1 = z[1] - z[3];
-                z[0] = z[0] + z[2]; z[1] = z[1] + z[3];
-                z[2] = enc_rot(d0, f2{t1.x, t1.y}); z[3] = enc_rot(d1, f2{t1.z, t1.w});
-            }
-            {   // bit 0 of j: (z0, z1), (z2, z3) with twiddle [0][0]
-                const f2 t0 = T.tw[126];
-                const f2 d0 = z[0] - z[1], d1 = z[2] - z[3];
-                z[0] = z[0] + z[1]; z[2] = z[2] + z[3];
-                z[1] = enc_rot(d0, t0); z[3] = enc_rot(d1, t0);
-            }
-            float* out = sp + sf * 128;
+        for (int r = 0; r < 8; r++) z[r] = tb[9 * l8 + r];
+        wave_lds_sync();
+        {   // bit 2: (z[r], z[r + 4]), twiddle [2][r]
 #pragma unroll
-            for (int r = 0; r < 4; r++) { const f2 o = z[r] * f2{0.125f, 0.125f}; out[opos[2 * r]] = o.x; out[opos[2 * r + 1]] = o.y; }
+            for (int r = 0; r < 4; r++) ENC_BFLY(r, r + 4, T.tw[120 + r])
+        }
+        {   // bit 1: (z[r], z[r + 2]), twiddle [1][r & 1]
+            const f2 t0 = T.tw[124], t1 = T.tw[125];
+            ENC_BFLY(0, 2, t0) ENC_BFLY(1, 3, t1) ENC_BFLY(4, 6, t0) ENC_BFLY(5, 7, t1)
+        }
+        {   // bit 0: (z[r], z[r + 1]), twiddle [0][0]
+            const f2 t0 = T.tw[126];
+            ENC_BFLY(0, 1, t0) ENC_BFLY(2, 3, t0) ENC_BFLY(4, 5, t0) ENC_BFLY(6, 7, t0)
+        }
+#undef ENC_BFLY
+        // point j = 8 l8 + r holds spectrum lines ishuf[2j], ishuf[2j + 1] (the inverse of the final shuffle), scaled by 1/8
+        const uint4 op = *(const uint4*)(T.ishuf + 16 * l8);
+        const uint32_t opw[4] = {op.x, op.y, op.z, op.w};
+        float* out = sp + sfm * 128;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const f2 o = z[r] * f2{0.125f, 0.125f};
+            const uint32_t w = opw[r >> 1] >> (16 * (r & 1));
+            out[w & 0xFF] = o.x; out[(w >> 8) & 0xFF] = o.y;
         }
     }
     const uint32_t mytype = F.type(c);
+    ENC_MARK(2);
 
     // ---- EncodeIntensityStereo, hca.cpp:2561-2609 (sequential sums: one lane per subframe), by the pair's primary wave
     if (C > 1 && F.stereo > 0) {
@@ -344,6 +367,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         __syncthreads();
     } else wave_lds_sync();
 
+    ENC_MARK(3);
     // ---- CalculateHfrGroupAverages, hca.cpp:2656-2674 (sequential sums: one lane per group).  It reads the unscaled
     //      spectra of the bands above the coded range.
     const int hfr_start = (int)(F.stereo + F.base);
@@ -367,6 +391,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     const uint32_t coded = F.coded(c);
     const uint32_t b0 = 2 * lane, b1 = b0 + 1;
     f2 xr[8];                                              // xr[subframe] = {band b0, band b1}, scaled
+    uint32_t cl[2][2];                                     // cl[band]: the classes (cri_host.cpp) of its 8 spectra, a byte each
     int sfr[2]; uint32_t ntop[2];
     {
         float m0 = 0, m1 = 0;
@@ -392,6 +417,22 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             xr[sf] = f2{v0, v1};
             ntop[0] += __float_as_uint(v0) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
             ntop[1] += __float_as_uint(v1) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
+        }
+        // class of every spectrum: how many of the fifteen resolutions' thresholds (of its sign) it reaches
+        cl[0][0] = cl[0][1] = cl[1][0] = cl[1][1] = 0;
+#pragma unroll
+        for (int sf = 0; sf < 8; sf++) {
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                const float v = b ? xr[sf].y : xr[sf].x;
+                const uint32_t u = __float_as_uint(v);
+                int e = (int)((u >> 23) & 0xFF) - 114;
+                e = e < 0 ? 0 : e;                         // (|v| < 1: at most 12)
+                const uint4 row = T.cls[2 * e + (int)(u >> 31)];
+                const uint32_t k = row.z + (fabsf(v) >= __uint_as_float(row.x) ? 1u : 0u) + (fabsf(v) >= __uint_as_float(row.y) ? 1u : 0u);
+                cl[b][sf >> 2] |= k << (8 * (sf & 3));
+            }
+            __builtin_amdgcn_sched_barrier(0);             // (a few rows in flight, not all sixteen: registers)
         }
     }
     const bool any_top = __builtin_amdgcn_ballot_w64((ntop[0] | ntop[1]) != 0) != 0;
@@ -424,6 +465,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         wave_lds_sync();
     }
 
+    ENC_MARK(4);
     // ---- rate loop: CalculateNoiseLevel, CalculateEvaluationBoundary (hca.cpp:2792-2866)
     // A band sits at curve position noise - kb; the table row of that position holds its resolution's thresholds and shortest code.
     int kb[2]; bool live[2];
@@ -431,40 +473,23 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 #pragma unroll
         for (int b = 0; b < 2; b++) { kb[b] = 5 * sfr[b] / 2 - 2; live[b] = (b ? b1 : b0) < coded && sfr[b] != 0; }
     };
-    auto row_of = [&](int noise, int b) -> uint4 {
+    auto row_of = [&](int noise, int b) -> uint2 {
         int cp = noise - kb[b];
         cp = cp < 0 ? 0 : (cp > 58 ? 58 : cp);
         return T.cp[live[b] ? cp : 59];
     };
-    auto anomaly_bits = [&](const uint4& t, int b) -> int {   // bits counted for values the quantiser pushes past its table (cri_host.cpp)
-        return (t.z >> 8) & 1 ? (int)(ntop[b] * (((t.z & 0xFF) >> 3) + 1)) : 0;
-    };
-    // this channel's spectra bits at one noise level for every band (CalculateUsedBits with evaluation boundary 0), wave-uniform
-    auto level_bits = [&](int noise) -> int {
-        int lsum = 0, cnt = 0;
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const uint4 t = row_of(noise, b);
-            const float tp = __uint_as_float(t.x), ntm = __uint_as_float(t.y);
-            lsum += (int)(t.z & 0xFF);
-            if (any_top) lsum -= anomaly_bits(t, b);
-#pragma unroll
-            for (int sf = 0; sf < 8; sf++) {
-                const float v = b ? xr[sf].y : xr[sf].x;
-                cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(v >= tp)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v <= ntm));
-            }
-        }
-        return cnt + wave_sum(lsum);
-    };
-    // the same per band, per lane
+    // the bits of band b's 8 spectra at one noise level (the inner part of CalculateUsedBits, hca.cpp:2771-2786): 8 times the
+    // resolution's shortest code plus the spectra whose class reaches the resolution's rank, less what was counted for values the
+    // quantiser pushes past its table (cri_host.cpp)
     auto band_bits = [&](int noise, int b) -> int {
-        const uint4 t = row_of(noise, b);
-        const float tp = __uint_as_float(t.x), ntm = __uint_as_float(t.y);
-        int n = (int)(t.z & 0xFF) - anomaly_bits(t, b);
-#pragma unroll
-        for (int sf = 0; sf < 8; sf++) { const float v = b ? xr[sf].y : xr[sf].x; n += (v >= tp ? 1 : 0) + (v <= ntm ? 1 : 0); }
+        const uint2 t = row_of(noise, b);
+        int n = (int)(t.y & 0xFF);
+        n += __builtin_popcount((cl[b][0] + t.x) & 0x10101010u) + __builtin_popcount((cl[b][1] + t.x) & 0x10101010u);
+        if (any_top) n -= (t.y >> 8) & 1 ? (int)(ntop[b] * (((t.y & 0xFF) >> 3) + 1)) : 0;
         return n;
     };
+    // this channel's spectra bits at one noise level for every band (CalculateUsedBits with evaluation boundary 0), wave-uniform
+    auto level_bits = [&](int noise) -> int { return wave_sum(band_bits(noise, 0) + band_bits(noise, 1)); };
     int hbits_c = 0, dbits_c = 0;
     const int avail = (int)F.frame_size * 8;
     int noise_level = -1, eval_boundary = 0, status = 0, hbtot = 0;
@@ -486,12 +511,20 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             } else hbtot = 16 + 16 + 16 + hbits_c;
             int low = 0, high = done ? 0 : 255;
             bool over = false;                             // "mid_value > available bits" of the last step (hca.cpp:2806-2815)
+#ifdef ENC_ABL_STEPS
+            for (int step = 0; step < ENC_ABL_STEPS; step++) {
+#else
             for (int step = 0; step < 8; step++) {         // 256 levels: always 8 steps
+#endif
                 const int mid = (low + high) / 2;
                 int bits = done ? 0 : level_bits(mid);
                 if (XCH) {
                     if (lane == 0) X_step[par * 8 + c] = bits;
+#ifdef ENC_ABL_NOBARRIER
+                    wave_lds_sync();
+#else
                     __syncthreads();
+#endif
                     bits = 0;
 #pragma unroll
                     for (uint32_t k = 0; k < C; k++) bits += X_step[par * 8 + k];
@@ -520,6 +553,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             }
         }
     }
+    ENC_MARK(5);
     uint32_t* P = (uint32_t*)sp;                           // the channel's spectra region is free from here on
     {
         // only two resolutions per band occur in this search (noise_level and noise_level - 1): cost them once, then the bits at an
@@ -559,6 +593,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             if (level < 0) status = CRI_ERR_HCA_ENCODE; else eval_boundary = level;
         }
     }
+    ENC_MARK(6);
     uint8_t* dst = a.out + st.dst_offset + (uint64_t)f * F.frame_size;
     if (status != 0) {                                     // (the same decision in every wave of the frame)
         if (c == 0) {
@@ -573,13 +608,13 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const int i = (int)(b ? b1 : b0);
-        const uint4 t = row_of(i < eval_boundary ? noise_level - 1 : noise_level, b);
-        rb[b] = (int)(t.z >> 16);                          // 0 for bands that are not coded or have no scalefactor
+        const uint2 t = row_of(i < eval_boundary ? noise_level - 1 : noise_level, b);
+        rb[b] = (int)(t.y >> 16);                          // 0 for bands that are not coded or have no scalefactor
     }
     uint32_t pos = 32;
     if (XCH) { for (uint32_t k = 0; k < c; k++) pos += (uint32_t)X_hbits[k]; }
     if (status == 0) {
-        if (c == 0 && lane == 0) { atomicOr(&words[0], 0xFFFF0000u); put_bits(words, 16, (uint32_t)noise_level, 9); put_bits(words, 25, (uint32_t)eval_boundary, 7); }
+        if (c == 0 && lane == 0) atomicOr(&words[0], 0xFFFF0000u | (uint32_t)noise_level << 7 | (uint32_t)eval_boundary);   // sync, 9 + 7 bits
         const int db = dbits_c;
         if (lane == 0) put_bits(words, pos, (uint32_t)db, 3);
         pos += 3;
@@ -615,6 +650,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         }
     }
 
+    ENC_MARK(7);
     // ---- spectra: QuantizeSpectra (hca.cpp:2878-2892) + WriteSpectra (2920-2936).  A row (subframe, channel) of the stream is
     // this wave's 64 band pairs: the two codes of a lane as one word, their place by a prefix sum over the lanes; the rows' totals
     // go through LDS so that every wave knows where its rows start.
@@ -645,6 +681,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             incl[sf] = wave_incl_scan_dpp(tl) | tl << 16;                  // a row is at most 64 * 26 bits
         }
     }
+    ENC_MARK(8);
     uint32_t rowbase[8];
     if (XCH) {
         if (lane == 63) {
@@ -661,7 +698,11 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) { rowbase[sf] = acc; acc += (uint32_t)__builtin_amdgcn_readlane((int)incl[sf], 63) & 0xFFFF; }
     }
+#ifdef ENC_ABL_NOPUT
+    if (status == 77) {
+#else
     if (status == 0) {
+#endif
         const uint32_t start = (uint32_t)hbtot - 16;       // sync + header + every channel's scalefactor part
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) {
@@ -670,8 +711,10 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             put_bits(words, start + rowbase[sf] + ((incl[sf] & 0xFFFF) - tl), both[sf], tl);
         }
     }
+    ENC_MARK(9);
     if (XCH) __syncthreads(); else wave_lds_sync();
-    if (c != 0 || status != 0) return;
+    ENC_MARK(10);
+    if (c != 0 || status != 0) { ENC_PROF_FLUSH(); return; }
 
     // ---- CRC16 over frame_size-2 bytes (hca.cpp:2961-2962), chunk per lane, then one multiply per lane and an xor across the wave.
     // The message is front-padded with zero bytes to 64*m bytes (leading zeros do not change a zero-init CRC).
@@ -707,6 +750,8 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     // the frame image is big-endian words; whole dwords go out byte-swapped (unaligned dword stores), then the last bytes
     for (uint32_t i = lane; 4 * i + 4 <= F.frame_size; i += 64) { const uint32_t w = __builtin_bswap32(words[i]); __builtin_memcpy(dst + 4 * i, &w, 4); }
     if (lane < (F.frame_size & 3)) { const uint32_t i = (F.frame_size & ~3u) + lane; dst[i] = (uint8_t)(words[i >> 2] >> (24 - 8 * (i & 3))); }
+    ENC_MARK(11);
+    ENC_PROF_FLUSH();
 }
 
 // LDS of one frame: exchange words, frame image, a region per channel
@@ -745,3 +790,15 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
 }
 
 }  // namespace cri
+
+#ifdef CRI_ENC_PROFILE
+extern "C" int cri_debug_enc_profile(unsigned long long* out16, int reset) {
+    static unsigned long long h[1024][16];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(cri::g_enc_prof), sizeof h) != hipSuccess) return -1;
+        for (int k = 0; k < 16; k++) { out16[k] = 0; for (int s = 0; s < 1024; s++) out16[k] += h[s][k]; }
+    }
+    if (reset) { memset(h, 0, sizeof h); if (hipMemcpyToSymbol(HIP_SYMBOL(cri::g_enc_prof), h, sizeof h) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

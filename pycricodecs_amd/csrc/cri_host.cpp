@@ -558,8 +558,13 @@ void hca_pack_header(const HcaEncSetup& e, uint8_t* o) {      // hca.cpp:3109-31
 // and every row of QuantizeSpectrumBits is "shortest code near zero, one bit more from some |q| on" (plus entries of 0 past
 // the row's ends).  (int)(fl(fl(x * inv) + up)) is monotone in x, so the bits of x are
 //   shortest[r] + (x >= t_plus[r]) + (x <= -t_minus[r])
-// for two floats found here by bisection over the float bit patterns with the reference's own expression; the one
-// exception is x = 0.9999999f (ScaleSpectra's clamp): at resolutions 2, 4 and 5 the sum rounds up to the next integer,
+// for two floats found here by bisection over the float bit patterns with the reference's own expression (they differ by a few
+// ulps: the sum rounds differently on the two sides).  The fifteen thresholds of either sign are well apart and in the same order,
+// so "x passes resolution r's threshold" is "at least rank[r] of its sign's thresholds are <= |x|": the kernel computes that count
+// -- the CLASS of x, 0 .. 15 -- once per spectrum (a table row per binade of |x| and sign holds the at most two thresholds inside
+// it), keeps a band's eight classes as eight bytes, and a search step then costs a band
+//   8 * shortest[r] + (number of its bytes with class + (16 - rank[r]) >= 16)            (two adds, two ands, two popcounts).
+// The one exception is x = 0.9999999f (ScaleSpectra's clamp): at resolutions 2, 4 and 5 the sum rounds up to the next integer,
 // the index runs one past the row's codes and the entry there is 0 -- no bits at all.  The kernel counts those values per
 // band once and takes their bits back out ("anomaly").  Everything is derived from the tables and checked: a table of
 // another shape makes this function fail instead of producing wrong bytes.
@@ -579,13 +584,15 @@ int hca_enc_build_tables(std::vector<uint8_t>& blob) {
     float* deq = (float*)(blob.data() + HCA_ET_DEQ);
     float* escale = (float*)(blob.data() + HCA_ET_ESCALE);
     uint32_t* cp = (uint32_t*)(blob.data() + HCA_ET_CP);
+    uint32_t* cls = (uint32_t*)(blob.data() + HCA_ET_CLS);
     float* inv = (float*)(blob.data() + HCA_ET_INV);
     float* ib = (float*)(blob.data() + HCA_ET_IBOUNDS);
     uint8_t* sfbase = blob.data() + HCA_ET_SFBASE;
     uint8_t* clen = blob.data() + HCA_ET_CLEN;
     uint8_t* code = blob.data() + HCA_ET_CODE;
     uint8_t* ishuf = blob.data() + HCA_ET_ISHUF;
-    for (int i = 0; i < 128; i++) { win[i] = HCA_WINDOW[i]; ishuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
+    for (int i = 0; i < 128; i++) { win[i] = HCA_WINDOW[i] * (1.0f / 32768.0f);   // exact: PcmToFloat's scale folded in (hca.cpp:2470-2479)
+         ishuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
     {
         int k = 0;
         const int rows[7] = {7, 5, 4, 3, 2, 1, 0}, count[7] = {64, 32, 16, 8, 4, 2, 1};
@@ -642,14 +649,39 @@ int hca_enc_build_tables(std::vector<uint8_t>& blob) {
             }
         }
     }
+    // ranks: the thresholds of either sign in ascending order are the same sequence of resolutions, strictly ascending
+    uint32_t rank[16]; rank[0] = 0;
+    for (int r = 1; r < 16; r++) {
+        uint32_t below_p = 0, below_m = 0;
+        for (int q = 1; q < 16; q++) {
+            if (q == r) continue;
+            if (tplus[q] == tplus[r] || tminus[q] == tminus[r]) return CRI_ERR_INVALID_ARG;
+            below_p += tplus[q] < tplus[r]; below_m += tminus[q] < tminus[r];
+        }
+        if (below_p != below_m) return CRI_ERR_INVALID_ARG;
+        rank[r] = below_p + 1;
+    }
+    // classes by binade: exponent field 114 + i (everything below 2^-13 is under every threshold: row 0), at most two thresholds each
+    for (int i = 0; i < 13; i++)
+        for (int sign = 0; sign < 2; sign++) {
+            const uint32_t* t = sign ? tminus : tplus;
+            uint32_t in_row[16]; uint32_t n = 0, base = 0;
+            for (int r = 1; r < 16; r++) {
+                const uint32_t e = t[r] >> 23;
+                if (e <= 114 || e > 126) return CRI_ERR_INVALID_ARG;      // row 0 also stands for everything smaller: it must be empty
+                if (e < 114u + (uint32_t)i) base++;
+                else if (e == 114u + (uint32_t)i) in_row[n++] = t[r];
+            }
+            if (n > 2) return CRI_ERR_INVALID_ARG;
+            if (n == 2 && in_row[0] > in_row[1]) { const uint32_t x = in_row[0]; in_row[0] = in_row[1]; in_row[1] = x; }
+            uint32_t* row = cls + 4 * (2 * i + sign);
+            row[0] = n > 0 ? in_row[0] : 0x7F800000u; row[1] = n > 1 ? in_row[1] : 0x7F800000u; row[2] = base; row[3] = 0;
+        }
     for (int i = 0; i < 60; i++) {
         const int r = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0;
-        cp[4 * i + 0] = tplus[r];
-        cp[4 * i + 1] = tminus[r] ^ 0x80000000u;              // -t_minus: the test is x <= -t_minus
-        cp[4 * i + 2] = 8 * shortest[r] | anomaly[r] << 8 | (uint32_t)r << 16;
-        cp[4 * i + 3] = 0;
+        cp[2 * i + 0] = r ? (16 - rank[r]) * 0x01010101u : 0u;
+        cp[2 * i + 1] = 8 * shortest[r] | anomaly[r] << 8 | (uint32_t)r << 16;
     }
-    cp[4 * 59 + 1] = 0xFF800000u;                             // -inf: nothing is <= it
     return 0;
 }
 

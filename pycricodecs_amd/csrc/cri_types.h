@@ -69,18 +69,19 @@ static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels
 #define HCA_QC_TILE(C) (8u * (C) * 4u * HCA_QC_QUARTER)              /* bytes of a tile: 2 KB per frame and channel */
 
 // Encoder tables as k_hca_encode keeps them in LDS: one blob, built on the host (hca_enc_build_tables), byte offsets below
-#define HCA_ET_WIN 0          // float[128]   MDCT window (hca.cpp:2529-2553)
+#define HCA_ET_WIN 0          // float[128]   MDCT window (hca.cpp:2529-2553) times 2^-15
 #define HCA_ET_TW 512         // float2[128]  {cos, sin} twiddles, only the entries the lane mapping reads: row 7 [0,64), row 5 [64,96), 4 [96,112), 3 [112,120), 2 [120,124), 1 [124,126), 0 [126]
 #define HCA_ET_DEQ 1536       // float[72]    scale-factor table padded with NaN
 #define HCA_ET_ESCALE 1824    // float[64]
-#define HCA_ET_CP 2080        // uint4[60]    per curve position {t_plus, -t_minus, 8 * shortest | anomaly << 8 | resolution << 16, 0}; [59] = a band that costs nothing
-#define HCA_ET_INV 3040       // float[16]    quantiser inverse step per resolution
-#define HCA_ET_IBOUNDS 3104   // float[16]
-#define HCA_ET_SFBASE 3168    // uint8[32]
-#define HCA_ET_CLEN 3200      // uint8[128]
-#define HCA_ET_CODE 3328      // uint8[128]
-#define HCA_ET_ISHUF 3456     // uint8[128]
-#define HCA_ET_BYTES 3584
+#define HCA_ET_CP 2080        // uint2[60]    per curve position {(16 - rank) in every byte, 8 * shortest | anomaly << 8 | resolution << 16}; [59] = a band that costs nothing
+#define HCA_ET_CLS 2560       // uint4[13][2] per binade of |x| (exponent field 114 .. 126; below: row 0) and sign: {A, B, classes below, 0}: class = base + (|x| >= A) + (|x| >= B)
+#define HCA_ET_INV 2976       // float[16]    quantiser inverse step per resolution
+#define HCA_ET_IBOUNDS 3040   // float[16]
+#define HCA_ET_SFBASE 3104    // uint8[32]
+#define HCA_ET_CLEN 3136      // uint8[128]
+#define HCA_ET_CODE 3264      // uint8[128]
+#define HCA_ET_ISHUF 3392     // uint8[128]
+#define HCA_ET_BYTES 3520
 #define HCA_ENC_CLAMP_BITS 0x3F7FFFFEu   // ScaleSpectra's clamp 0.9999999f (hca.cpp:2639-2654): the one value the quantiser can push past its table
 
 

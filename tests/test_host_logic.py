@@ -155,34 +155,48 @@ def test_header_walk_mutation_fuzz_vs_oracle(shim):
 
 
 def test_encoder_threshold_tables_equal_the_quantiser_rule(shim):
-    """k_hca_encode's rate loop costs a spectrum as shortest[r] + (x >= t_plus) + (x <= -t_minus) (minus the clamp-value anomaly)
-    instead of quantising it (hca.cpp:2763-2790).  The thresholds come from hca_enc_build_tables; here the rule is held against the
-    reference's own expression -- (int)(x * inv + (inv + 1)) - (int)(inv + 0.5 - 8) into QuantizeSpectrumBits, |x| >= dead zone for
-    resolutions 8..15 -- on every float within 4096 ulps of a threshold, the clamp value and its neighbours, and two million random
-    values per resolution."""
-    ET_CP, ET_INV, ET_CLEN, ET_BYTES = 2080, 3040, 3200, 3584
+    """k_hca_encode's rate loop never quantises (hca.cpp:2763-2790): a spectrum is classed once -- how many of the fifteen
+    resolutions' length thresholds of its sign it reaches, from a table row per binade and sign -- and costs
+    shortest[r] + (class + (16 - rank[r]) >= 16) at resolution r, minus the clamp-value anomaly.  The tables come from
+    hca_enc_build_tables; here the rule is held against the reference's own expression -- (int)(x * inv + (inv + 1)) -
+    (int)(inv + 0.5 - 8) into QuantizeSpectrumBits, |x| >= dead zone for resolutions 8..15 -- on every float within 4096 ulps of
+    a threshold, the clamp value and its neighbours, the smallest magnitudes, and two million random values per resolution."""
+    ET_CP, ET_CLS, ET_INV, ET_CLEN, ET_BYTES = 2080, 2560, 2976, 3136, 3520
     CLAMP = 0x3F7FFFFE
     buf = (C.c_uint8 * 4096)()
     shim.shim_hca_enc_tables.argtypes = [C.c_void_p, C.c_size_t]
     assert shim.shim_hca_enc_tables(buf, 4096) == ET_BYTES
     blob = bytes(buf)[:ET_BYTES]
-    cp = np.frombuffer(blob, dtype=np.uint32, count=240, offset=ET_CP).reshape(60, 4)
+    cp = np.frombuffer(blob, dtype=np.uint32, count=120, offset=ET_CP).reshape(60, 2)
+    cls = np.frombuffer(blob, dtype=np.uint32, count=104, offset=ET_CLS).reshape(13, 2, 4)
     inv_tab = np.frombuffer(blob, dtype=np.float32, count=16, offset=ET_INV)
     clen = np.frombuffer(blob, dtype=np.uint8, count=128, offset=ET_CLEN).reshape(8, 16)
     curve = [15, 14, 14, 14, 14, 14, 14, 13, 13, 13, 13, 13, 13, 12, 12, 12, 12, 12, 12, 11, 11, 11, 11, 11, 11, 10, 10, 10, 10, 10, 10, 10,
              9, 9, 9, 9, 9, 9, 8, 8, 8, 8, 8, 8, 7, 6, 6, 5, 4, 4, 4, 3, 3, 3, 2, 2, 2, 2, 1]
     dead = {8: 0x3D042108, 9: 0x3C820821, 10: 0x3C010204, 11: 0x3B808081, 12: 0x3B004020, 13: 0x3A802008, 14: 0x3A001002, 15: 0x39800801}
+    thresholds = sorted(set(int(t) for t in cls[:, :, 0:2].reshape(-1) if t != 0x7F800000))
+    assert len(thresholds) == 22                                   # fifteen per sign; the eight dead zones serve both signs
+
+    def classes(x):                                                # what the kernel does per spectrum
+        u = x.view(np.uint32)
+        e = np.maximum(((u >> 23) & 0xFF).astype(np.int64) - 114, 0)
+        assert e.max() <= 12
+        row = cls[e, (u >> 31).astype(np.int64)]
+        ax = np.abs(x)
+        return row[:, 2].astype(np.int64) + (ax >= row[:, 0].copy().view(np.float32)) + (ax >= row[:, 1].copy().view(np.float32))
+
     rng = np.random.default_rng(5)
     seen = set()
     for pos in range(59):
         r = curve[pos]
-        assert cp[pos, 2] >> 16 == r
+        assert cp[pos, 1] >> 16 == r
         if r in seen:
             continue
         seen.add(r)
-        tp, ntm = cp[pos, 0:1].view(np.float32)[0], cp[pos, 1:2].view(np.float32)[0]
-        shortest, anomaly = int(cp[pos, 2] & 0xFF) // 8, int(cp[pos, 2] >> 8) & 1
-        mags = [np.arange(max(0, int(t) - 4096), min(CLAMP, int(t) + 4096) + 1, dtype=np.uint32) for t in (cp[pos, 0], cp[pos, 1] & 0x7FFFFFFF)]
+        k = int(cp[pos, 0] & 0xFF)
+        assert cp[pos, 0] == k * 0x01010101 and 1 <= k <= 15
+        shortest, anomaly = int(cp[pos, 1] & 0xFF) // 8, int(cp[pos, 1] >> 8) & 1
+        mags = [np.arange(max(0, t - 4096), min(CLAMP, t + 4096) + 1, dtype=np.uint32) for t in thresholds]
         mags += [np.arange(CLAMP - 64, CLAMP + 1, dtype=np.uint32), np.arange(0, 64, dtype=np.uint32),
                  rng.integers(0, CLAMP + 1, 2_000_000, dtype=np.uint32)]
         mag = np.concatenate(mags)
@@ -194,9 +208,9 @@ def test_encoder_threshold_tables_equal_the_quantiser_rule(shim):
             down = int(float(inv) + 0.5 - 8)
             t = (x * inv).astype(np.float32) + up
             want = clen[r][t.astype(np.int32) - down].astype(np.int64)
-        got = shortest + (x >= tp).astype(np.int64) + (x <= ntm).astype(np.int64)
+        got = shortest + (((classes(x) + k) & 0x10) != 0).astype(np.int64)
         if anomaly:
             got = np.where(x.view(np.uint32) == CLAMP, 0, got)
         assert np.array_equal(got, want), f"resolution {r}"
     assert seen == set(range(1, 16))
-    assert cp[59, 2] == 0 and np.isinf(cp[59, 0:1].view(np.float32)[0])
+    assert cp[59, 0] == 0 and cp[59, 1] == 0
