@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     { uint32_t t = 0; for (uint32_t k = 0; k < 16; k++) t |= (uint32_t)(Fp->type[k] & 3) << (2 * k); F.types = t; }
     uint32_t g = blockIdx.x * a.frames_per_group + fw;
     if (g >= a.frames) g = a.frames - 1;                   // a spare frame slot of the last workgroup repeats the last frame (same bytes, same place)
+    g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);  // (wave-uniform: the stream's fields below belong in scalar registers)
     const uint32_t nwords = (F.frame_size + 3) / 4 + 1;
     uint32_t* wg_vote = (uint32_t*)(smem_all + HCA_ET_BYTES);   // [2] (+ padding to 16 bytes)
     if (tid < 2) wg_vote[tid] = 0;
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     // frame -> stream
     uint32_t lo = a.stream_begin, hi = a.stream_end;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_frame <= g) lo = mid; else hi = mid; }
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const HcaStream st = a.streams[lo];
     const uint32_t f = g - st.first_frame;
     const uint8_t* pcm = (st.src_in_scratch ? a.scratch : a.in) + st.src_offset;
@@ -406,17 +408,23 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         sfr[0] = (int)s0; sfr[1] = (int)s1;
         *(uint16_t*)(sfac + b0) = (uint16_t)(s0 | s1 << 8);
         const float e0 = T.escale[s0], e1 = T.escale[s1];
-        ntop[0] = ntop[1] = 0;
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) {
             float v0 = xr[sf].x * e0, v1 = xr[sf].y * e1;
-            if (v0 > 0.9999999f) v0 = 0.9999999f; else if (v0 < -0.9999999f) v0 = -0.9999999f;
-            if (v1 > 0.9999999f) v1 = 0.9999999f; else if (v1 < -0.9999999f) v1 = -0.9999999f;
+            v0 = __builtin_amdgcn_fmed3f(v0, -0.9999999f, 0.9999999f);   // hca.cpp:2646-2649 (the products are never NaN)
+            v1 = __builtin_amdgcn_fmed3f(v1, -0.9999999f, 0.9999999f);
             if (s0 == 0) v0 = 0;                           // also every band past the coded range
             if (s1 == 0) v1 = 0;
             xr[sf] = f2{v0, v1};
-            ntop[0] += __float_as_uint(v0) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
-            ntop[1] += __float_as_uint(v1) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
+        }
+        // values that sit on the clamp (the quantiser's one irregular input, cri_host.cpp): counted per band, in the rare frame that has any
+        ntop[0] = ntop[1] = 0;
+        if (__builtin_amdgcn_ballot_w64(m0 * e0 >= 0.9999999f || m1 * e1 >= 0.9999999f) != 0) {
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) {
+                ntop[0] += __float_as_uint(xr[sf].x) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
+                ntop[1] += __float_as_uint(xr[sf].y) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
+            }
         }
         // class of every spectrum: how many of the fifteen resolutions' thresholds (of its sign) it reaches
         cl[0][0] = cl[0][1] = cl[1][0] = cl[1][1] = 0;
@@ -511,20 +519,12 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             } else hbtot = 16 + 16 + 16 + hbits_c;
             int low = 0, high = done ? 0 : 255;
             bool over = false;                             // "mid_value > available bits" of the last step (hca.cpp:2806-2815)
-#ifdef ENC_ABL_STEPS
-            for (int step = 0; step < ENC_ABL_STEPS; step++) {
-#else
             for (int step = 0; step < 8; step++) {         // 256 levels: always 8 steps
-#endif
                 const int mid = (low + high) / 2;
                 int bits = done ? 0 : level_bits(mid);
                 if (XCH) {
                     if (lane == 0) X_step[par * 8 + c] = bits;
-#ifdef ENC_ABL_NOBARRIER
-                    wave_lds_sync();
-#else
                     __syncthreads();
-#endif
                     bits = 0;
 #pragma unroll
                     for (uint32_t k = 0; k < C; k++) bits += X_step[par * 8 + k];
@@ -698,11 +698,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) { rowbase[sf] = acc; acc += (uint32_t)__builtin_amdgcn_readlane((int)incl[sf], 63) & 0xFFFF; }
     }
-#ifdef ENC_ABL_NOPUT
-    if (status == 77) {
-#else
     if (status == 0) {
-#endif
         const uint32_t start = (uint32_t)hbtot - 16;       // sync + header + every channel's scalefactor part
 #pragma unroll
         for (int sf = 0; sf < 8; sf++) {
