@@ -679,7 +679,7 @@ def host_path_run(streams, unique, seconds):
     Job planning (header parse of every item) is outside the timed call, as for the device-resident line."""
     import numpy as np
     import oracle_lib as O
-    from pycricodecs_amd.batch import Job, pinned_array, pinned_release
+    from pycricodecs_amd.batch import Job, pinned_array
     from pycricodecs_amd import _capi
     uniq = make_hca_streams(unique, seconds, 0, 1, "tonal")
     items = tile(uniq, streams)
@@ -708,7 +708,7 @@ def host_path_run(streams, unique, seconds):
     pin = pinned_array(job.output_bytes)
     job.blob                                                   # the batch as one host blob (built once)
     t_blob, _ = timed(pin, True)
-    pinned_release(pin)
+    del pin
     res = {"workload": "HCA decode of %d x %.0f s encrypted stereo streams from host memory to host memory" % (streams, seconds),
            "frames_per_s": round(job.units / t_items, 1), "ms": round(t_items * 1e3, 2),
            "form": "the items' own bytes objects (pageable) in, WAVs into a pageable numpy buffer: cri_job_run_host_items",

@@ -13,6 +13,7 @@ except Exception:  # pragma: no cover
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcricodecs_hip.so")
+TESTING_LIB_PATH = os.path.join(HERE, "lib", "libcricodecs_hip_testing.so")   # the same sources + the parity tests' knobs (cri_test_set); never shipped
 
 SYMBOLS = [
     "cri_adx_decode", "cri_adx_encode", "cri_hca_decode", "cri_hca_encode", "cri_hca_crypt", "cri_free", "cri_strerror",
@@ -45,15 +46,56 @@ class AdxEncodeParams(C.Structure):
 
 
 _lib = None
+_product = None
+_testing = None
 
 
 def lib():
-    global _lib
+    """The library every call of this package goes through: the shipped one, unless a test has switched to the testing build."""
+    global _lib, _product
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise OSError("%s not built: run `python -m pycricodecs_amd.build` (hipcc, gfx950)" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    if _product is None:
+        _product = _bind(LIB_PATH)
+    _lib = _product
+    return _lib
+
+
+class testing_knobs:
+    """Context manager for the parity tests: routes the package through libcricodecs_hip_testing.so (the same sources built with
+    -DCRI_TESTING) and sets planner knobs that the shipped library does not expose (cri_capi.cpp, struct Knobs) -- e.g.
+    testing_knobs(adx_mapping="seg", adx_warm_pct=1).  Everything is restored on exit."""
+    ADX_MAPPING = {"auto": 0, "chain": 1, "file": 2, "seg": 3, "lane": 4, "wave": 5}
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        global _lib, _testing
+        if _testing is None:
+            _testing = _bind(TESTING_LIB_PATH)
+            _testing.cri_test_set.argtypes = [C.c_char_p, C.c_longlong]
+        self.prev = _lib
+        _lib = _testing
+        _testing.cri_test_set(None, 0)
+        for k, v in self.knobs.items():
+            if k == "adx_mapping":
+                v = self.ADX_MAPPING[v]
+            rc = _testing.cri_test_set(k.encode(), int(v))
+            assert rc == 0, "unknown knob %r" % k
+        return _testing
+
+    def __exit__(self, *exc):
+        global _lib
+        _testing.cri_test_set(None, 0)
+        _lib = self.prev
+        return False
+
+
+def _bind(path):
+    if not os.path.exists(path):
+        raise OSError("%s not built: run `python -m pycricodecs_amd.build` (hipcc, gfx950)" % path)
+    L = C.CDLL(path)
     u8p, u64p, i32p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)
     vp = C.c_void_p
     L.cri_adx_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(u8p), szp]
@@ -122,7 +164,6 @@ def lib():
     L.cri_job_item_tags.restype = C.POINTER(C.c_uint32)
     L.cri_job_item_sizes.argtypes = [vp]
     L.cri_job_item_sizes.restype = C.POINTER(C.c_uint64)
-    _lib = L
     return L
 
 

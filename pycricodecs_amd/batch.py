@@ -3,6 +3,7 @@
 PyTorch is used only as the owner of device memory and streams; pointers are handed to the C ABI as integers.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -44,33 +45,17 @@ def items_struct(items, offsets=None):
     return st, (ptrs, lens, keep, offs, items)
 
 
-class _Pinned:
-    def __init__(self, nbytes):
-        self.ptr = _capi.lib().cri_pinned_alloc(max(int(nbytes), 1))
-        if not self.ptr:
-            raise MemoryError("cri_pinned_alloc(%d)" % nbytes)
-
-    def __del__(self):
-        try:
-            _capi.lib().cri_pinned_free(self.ptr)
-        except Exception:
-            pass
-
-
 def pinned_array(nbytes):
-    """uint8 numpy array over page-locked host memory (cri_pinned_alloc): PCIe copies to / from it are asynchronous DMA."""
-    owner = _Pinned(nbytes)
-    arr = np.ctypeslib.as_array((C.c_uint8 * max(int(nbytes), 1)).from_address(owner.ptr))
-    arr = arr[:max(int(nbytes), 1)]
-    _PINNED_OWNERS[arr.ctypes.data] = owner
-    return arr
-
-
-_PINNED_OWNERS = {}
-
-
-def pinned_release(arr):
-    _PINNED_OWNERS.pop(arr.ctypes.data, None)
+    """uint8 numpy array over page-locked host memory (cri_pinned_alloc): PCIe copies to / from it are asynchronous DMA.
+    The block lives exactly as long as the array or anything derived from it (slices, memoryviews) does."""
+    n = max(int(nbytes), 1)
+    L = _capi.lib()
+    ptr = L.cri_pinned_alloc(n)
+    if not ptr:
+        raise MemoryError("cri_pinned_alloc(%d)" % n)
+    base = (C.c_uint8 * n).from_address(ptr)                   # numpy keeps this object alive for as long as a view of it exists
+    weakref.finalize(base, L.cri_pinned_free, ptr)
+    return np.ctypeslib.as_array(base)
 
 
 class Job:
@@ -80,7 +65,7 @@ class Job:
     def __init__(self, handle, blob, offsets, items=None):
         self._h = handle
         self._blob, self.items = blob, items
-        L = _capi.lib()
+        L = self._L = _capi.lib()                              # the library that made the handle serves it to the end
         self.n = L.cri_job_items(handle)
         self.kind = KIND_NAMES[L.cri_job_kind(handle)]
         self.input_bytes = L.cri_job_input_bytes(handle)
@@ -101,7 +86,7 @@ class Job:
     def __del__(self):
         try:
             if self._h:
-                _capi.lib().cri_job_destroy(self._h)
+                self._L.cri_job_destroy(self._h)
                 self._h = None
         except Exception:
             pass
@@ -248,7 +233,7 @@ class Job:
     def run(self, d_in, d_out, d_scratch, d_status, stream=None):
         import torch
         st = (stream or torch.cuda.current_stream()).cuda_stream
-        rc = _capi.lib().cri_job_run(self._h, d_in.data_ptr(), d_out.data_ptr(), d_scratch.data_ptr(),
+        rc = self._L.cri_job_run(self._h, d_in.data_ptr(), d_out.data_ptr(), d_scratch.data_ptr(),
                                      d_status.data_ptr() if d_status is not None else None, st)
         if rc:
             _capi.raise_for(rc)
@@ -257,7 +242,7 @@ class Job:
         """Validation run of an HCA decode job: run() plus the samples before the int16 conversion.  Returns
         (float32 tensor, offsets uint64[n+1] in floats): item i = [frame][1024][channels] at offsets[i]."""
         import torch
-        L = _capi.lib()
+        L = self._L
         n = int(L.cri_job_float_count(self._h))
         offs = np.ctypeslib.as_array(L.cri_job_float_offsets(self._h), shape=(self.n + 1,)).copy()
         d_f = torch.zeros(max(n, 1), dtype=torch.float32, device=d_in.device)
@@ -271,7 +256,7 @@ class Job:
     def record_census(self, d_scratch):
         """HCA decode diagnostics after a run: {"frames": n, "narrow": frames whose quantised lines crossed scratch as int8}."""
         import torch
-        L = _capi.lib()
+        L = self._L
         arr = (_capi.HcaGroupInfo * 64)()
         n = L.cri_job_hca_groups(self._h, arr, 64)
         frames = narrow = 0
@@ -286,13 +271,13 @@ class Job:
         return {"frames": frames, "narrow": narrow}
 
     def enable_events(self, on=True):
-        _capi.lib().cri_job_enable_events(self._h, 1 if on else 0)
+        self._L.cri_job_enable_events(self._h, 1 if on else 0)
 
     def event_ms(self):
         """{kernel class name: milliseconds of the last run} (waits for that run)."""
         ms = (C.c_float * 4)()
         names = (C.c_char_p * 4)()
-        n = _capi.lib().cri_job_event_ms(self._h, ms, names, 4)
+        n = self._L.cri_job_event_ms(self._h, ms, names, 4)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
     def run_host(self, out=None, joined=False):
@@ -313,10 +298,10 @@ class Job:
             if getattr(self, "_run_items", None) is None:      # (built once: the items list is this Job's for its lifetime)
                 self._run_items = items_struct(self.items)
             st, keep = self._run_items
-            rc = _capi.lib().cri_job_run_host_items(self._h, C.byref(st), out.ctypes.data, status)
+            rc = self._L.cri_job_run_host_items(self._h, C.byref(st), out.ctypes.data, status)
         else:
             blob = self.blob
-            rc = _capi.lib().cri_job_run_host_into(self._h, blob if blob else b"\0", out.ctypes.data, status)
+            rc = self._L.cri_job_run_host_into(self._h, blob if blob else b"\0", out.ctypes.data, status)
         if rc:
             _capi.raise_for(rc)
         return self.split(memoryview(out)), np.array(status[:self.n], dtype=np.int32)

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include "cri_kernels.h"
 #include "cri_device.h"
+#include "cri_adx_quant.h"
 #include "../../include/cricodecs_hip.h"
 
 #define CRI_TABLE_QUAL static __device__ const
@@ -299,27 +300,19 @@ __global__ __launch_bounds__(64) void k_adx_encode(AdxArgs a) {
                 blk[0] = (uint8_t)(word >> 8) | stale; blk[1] = (uint8_t)word;
                 h1 = o1; h2 = o2;
                 if (!scale) scale = 1;
-                const float rcp = 1.0f / (float)scale, half_rcp = 0.5f * rcp;
-                // delta / scale is clamped to [~limit, limit] right after, so only quotients up to limit + 1 matter: with
-                // |delta| capped at (limit + 2) * scale (exact in fp32 for bitdepths <= 8) floor((n + 0.5) / scale) comes out
-                // of one fma and a truncation -- the 0.5 keeps exact quotients >= 1.2e-4 away from an integer, against an
-                // error below 129 * 2^-22.  (Same shortening of the serial chain as in k_adx_encode_wpf.)
+                // (bitdepths <= 8: the float form of the quantiser, cri_adx_quant.h -- the same shortening of the serial chain as in
+                //  k_adx_encode_wpf)
                 const bool small = limit <= 127;
-                const int32_t hs = (int32_t)(scale >> 1), cap = (limit + 2) * (int32_t)scale, iscale = (int32_t)scale;
+                const AdxQuantSmall quant(scale, limit);
+                const float rcp = quant.rcp;
+                const int32_t hs = (int32_t)(scale >> 1), iscale = (int32_t)scale;
                 uint32_t acc = 0, have = 0, bytepos = 2;
                 for (uint32_t i = 0; i < spb; i++) {                       // pass B (adx.cpp:254-271)
                     const int32_t v = x[(uint64_t)i * C];
                     const int32_t pred = __mul24(c0, h1) + __mul24(c1, h2);
                     int32_t delta = ((int32_t)((uint32_t)v << 12) - pred) >> 12;
-                    if (small) {
-                        const bool neg = delta < 0;
-                        int32_t an = (neg ? -delta : delta) + hs;
-                        an = an < cap ? an : cap;
-                        int32_t q = (int32_t)__builtin_fmaf((float)an, rcp, half_rcp);
-                        const int32_t qmax = neg ? limit + 1 : limit;
-                        q = q < qmax ? q : qmax;
-                        delta = neg ? -q : q;
-                    } else {
+                    if (small) delta = quant(delta);
+                    else {
                         delta = delta > 0 ? delta + hs : delta - hs;
                         // delta /= scale (truncating), exact: float estimate + correction; |delta| < 2^22 here
                         const uint32_t an = (uint32_t)(delta < 0 ? -delta : delta);
@@ -1164,12 +1157,7 @@ __device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t
     } else if (S.mode == 2) word = (S.filter_bits | (scale & 0x1FFF)) & 0xFFFF;
     else word = scale;
     if (!scale) scale = 1;
-    // The quantiser (adx.cpp:256-261): delta +- scale / 2, C division by scale, clamp to [-8, 7] -- sign(d) * floor((|d| + hs) / scale).
-    // In float, symmetric in the sign so that the chain from one sample to the next has no compare / select pair on it:
-    //   code = clamp(trunc(fma(d, 1 / scale, copysign((hs + 0.5) / scale, d))))
-    // exact wherever it matters: for |d| + hs <= 9 * scale the quotient (|d| + hs + 0.5) / scale is at least 0.5 / 4096 = 1.2e-4 away from
-    // an integer and the float error is below 3e-6 (the same bound as k_adx_encode's form); beyond, both sides are past +-8 and clamp alike.
-    const float rcp = 1.0f / (float)scale, adj = ((float)(scale >> 1) + 0.5f) * rcp;
+    const AdxQuantLane quant(scale);                              // the quantiser (adx.cpp:256-261) as one sign-symmetric float step: cri_adx_quant.h
     const int32_t iscale = (int32_t)scale;
     int32_t g1 = h1, g2 = h2;
     int32_t c1g2 = __mul24(c1, g2);
@@ -1180,10 +1168,7 @@ __device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t
         for (int i = 0; i < 8; i++) {                                // pass B (adx.cpp:254-271)
             const int32_t pred = __mul24(c0, g1) + c1g2;
             const int32_t d = ((int32_t)((uint32_t)x[8 * w + i] << 12) - pred) >> 12;
-            const float df = (float)d;
-            const float sadj = __uint_as_float((__float_as_uint(adj) & 0x7FFFFFFFu) | (__float_as_uint(df) & 0x80000000u));
-            int32_t code = (int32_t)__builtin_fmaf(df, rcp, sadj);
-            code = code > 7 ? 7 : (code < -8 ? -8 : code);
+            const int32_t code = quant(d);
             // = ((code * scale << 12) + pred) >> 12: the product has no low bits.  (As v_mad_i32_i24 by hand: knowing code's range the compiler
             //  drops the 24-bit form and takes v_mad_u64_u32, a quarter-rate instruction, onto the chain from one sample to the next.)
             int32_t sim;

@@ -88,6 +88,41 @@ struct Image { uint64_t dst; std::vector<uint8_t> bytes; };
 
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// Tuning knobs.  The shipped library reads three documented environment variables ONCE ("Knobs"):
+//   CRICODECS_ADX_MAPPING = chain | file | seg | lane | wave   which ADX kernels take a job (default: chosen by job shape)
+//   CRICODECS_HOST_SLICE_MIN = bytes                           host-memory jobs moving at least this much are pipelined
+//   CRICODECS_HOST_STAGE_PIECE = bytes                         largest piece of the page-locked staging ring used per copy
+// Everything else here exists for the parity tests, which must be able to push work onto the kernels that normally take little of
+// it (repair passes, general transforms): those fields can only be changed through cri_test_set, and that entry point exists only
+// in the -DCRI_TESTING build of this file (pycricodecs_amd/lib/libcricodecs_hip_testing.so; never in libcricodecs_hip.so).
+enum { ADX_MAP_AUTO = 0, ADX_MAP_CHAIN, ADX_MAP_FILE, ADX_MAP_SEG, ADX_MAP_LANE, ADX_MAP_WAVE };
+struct Knobs {
+    int adx_mapping = ADX_MAP_AUTO;
+    uint64_t host_slice_min = 64ull << 20;       // jobs moving at least this much (in + out) are pipelined
+    uint64_t host_stage_piece = 0;               // 0: the staging slot size
+    // test-only
+    int no_inlane = 0;                           // joint / wide / noise formats on the general transform kernels instead of the in-lane ones
+    uint64_t adx_warm_pct = 100;                 // segmented ADX chains: warm-up length in per cent of the planner's
+    uint64_t adx_seglen = 0;                     // ... least segment length (decode: in warm-ups, default 3; lane encode: per cent of the warm-up, default 50)
+};
+static int adx_mapping_of(const char* e) {
+    if (!e) return ADX_MAP_AUTO;
+    const char* names[] = {"", "chain", "file", "seg", "lane", "wave"};
+    for (int k = 1; k < 6; k++) if (!strcmp(e, names[k])) return k;
+    return ADX_MAP_AUTO;
+}
+static Knobs& knobs_mut() {
+    static Knobs k;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        k.adx_mapping = adx_mapping_of(getenv("CRICODECS_ADX_MAPPING"));
+        if (const char* e = getenv("CRICODECS_HOST_SLICE_MIN")) k.host_slice_min = strtoull(e, nullptr, 10);
+        if (const char* e = getenv("CRICODECS_HOST_STAGE_PIECE")) k.host_stage_piece = strtoull(e, nullptr, 10);
+    });
+    return k;
+}
+static const Knobs& knobs() { return knobs_mut(); }
+
 }  // namespace
 
 struct cri_job {
@@ -157,7 +192,21 @@ struct cri_job {
         class_used[cls]++;
         return nullptr;
     }
-    ~cri_job() { for (auto& v : class_events) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+    // Lifetime: the kernels of a run read the job's metadata, and a destroyed job's metadata allocation is handed to the next job
+    // (MetaPool).  Every cri_job_run leaves an event behind its last kernel; the destructor waits for it before anything is
+    // recycled.  A run that is being CAPTURED into a hipGraph records nothing (a captured event cannot be waited for): a job must
+    // outlive the launches of a graph that holds it (include/cricodecs_hip.h).
+    hipEvent_t last_run = nullptr;
+    void note_run(hipStream_t s) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+        if (!last_run && hipEventCreateWithFlags(&last_run, hipEventDisableTiming) != hipSuccess) { last_run = nullptr; return; }
+        (void)hipEventRecord(last_run, s);
+    }
+    ~cri_job() {
+        if (last_run) { (void)hipEventSynchronize(last_run); (void)hipEventDestroy(last_run); }
+        for (auto& v : class_events) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
 
     int upload_images() {
         std::vector<uint8_t> blob; std::vector<uint64_t> off{0}, dst;
@@ -286,7 +335,16 @@ struct ItemSrc {
         for (uint32_t i = 0; i < it->n; i++) if (!it->ptrs[i] && it->lens[i]) return CRI_ERR_INVALID_ARG;
         return 0;
     }
-    bool ok() const { return offsets && (blob || ptrs || n == 0); }
+    // device offsets never decrease with the item index (the planner's upload ranges and per-item lengths rely on it), and an item
+    // given by pointer + length ends before the next one starts
+    bool ok() const {
+        if (!offsets || !(blob || ptrs || n == 0)) return false;
+        for (uint32_t i = 0; i < n; i++) {
+            if (offsets[i + 1] < offsets[i]) return false;
+            if (lens && lens[i] > offsets[i + 1] - offsets[i]) return false;
+        }
+        return true;
+    }
     const uint8_t* ptr(uint32_t i) const { return ptrs ? ptrs[i] : blob + offsets[i]; }
     size_t len(uint32_t i) const { return (size_t)(lens ? lens[i] : offsets[i + 1] - offsets[i]); }
     uint64_t off(uint32_t i) const { return offsets[i]; }   // device offset of item i
@@ -428,7 +486,9 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
             if (n == 4 && cb + 4 < F.channels && F.type[cb + 3] == CRI_CH_PRIMARY && F.type[cb + 4] == CRI_CH_SECONDARY) n = 3;
             cb += n;
         }
-        if (a.inlane && getenv("CRI_NO_INLANE")) a.inlane = 0;             // (developer switch: the general transform instead)
+        if (a.inlane && knobs().no_inlane) a.inlane = 0;                   // (parity tests: the general transform instead)
+        if (a.channels > 8) { a.inlane = 0; a.narrow = 0; a.wide_waves = 0; }   // the wide forms are built for up to eight channels (two waves of
+                                                                           // four): 9 .. 16 go to k_hca_transform_generic, which reads int16 lines
         if (a.inlane) a.narrow = 1;                                        // (every in-lane instance reads either form, noise fill included)
         if (a.channels == 4 && !a.inlane && !a.plain) a.narrow = 0;         // k_hca_transform<false, 4> reads int16 lines only
         j->hca_dec.push_back(a);
@@ -476,9 +536,9 @@ extern "C" int cri_job_create_hca_decode_items(const cri_items* items, const uin
 // CRICODECS_ADX_MAPPING = "chain" | "file" overrides the choice (tests use it to cover both kernels).
 static bool adx_pick_wave_per_file(bool all_std, size_t n_streams, bool encode) {
     if (!all_std || n_streams == 0) return false;
-    const char* e = getenv("CRICODECS_ADX_MAPPING");
-    if (e && !strcmp(e, "chain")) return false;
-    if (e && !strcmp(e, "file")) return true;
+    const int m = knobs().adx_mapping;
+    if (m == ADX_MAP_CHAIN) return false;
+    if (m == ADX_MAP_FILE) return true;
     return n_streams <= (encode ? 65536u : 12288u);
 }
 
@@ -490,8 +550,8 @@ static bool adx_pick_wave_per_file(bool all_std, size_t n_streams, bool encode) 
 // layout is not the standard one): the unsegmented kernels stay.
 // CRICODECS_ADX_MAPPING = "seg" forces it where it applies, "chain" / "file" pick the unsegmented kernels.
 static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
-    const char* e = getenv("CRICODECS_ADX_MAPPING");
-    if (e && (!strcmp(e, "chain") || !strcmp(e, "file"))) return false;
+    const int m = knobs().adx_mapping;
+    if (m == ADX_MAP_CHAIN || m == ADX_MAP_FILE) return false;
     if (streams.empty()) return false;
     uint64_t chains = 0;
     for (const AdxStream& S : streams) {
@@ -499,8 +559,7 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
         if (encode && S.channels > 2) return false;
         chains += S.channels;
     }
-    const char* we = getenv("CRICODECS_ADX_WARM");               // (developer switch: warm-up length in per cent of the default)
-    const uint64_t warm_pct = we ? strtoull(we, nullptr, 10) : 100;
+    const uint64_t warm_pct = knobs().adx_warm_pct;              // (100 outside the parity tests)
     if (encode) {
         // a WAVE per (file, segment): four waves per SIMD fill the chip (the wave-per-file encoder's rate stops growing there); the
         // encoder merges later than the decoder -- 120 rows on average for tonal material, 500 for sparse, at the standard coefficients
@@ -517,11 +576,10 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
             S.seg_rows = (uint32_t)rows; S.seg_count = (uint32_t)((S.frames + rows - 1) / rows); S.warm_rows = (uint32_t)warm;
             any = true;
         }
-        return any || (e && !strcmp(e, "seg"));
+        return any || m == ADX_MAP_SEG;
     }
     const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains);
-    const char* se = getenv("CRICODECS_ADX_SEGLEN");             // (developer switch: least segment length in warm-ups)
-    const uint64_t seg_mult = se ? std::max<uint64_t>(1, strtoull(se, nullptr, 10)) : 3;
+    const uint64_t seg_mult = knobs().adx_seglen ? knobs().adx_seglen : 3;      // least segment length in warm-ups
     bool any = false;
     for (AdxStream& S : streams) {
         const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;     // (mode 2: the slowest of the four static filters)
@@ -534,7 +592,7 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
         S.seg_rows = (uint32_t)rows; S.seg_count = (uint32_t)((S.frames + rows - 1) / rows); S.warm_rows = (uint32_t)warm;
         any = true;
     }
-    return any || (e && !strcmp(e, "seg"));
+    return any || m == ADX_MAP_SEG;
 }
 
 // LDS plan of the lane-per-chain ADX kernels.  A wave stages, for each of its files, T rows of blocks and of PCM in LDS
@@ -1096,22 +1154,20 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
     // Segmented chains.  Many files: a LANE per (file, channel, segment) -- no warm-up, every segment is encoded twice at its start
     // (k_adx_lane_encode); few files: a WAVE per (file, segment) on the wave-per-file encoder (k_adx_seg_encode).
     // CRICODECS_ADX_MAPPING = "lane" / "wave" forces one of the two where segments apply.
-    const char* map_env = getenv("CRICODECS_ADX_MAPPING");
+    const int map_knob = knobs().adx_mapping;
     // measured (tools/debug/adx_seg_sweep.py): 10 s files -- wave 1.7 / 3.2 / 5.4 / 12.3 ms at 1 / 128 / 256 / 1000 files, lane 3.8 / 4.7 /
     // 4.8 / 5.2 ms; 1 s files -- wave 1.4 / 2.1 / 4.6 ms at 64 / 1000 / 4000 files, lane 3.4 / 3.7 / 3.9 ms (6.0 at 20 000): the lane form
     // has a floor of some 3.5 ms (one segment's rows plus the repair, a row at a time) and takes over from about 8 M blocks
     uint64_t blocks_total = 0;
     for (const AdxStream& S : streams) blocks_total += (uint64_t)S.frames * S.channels;
-    const bool want_lane = all_std && !streams.empty() && !(map_env && (!strcmp(map_env, "chain") || !strcmp(map_env, "file") || !strcmp(map_env, "wave") || !strcmp(map_env, "seg"))) &&
-                           (blocks_total >= 8000000ull || (map_env && !strcmp(map_env, "lane")));
+    const bool want_lane = all_std && !streams.empty() && !(map_knob == ADX_MAP_CHAIN || map_knob == ADX_MAP_FILE || map_knob == ADX_MAP_WAVE || map_knob == ADX_MAP_SEG) &&
+                           (blocks_total >= 8000000ull || map_knob == ADX_MAP_LANE);
     if (want_lane) {
         uint64_t chains_total = 0;
         for (const AdxStream& S : streams) chains_total += S.channels;
-        const char* we = getenv("CRICODECS_ADX_WARM");
-        const uint64_t pct = we ? strtoull(we, nullptr, 10) : 100;
+        const uint64_t pct = knobs().adx_warm_pct;
         const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains_total);
-        const char* se = getenv("CRICODECS_ADX_SEGLEN");
-        const uint64_t seg_pct = se ? std::max<uint64_t>(1, strtoull(se, nullptr, 10)) : 50;      // a segment's least length, in percent of the warm-up
+        const uint64_t seg_pct = knobs().adx_seglen ? knobs().adx_seglen : 50;      // a segment's least length, in percent of the warm-up
         // Two regimes.  Lanes enough at long segments (1024 rows: longer than the encoder's merge time; 1.5 waves per SIMD and more): no
         // warm-up, every segment is encoded from the raw samples before it and repaired where that was wrong -- the least work.  Fewer
         // lanes (1000 files of 10 s): the kernel is bound by the latency of one row after the other in a lane, ~3 us, and a lane's rows are
@@ -1497,6 +1553,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
         }
         default: return CRI_ERR_UNSUPPORTED;
     }
+    j->note_run(s);
     return hipGetLastError() == hipSuccess ? 0 : CRI_ERR_HIP;
 }
 
@@ -1574,7 +1631,6 @@ extern "C" int cri_job_event_ms(cri_job* j, float* ms, const char** names, int m
 // download stream, events ordering the three) -- see run_host_core for what that took.
 namespace {
 const size_t HOST_ARENA_KEEP_MIN = 512ull << 20;             // kept whatever the device: single-file calls
-const uint64_t HOST_SLICE_MIN = 64ull << 20;                   // jobs moving at least this much (in + out) are pipelined
 const uint64_t HOST_SLICE_BYTES = 128ull << 20;                // ... in slices of about this much traffic
 const uint64_t HOST_STAGE_BYTES = 16ull << 20;                 // page-locked staging ring for pageable input: slots of this size
 const uint32_t HOST_STAGE_SLOTS = 4;
@@ -1741,8 +1797,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
     //    page-locked staging slots by this thread (items: 26 GB/s on one core, beside the DMA); a pageable output buffer is locked for
     //    the call as well.
     // 72 ms for the same job (12.9 M frames/s; the download alone is 67).  The tests run both orders.
-    uint64_t slice_min = HOST_SLICE_MIN;
-    if (const char* e = getenv("CRICODECS_HOST_SLICE_MIN")) slice_min = strtoull(e, nullptr, 10);
+    const uint64_t slice_min = knobs().host_slice_min;
     const bool sliced = hca_decode_sliceable(j) && out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
     if (!sliced) {
         if (gaps && !j->items_packed) ok(hipMemsetAsync(d_in, 0, j->in_bytes, A.s_run));
@@ -1769,7 +1824,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         vout.open(out, j->out_bytes);
         if (!pull_src && !A.ensure_stage()) rc = CRI_ERR_HIP;
         uint64_t piece_max = HOST_STAGE_BYTES;                    // (tests cut the pieces small: items then straddle them)
-        if (const char* e = getenv("CRICODECS_HOST_STAGE_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 64 && v < piece_max) piece_max = v; }
+        { const uint64_t v = knobs().host_stage_piece; if (v >= 64 && v < piece_max) piece_max = v; }
         ok(hipMemsetAsync(d_out, 0, j->out_bytes, A.s_run));
         if (d_st) launch_fill_i32(d_st, 0, j->n, A.s_run);
         if (j->n_images)
@@ -1910,8 +1965,14 @@ extern "C" void cri_release_cache(void) {
     int d = -1;
     if (!cri_device_available() || hipGetDevice(&d) != hipSuccess) return;
     HostArena* A = arena_of(d);
-    std::lock_guard<std::mutex> lk(A->mu);
-    A->destroy();
+    {
+        std::lock_guard<std::mutex> lk(A->mu);
+        A->destroy();
+    }
+    MetaCache* c = meta_cache_of(d);                           // recycled metadata allocations of destroyed jobs
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (auto& e : c->free_list) (void)hipFree(e.first);
+    c->free_list.clear();
 }
 
 // ------------------------------------------------------------------------------------------------ single-file entry points
@@ -1993,3 +2054,28 @@ extern "C" int cri_hca_encode(const uint8_t* wav, size_t len, uint32_t force_no_
     if (!j->host_status[0]) { const uint8_t* h = j->images[0].bytes.data(); item = (size_t)be16(h + 6) + (size_t)be32(h + 16) * be16(h + 28); }
     return run_single(j, wav, out, out_len, item);
 }
+
+#ifdef CRI_TESTING
+// TEST BUILD ONLY: the encoder's table blob as the planner uploads it (HCA_ET_BYTES bytes)
+extern "C" int cri_test_enc_tables(uint8_t* out, size_t cap) {
+    std::vector<uint8_t> blob;
+    const int rc = hca_enc_build_tables(blob);
+    if (rc) return rc;
+    if (!out || cap < blob.size()) return CRI_ERR_INVALID_ARG;
+    memcpy(out, blob.data(), blob.size());
+    return (int)blob.size();
+}
+// TEST BUILD ONLY (libcricodecs_hip_testing.so): sets a knob for the jobs created from here on.  Not thread-safe; not part of the C ABI.
+extern "C" int cri_test_set(const char* key, long long value) {
+    Knobs& k = knobs_mut();
+    if (!key) { k = Knobs(); return 0; }                         // reset to the shipped defaults (the environment is not read again)
+    if (!strcmp(key, "adx_mapping")) k.adx_mapping = (int)value;
+    else if (!strcmp(key, "host_slice_min")) k.host_slice_min = (uint64_t)value;
+    else if (!strcmp(key, "host_stage_piece")) k.host_stage_piece = (uint64_t)value;
+    else if (!strcmp(key, "no_inlane")) k.no_inlane = (int)value;
+    else if (!strcmp(key, "adx_warm_pct")) k.adx_warm_pct = (uint64_t)value;
+    else if (!strcmp(key, "adx_seglen")) k.adx_seglen = (uint64_t)value;
+    else return CRI_ERR_INVALID_ARG;
+    return 0;
+}
+#endif

@@ -2125,7 +2125,7 @@ size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
-    const bool in_regs = a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even);
+    const bool in_regs = a.channels <= 8 && (a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even));
     if (in_regs) {
         const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
         const bool flt = a.float_out != nullptr;

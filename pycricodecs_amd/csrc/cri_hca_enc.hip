@@ -25,6 +25,7 @@
 #include <string.h>
 #include "cri_kernels.h"
 #include "cri_device.h"
+#include "cri_hca_enc_cost.h"
 #include "../../include/cricodecs_hip.h"
 
 namespace cri {
@@ -422,8 +423,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         if (__builtin_amdgcn_ballot_w64(m0 * e0 >= 0.9999999f || m1 * e1 >= 0.9999999f) != 0) {
 #pragma unroll
             for (int sf = 0; sf < 8; sf++) {
-                ntop[0] += __float_as_uint(xr[sf].x) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
-                ntop[1] += __float_as_uint(xr[sf].y) == HCA_ENC_CLAMP_BITS ? 1u : 0u;
+                ntop[0] += enc_on_clamp(xr[sf].x); ntop[1] += enc_on_clamp(xr[sf].y);
             }
         }
         // class of every spectrum: how many of the fifteen resolutions' thresholds (of its sign) it reaches
@@ -432,12 +432,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         for (int sf = 0; sf < 8; sf++) {
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-                const float v = b ? xr[sf].y : xr[sf].x;
-                const uint32_t u = __float_as_uint(v);
-                int e = (int)((u >> 23) & 0xFF) - 114;
-                e = e < 0 ? 0 : e;                         // (|v| < 1: at most 12)
-                const uint4 row = T.cls[2 * e + (int)(u >> 31)];
-                const uint32_t k = row.z + (fabsf(v) >= __uint_as_float(row.x) ? 1u : 0u) + (fabsf(v) >= __uint_as_float(row.y) ? 1u : 0u);
+                const uint32_t k = enc_class(T.cls, b ? xr[sf].y : xr[sf].x);
                 cl[b][sf >> 2] |= k << (8 * (sf & 3));
             }
             __builtin_amdgcn_sched_barrier(0);             // (a few rows in flight, not all sixteen: registers)
@@ -489,13 +484,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     // the bits of band b's 8 spectra at one noise level (the inner part of CalculateUsedBits, hca.cpp:2771-2786): 8 times the
     // resolution's shortest code plus the spectra whose class reaches the resolution's rank, less what was counted for values the
     // quantiser pushes past its table (cri_host.cpp)
-    auto band_bits = [&](int noise, int b) -> int {
-        const uint2 t = row_of(noise, b);
-        int n = (int)(t.y & 0xFF);
-        n += __builtin_popcount((cl[b][0] + t.x) & 0x10101010u) + __builtin_popcount((cl[b][1] + t.x) & 0x10101010u);
-        if (any_top) n -= (t.y >> 8) & 1 ? (int)(ntop[b] * (((t.y & 0xFF) >> 3) + 1)) : 0;
-        return n;
-    };
+    auto band_bits = [&](int noise, int b) -> int { return enc_band_cost(row_of(noise, b), cl[b][0], cl[b][1], ntop[b], any_top); };
     // this channel's spectra bits at one noise level for every band (CalculateUsedBits with evaluation boundary 0), wave-uniform
     auto level_bits = [&](int noise) -> int { return wave_sum(band_bits(noise, 0) + band_bits(noise, 1)); };
     int hbits_c = 0, dbits_c = 0;

@@ -81,10 +81,10 @@ def test_adx_vs_oracle(cc, seed, n, ch, sr, bd, bs, mode, ver):
 
 
 @pytest.mark.parametrize("mapping", ["chain", "file"])
-def test_adx_both_mappings(cc, mapping, monkeypatch):
+def test_adx_both_mappings(cc, mapping, knobs):
     """Standard-layout files through the lane-per-chain kernels and through the wave-per-file kernels."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", mapping)
+    knobs(adx_mapping=mapping)
     z = np.zeros((1600, 2), dtype=np.int16)
     z[500:700, 0] = 20000
     wavs = [synth.wav(400 + i, 32 * (3 + 7 * i), 1 + (i % 2), 48000) for i in range(9)] + [synth.wav_bytes(z, 44100)]

@@ -157,9 +157,9 @@ def test_device_floats_random_frames(cc):
 # ------------------------------------------------------------------------------------------------ ADX parameter space
 @pytest.mark.parametrize("hp", [0, 100, 4000, 20000, 65535])
 @pytest.mark.parametrize("mapping", ["chain", "file"])
-def test_adx_highpass_frequencies(cc, hp, mapping, monkeypatch):
+def test_adx_highpass_frequencies(cc, hp, mapping, knobs):
     """Highpass_Frequency != 500 (CalculateCoefficients, adx.cpp:58-64) through encode and decode, both kernel mappings"""
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", mapping)
+    knobs(adx_mapping=mapping)
     for seed, n, ch, sr in ((7, 4800, 2, 48000), (8, 3008, 1, 22050)):
         w = synth.wav(seed, n, ch, sr)
         for mode in (3, 4):
@@ -170,10 +170,10 @@ def test_adx_highpass_frequencies(cc, hp, mapping, monkeypatch):
 
 @pytest.mark.parametrize("filt", [0, 1, 2, 3])
 @pytest.mark.parametrize("mapping", ["chain", "file"])
-def test_adx_static_filters(cc, filt, mapping, monkeypatch):
+def test_adx_static_filters(cc, filt, mapping, knobs):
     """EncodingMode 2 with Filter 0..3 (static coefficient sets, adx.cpp:434, 463-468; the filter rides in the top bits of
     every block's scale word, 247) and the decoder's per-block predictor select"""
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", mapping)
+    knobs(adx_mapping=mapping)
     from pycricodecs_amd.batch import Job
     wavs = [synth.wav(50 + i, 3200 + 640 * i, 1 + i % 2, [48000, 44100, 32000][i % 3]) for i in range(5)]
     for bd, bs in ((4, 18), (8, 18), (6, 26)):
@@ -417,12 +417,12 @@ def test_sfa_pack_adx_shorter_than_one_chunk(cc):
 
 
 @pytest.mark.parametrize("mapping", ["chain", "file"])
-def test_adx_decode_many_lengths_both_mappings(cc, mapping, monkeypatch):
+def test_adx_decode_many_lengths_both_mappings(cc, mapping, knobs):
     """The lane-per-chain planner lays the files out by length (a wave lasts as long as its longest chain) and the wave-per-file
     kernels take them longest first; outputs stay in item order.  A few hundred clips of shuffled lengths, mono and stereo, cross
     wave boundaries in both."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", mapping)
+    knobs(adx_mapping=mapping)
     rng = np.random.default_rng(31)
     uniq = [O.adx_encode(synth.wav(700 + k, 32 * int(rng.integers(1, 60)), 1 + k % 2, 48000)) for k in range(24)]
     pick = rng.integers(0, len(uniq), 300)

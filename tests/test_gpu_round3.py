@@ -155,7 +155,7 @@ def _ragged_hca_batch():
 
 
 @pytest.mark.parametrize("order", ["default", "pipelined", "pipelined-small-pieces", "one-piece"])
-def test_run_host_equals_device_resident_run(cc, monkeypatch, order):
+def test_run_host_equals_device_resident_run(cc, knobs, order):
     """cri_job_run_host_items / _into (host buffers in and out, the arena's private streams) give the bytes and statuses of the
     device-resident cri_job_run, and those are the oracle's -- in one piece and pipelined (CRICODECS_HOST_SLICE_MIN=0: tile slices,
     uploads pulled by k_pull_host from page-locked or staged memory, downloads beside them), from separate items (staged; with
@@ -163,11 +163,11 @@ def test_run_host_equals_device_resident_run(cc, monkeypatch, order):
     a page-locked blob, into pageable and into page-locked memory."""
     import ctypes as C
     from pycricodecs_amd import _capi
-    from pycricodecs_amd.batch import Job, pinned_array, pinned_release
+    from pycricodecs_amd.batch import Job, pinned_array
     if order != "default":
-        monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", str(1 << 62) if order == "one-piece" else "0")
+        knobs(host_slice_min=(1 << 62) if order == "one-piece" else 0)
     if order == "pipelined-small-pieces":
-        monkeypatch.setenv("CRICODECS_HOST_STAGE_PIECE", "1000")
+        knobs(host_stage_piece=1000)
     uniq, items = _ragged_hca_batch()
     job = Job.hca_decode(items, keys=[KEY] * len(items))
     assert job.host_status[17] != 0
@@ -207,17 +207,17 @@ def test_run_host_equals_device_resident_run(cc, monkeypatch, order):
         end = int(o[i]) + len(want[i])
         assert not page_out[end:int(o[i + 1])].any(), i
     del outs
-    pinned_release(buf); pinned_release(pin_in)
+    del buf, pin_in
 
 
 @pytest.mark.parametrize("order", ["pipelined", "pipelined-small-pieces", "one-piece"])
-def test_run_host_items_at_caller_offsets(cc, monkeypatch, order):
+def test_run_host_items_at_caller_offsets(cc, knobs, order):
     """HCA streams placed at caller offsets with gaps between them (the gaps are zero on the device whatever the staging slots
     held before), decoded from the items' own buffers."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", str(1 << 62) if order == "one-piece" else "0")
+    knobs(host_slice_min=(1 << 62) if order == "one-piece" else 0)
     if order == "pipelined-small-pieces":
-        monkeypatch.setenv("CRICODECS_HOST_STAGE_PIECE", "777")
+        knobs(host_stage_piece=777)
     uniq, items = _ragged_hca_batch()
     items = [it for k, it in enumerate(items) if k != 17][:40]
     offs = np.zeros(len(items) + 1, dtype=np.uint64)
@@ -293,14 +293,14 @@ def _adx_files():
 
 
 @pytest.mark.parametrize("warm", ["100", "10", "1"])
-def test_adx_segmented_decode_vs_oracle(cc, monkeypatch, warm):
+def test_adx_segmented_decode_vs_oracle(cc, knobs, warm):
     """k_adx_seg_decode / _fix / _serial: files cut into segments decoded speculatively from a warm-up, verified and repaired.
     With the default warm-up nearly every speculation is right; at 10 % and 1 % of it most are wrong and the repair passes do
     the work -- the bytes are the oracle's either way (modes 2 and 3, 1 / 2 / 4 channels, several coefficient sets, a sample
     count that is not a whole row, full-scale noise)."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "seg")
-    monkeypatch.setenv("CRICODECS_ADX_WARM", warm)
+    knobs(adx_mapping="seg")
+    knobs(adx_warm_pct=int(warm))
     files = _adx_files()
     job = Job.adx_decode(files)
     assert job.dominant_kernel == "k_adx_seg_decode"
@@ -315,13 +315,13 @@ def test_adx_segmented_decode_vs_oracle(cc, monkeypatch, warm):
 
 
 @pytest.mark.parametrize("warm", ["100", "2"])
-def test_adx_segmented_decode_end_markers_and_truncation(cc, monkeypatch, warm):
+def test_adx_segmented_decode_end_markers_and_truncation(cc, knobs, warm):
     """adx.cpp:405-406 inside a segmented file: an end-of-stream scale word on a row's first block (in the first segment, in a
     later one, right at a segment's first row), inputs cut in the middle of a row, a header that announces more blocks than the
     file holds, a sample count below a whole row -- everything after the end decodes to silence, in every later segment."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "seg")
-    monkeypatch.setenv("CRICODECS_ADX_WARM", warm)
+    knobs(adx_mapping="seg")
+    knobs(adx_warm_pct=int(warm))
     base = O.adx_encode(synth.wav(1300, 32 * 1200, 2, 48000))
     mono = O.adx_encode(synth.wav(1301, 32 * 800, 1, 48000))
     do = int.from_bytes(base[2:4], "big") + 4
@@ -385,13 +385,13 @@ def _enc_wavs():
 
 @pytest.mark.parametrize("mode,hp", [(3, 500), (4, 500), (2, 500), (3, 2000)])
 @pytest.mark.parametrize("warm", ["100", "5", "1"])
-def test_adx_segmented_encode_vs_oracle(cc, monkeypatch, warm, mode, hp):
+def test_adx_segmented_encode_vs_oracle(cc, knobs, warm, mode, hp):
     """k_adx_seg_encode: files cut into segments, each encoded by a wave of its own from a warm-up, verified against the previous
     segment's end state and repaired (passes 0 / 1 / 2).  At 5 % and 1 % of the default warm-up nearly every speculation is wrong
     and the repair passes write most of the bytes -- which are the oracle's either way."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "seg")
-    monkeypatch.setenv("CRICODECS_ADX_WARM", warm)
+    knobs(adx_mapping="seg")
+    knobs(adx_warm_pct=int(warm))
     wavs = _enc_wavs()
     job = Job.adx_encode(wavs, mode=mode, highpass=hp)
     assert job.dominant_kernel == "k_adx_seg_encode"
@@ -420,14 +420,14 @@ def test_adx_ten_second_file_encodes_in_segments(cc):
 
 @pytest.mark.parametrize("mode,hp", [(3, 500), (4, 500), (2, 500)])
 @pytest.mark.parametrize("pct", ["100", "20", "3"])
-def test_adx_lane_encode_vs_oracle(cc, monkeypatch, pct, mode, hp):
+def test_adx_lane_encode_vs_oracle(cc, knobs, pct, mode, hp):
     """k_adx_lane_encode / _serial: a lane per (file, channel, segment), every segment encoded from a guessed history and again from
     the previous segment's end until the two histories merge at a checkpoint.  With the default minimum segment length the files of
     this test are one to three segments; at 20 % and 3 % of it they are dozens of segments too short to merge in, so the files are
     flagged and the serial pass rewrites them -- the bytes are the oracle's either way."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "lane")
-    monkeypatch.setenv("CRICODECS_ADX_WARM", pct)
+    knobs(adx_mapping="lane")
+    knobs(adx_warm_pct=int(pct))
     wavs = _enc_wavs() + [synth.wav(1700, 32 * 2600, 2, 48000), synth.wav(1701, 32 * 2100 + 5, 1, 48000)]
     job = Job.adx_encode(wavs, mode=mode, highpass=hp)
     assert job.dominant_kernel == "k_adx_lane_encode"
@@ -441,11 +441,11 @@ def test_adx_lane_encode_vs_oracle(cc, monkeypatch, pct, mode, hp):
         assert bytes(o) == r, i
 
 
-def test_adx_lane_encode_many_files(cc, monkeypatch):
+def test_adx_lane_encode_many_files(cc, knobs):
     """A few hundred clips of shuffled lengths, mono and stereo, 24-bit input among them, in the lane mapping (the planner's own choice
     from about 8 M blocks on), all against the oracle."""
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_ADX_MAPPING", "lane")
+    knobs(adx_mapping="lane")
     rng = np.random.default_rng(99)
     uniq = [synth.wav(1800 + k, 32 * int(rng.integers(1, 1500)) + int(rng.integers(0, 32)), 1 + k % 2, 48000) for k in range(20)]
     uniq.append(synth.wav_typed(1830, 32 * 700, 2, 48000, "s24"))
@@ -509,7 +509,7 @@ def test_wide_plain_layouts_trims_and_alignments(cc, ch):
 # ------------------------------------------------------------------------------------------------ the general transform kernel stays covered
 @pytest.mark.parametrize("ch,q,v3", [(1, 2, False), (2, 2, False), (2, 4, False), (4, 2, False), (4, 3, False), (6, 2, False), (8, 3, False), (3, 2, False), (5, 2, False), (7, 3, False),
                                       (2, 1, True), (2, 2, True), (1, 1, True), (4, 1, True), (3, 1, True), (5, 1, True)])
-def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, monkeypatch, ch, q, v3):
+def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, knobs, ch, q, v3):
     """Joint-stereo / HFR / noise-fill formats of 1, 2, 4 (and, without noise fill, 6 and 8) channels run on k_hca_transform_plain's
     joint, wide and noise instances; k_hca_transform<false, C> and k_hca_transform_generic -- what noise fill on 3 and 5 to 8
     channels still uses -- are forced onto the same streams here (CRI_NO_INLANE, read when the job is created): floats and PCM equal to the oracle's,
@@ -517,7 +517,7 @@ def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, monkeyp
     import hca_forge
     import torch
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRI_NO_INLANE", "1")
+    knobs(no_inlane=1)
     items = []
     for seed, n in ((50, 5000), (51, 9000), (52, 1024)):
         h = O.hca_encode(synth.wav(seed + ch, n, ch, 48000), q)
@@ -544,13 +544,13 @@ def test_general_transform_kernel_on_formats_the_inlane_kernel_takes(cc, monkeyp
     assert good >= 2
 
 
-def test_run_host_from_two_threads_at_once(cc, monkeypatch):
+def test_run_host_from_two_threads_at_once(cc, knobs):
     """Two threads in the pipelined host path at the same time (one works on the device's arena, the other on buffers, streams
     and staging slots of its own for the call), both from the same items and into their own buffers, several times over."""
     import threading
     from pycricodecs_amd.batch import Job
-    monkeypatch.setenv("CRICODECS_HOST_SLICE_MIN", "0")
-    monkeypatch.setenv("CRICODECS_HOST_STAGE_PIECE", "4096")
+    knobs(host_slice_min=0)
+    knobs(host_stage_piece=4096)
     uniq, items = _ragged_hca_batch()
     items = [it for k, it in enumerate(items) if k != 17]
     refs = {id(u): O.hca_decode(u, KEY) for u in uniq}

@@ -1,0 +1,271 @@
+"""GPU parity, round-4 additions (through the C ABI, against the pinned oracle): exhaustive checks of the float shortcuts inside the
+encoders (the ADX quantisers, the HCA encoder's band-cost rule) run on the device over their whole domains, a seeded differential
+fuzz of the segmented ADX kernels, the hipGraph capture the header promises, decode layouts of 9 .. 16 channels, job lifetime."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+from pycricodecs_amd import synth
+
+pytestmark = pytest.mark.gpu
+KEY = G.KEY
+
+
+@pytest.fixture(scope="module")
+def cc():
+    from pycricodecs_amd import CriCodecs, _capi
+    assert _capi.lib().cri_device_available() == 1, "no HIP device: the GPU tests must run on the HIP path"
+    return CriCodecs
+
+
+def run_job(job, stream=None):
+    import torch
+    bufs = job.alloc("cuda:0")
+    job.run(*bufs, stream=stream)
+    torch.cuda.synchronize()
+    blob = bytes(bufs[1].cpu().numpy())
+    status = bufs[3].cpu().numpy()[:job.n]
+    return job.split(blob), status
+
+
+# ------------------------------------------------------------------------------------------------ a5: the float quantisers, every case
+@pytest.mark.parametrize("form,bitdepth", [(0, b) for b in range(2, 9)] + [(1, 4)], ids=lambda v: str(v))
+def test_adx_float_quantisers_exhaustive(cc, form, bitdepth):
+    """The ADX encoders quantise in float (csrc/cri_adx_quant.h: AdxQuantSmall in k_adx_encode for bit depths <= 8, AdxQuantLane in
+    k_adx_lane_encode) where the reference divides integers (adx.cpp:256-261).  The comments argue an error bound; here the same
+    device functions are held against the integer rule for EVERY delta in [-2^18, 2^18) -- more than ((sample << 12) - prediction)
+    >> 12 can reach -- times every scale a block can carry (1 .. 4096, and mode 4's 8192): 2.1 G cases per bit depth."""
+    from pycricodecs_amd import _capi
+    with _capi.testing_knobs() as L:
+        L.cri_test_adx_quantisers.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int32)]
+        cases, bad, first = C.c_ulonglong(), C.c_ulonglong(), (C.c_int32 * 4)()
+        assert L.cri_test_adx_quantisers(form, bitdepth, -(1 << 18), (1 << 18) - 1, C.byref(cases), C.byref(bad), first) == 0
+        assert cases.value == 4097 * (1 << 19)
+        assert bad.value == 0, "delta %d scale %d: got %d, the reference's rule gives %d" % tuple(first)
+
+
+# ------------------------------------------------------------------------------------------------ a32: the encoder's band cost, every float
+def test_hca_encoder_band_cost_rule_on_the_device(cc):
+    """k_hca_encode never quantises in its rate loop: a spectrum is classed once and a band costs 8 * shortest + (classes that reach
+    the resolution's rank) - (the clamp-value anomaly) (csrc/cri_hca_enc_cost.h).  The same device functions against
+    CalculateUsedBits' inner loop (hca.cpp:2771-2786) at all fifteen resolutions: every magnitude 0 .. 0.9999999f (ScaleSpectra's
+    clamp) of both signs, in bands of eight consecutive bit patterns -- 1.07 G floats x 2 signs, nothing sampled."""
+    from pycricodecs_amd import _capi
+    with _capi.testing_knobs() as L:
+        tab = (C.c_uint8 * 4096)()
+        L.cri_test_enc_tables.argtypes = [C.c_void_p, C.c_size_t]
+        assert L.cri_test_enc_tables(tab, 4096) > 0
+        L.cri_test_enc_band_cost.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint32)]
+        cases, bad, first = C.c_ulonglong(), C.c_ulonglong(), (C.c_uint32 * 4)()
+        clamp = 0x3F7FFFFE
+        total = 0
+        chunk = 1 << 24                                              # bands per launch
+        bands = (clamp + 8) // 8
+        for b0 in range(0, bands, chunk):
+            n = min(chunk, bands - b0)
+            assert L.cri_test_enc_band_cost(tab, 8 * b0, 1, n, C.byref(cases), C.byref(bad), first) == 0
+            assert bad.value == 0, "first spectrum %08x, resolution %d: %d bits, the reference's rule gives %d" % tuple(first)
+            total += cases.value
+        assert total == bands * 2 * 15
+
+
+# ------------------------------------------------------------------------------------------------ a3 / a5: differential fuzz of the segmented ADX kernels
+def _material(rng, n, ch):
+    """(n, ch) int16 of a randomly chosen family: tonal + noise floor, full-scale noise, pure tones (limit cycles), digital silence
+    with bursts (game-SFX shape), square waves, a constant."""
+    kind = int(rng.integers(0, 6))
+    t = np.arange(n)[:, None]
+    if kind == 0:
+        x = sum(rng.uniform(500, 9000) * np.sin(2 * np.pi * rng.uniform(50, 12000) / 48000 * t + c) for c in range(3)) + rng.normal(0, rng.uniform(1, 300), (n, ch))
+    elif kind == 1:
+        x = rng.integers(-32768, 32768, (n, ch)).astype(np.float64)
+    elif kind == 2:
+        x = rng.uniform(1000, 32000) * np.sin(2 * np.pi * rng.uniform(100, 8000) / 48000 * t + np.arange(ch)[None, :])
+    elif kind == 3:
+        x = np.zeros((n, ch))
+        for _ in range(int(rng.integers(1, 5))):
+            a = int(rng.integers(0, max(1, n - 1))); b = min(n, a + int(rng.integers(16, 4000)))
+            x[a:b] = rng.normal(0, rng.uniform(50, 9000), (b - a, ch))
+    elif kind == 4:
+        x = rng.uniform(2000, 30000) * np.sign(np.sin(2 * np.pi * rng.uniform(30, 3000) / 48000 * t + 0.1))
+        x = np.repeat(x, ch, axis=1) if x.shape[1] == 1 else x
+    else:
+        x = np.full((n, ch), float(rng.integers(-3000, 3000)))
+    x = np.asarray(x, dtype=np.float64) * np.ones((1, ch))
+    m = min(512, n)
+    x[:m] *= ((np.arange(m) / 512.0) ** 2)[:, None]                       # (a first scale word >= 0x100 is rejected by the reference's own decoder)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("batch", range(16))
+def test_adx_segmented_kernels_differential_fuzz(cc, knobs, batch):
+    """2048 decode cases and 2048 encode cases in 16 seeded batches (tools/debug/adx_lane_cases.py's shapes, promoted): every batch
+    draws a mapping (segmented decode; wave-per-segment or lane-per-segment encode), a warm-up of 100 / 30 / 5 / 1 % and a least
+    segment length, then 128 files of random length (1 .. 2500 rows), channel count, mode 2 / 3 / 4, high-pass 0 .. 65535 and
+    material (tonal, full-scale noise, pure tones, silence with bursts, squares, DC); a quarter of the decode inputs carry an
+    `80 01` end marker at a random row or are cut short.  Every output byte is the oracle's."""
+    from pycricodecs_amd.batch import Job
+    rng = np.random.default_rng(9000 + batch)
+    warm = [100, 30, 5, 1][batch % 4]
+    # ---- encode
+    mode = [3, 3, 2, 4][(batch // 4) % 4]
+    hp = int([500, 0, 65535, int(rng.integers(1, 20000))][batch % 4]) if mode != 2 else 500
+    enc_map = "lane" if batch % 2 else "seg"
+    knobs(adx_mapping=enc_map, adx_warm_pct=warm, adx_seglen=[0, 10, 3, 1][(batch // 2) % 4] if enc_map == "lane" else 0)
+    wavs = []
+    for k in range(128):
+        rows = int(np.exp(rng.uniform(0, np.log(2500))))
+        ch = int(rng.integers(1, 3))
+        n = 32 * rows - int(rng.integers(0, 32)) * int(rng.integers(0, 2))
+        wavs.append(synth.wav_bytes(_material(rng, max(n, 1), ch), int(rng.choice([48000, 44100, 22050]))))
+    job = Job.adx_encode(wavs, mode=mode, highpass=hp)
+    outs, st = run_job(job)
+    refs = [O.adx_encode(w, 4, 18, mode, hp, 0, 4) for w in wavs]
+    assert not st.any() and not job.host_status.any()
+    for i, (o, r) in enumerate(zip(outs, refs)):
+        assert bytes(o) == r, ("encode", batch, i, job.dominant_kernel)
+    # ---- decode (of those files, some damaged; modes 2 / 3 segment, mode 4 takes the unsegmented kernels)
+    knobs(adx_mapping="seg", adx_warm_pct=warm, adx_seglen=[0, 1, 2, 5][(batch // 2) % 4])
+    files = []
+    for k, r in enumerate(refs):
+        b = bytearray(r)
+        do = int.from_bytes(b[2:4], "big") + 4
+        ch = b[7]
+        rows = (len(b) - do) // (18 * ch)
+        what = int(rng.integers(0, 8))
+        if what == 0 and rows > 1:                                   # end marker on a row's first block
+            row = int(rng.integers(0, rows))
+            b[do + row * 18 * ch:do + row * 18 * ch + 2] = b"\x80\x01"
+        elif what == 1 and rows > 1:                                 # cut inside a row
+            b = b[:do + int(rng.integers(1, rows * 18 * ch))]
+        files.append(bytes(b))
+    job = Job.adx_decode(files)
+    outs, st = run_job(job)
+    for i, f in enumerate(files):
+        try:
+            want = O.adx_decode(f)
+        except O.OracleError as e:
+            assert job.host_status[i] == e.code or st[i] == e.code, ("decode status", batch, i)
+            continue
+        assert not job.host_status[i] and not st[i], ("decode", batch, i)
+        assert bytes(outs[i]) == want, ("decode", batch, i, job.dominant_kernel)
+
+
+# ------------------------------------------------------------------------------------------------ b: cri_job_run inside a hipGraph
+@pytest.mark.parametrize("kind", ["hca_decode", "hca_encode", "adx_decode", "adx_encode", "hca_crypt"])
+def test_job_run_captured_in_a_hip_graph(cc, kind):
+    """include/cricodecs_hip.h: "cri_job_run only enqueues kernels on the caller's stream and can be captured in a hipGraph".  One
+    capture, three replays over zeroed output buffers, every replay's bytes are the oracle's (small banks are launch-bound: this is
+    how a caller amortises the launches)."""
+    import torch
+    from pycricodecs_amd.batch import Job
+    wavs = [synth.wav(4100 + k, 32 * (40 + 300 * k), 1 + k % 2, 48000) for k in range(6)]
+    if kind == "hca_decode":
+        items = [O.hca_crypt(O.hca_encode(w, 1 + k % 3), 1, 56, KEY) for k, w in enumerate(wavs)]
+        job, refs = Job.hca_decode(items, keys=[KEY] * len(items)), [O.hca_decode(h, KEY) for h in items]
+    elif kind == "hca_encode":
+        job, refs = Job.hca_encode(wavs, quality=2), [O.hca_encode(w, 2) for w in wavs]
+    elif kind == "adx_decode":
+        items = [O.adx_encode(w) for w in wavs]
+        job, refs = Job.adx_decode(items), [O.adx_decode(a) for a in items]
+    elif kind == "adx_encode":
+        job, refs = Job.adx_encode(wavs), [O.adx_encode(w) for w in wavs]
+    else:
+        items = [O.hca_encode(w, 1) for w in wavs]
+        job, refs = Job.hca_crypt(items, True, 56, keys=[KEY] * len(items)), [O.hca_crypt(h, 1, 56, KEY) for h in items]
+    bufs = job.alloc("cuda:0")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        job.run(*bufs)                                             # (uncaptured once: modules loaded, arena-free path)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        job.run(*bufs)
+    for _ in range(3):
+        bufs[1].zero_(); bufs[3].fill_(-1)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(bufs[3][:job.n].abs().sum().item()) == 0
+        outs = job.split(bytes(bufs[1].cpu().numpy()))
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            assert bytes(o) == r, (kind, i)
+    del g
+
+
+# ------------------------------------------------------------------------------------------------ a10 / a23: 9 .. 16 channels
+@pytest.mark.parametrize("ch", [9, 12, 16])
+def test_hca_decode_of_nine_to_sixteen_channels(cc, ch):
+    """clHCA_DecodeHeader takes up to 16 channels (hca.cpp:662-687) and the reference decodes them; the wide forms of the in-lane
+    transform are built for eight (two waves of four), so 9 .. 16 go to k_hca_transform_generic.  Forged streams (an 8-channel
+    header re-written to `ch` channels with a frame size that fits them, seeded sparse random frames the oracle accepts), plain
+    and with joint-stereo bands, v2.0 and v3.0: PCM equal to the oracle's."""
+    import hca_forge
+    from pycricodecs_amd.batch import Job
+    base = O.hca_encode(synth.wav(77, 1024 * 12, 8, 48000), 1)
+
+    def takes(stream):
+        try:
+            O.hca_decode(stream)
+            return True
+        except O.OracleError:
+            return False
+    items = []
+    for k, (stereo, v3) in enumerate([(0, False), (8, False), (0, True)]):
+        b = bytearray(hca_forge.forge_header(base, frame_size=4000))
+        assert bytes(x & 0x7F for x in b[8:12]) == b"fmt\0"
+        b[0x0C] = ch
+        hca_forge.fix_header_crc(b)
+        h = bytes(b)
+        hs = int.from_bytes(h[6:8], "big")
+        h = h[:hs] + bytes(4000 * int.from_bytes(h[0x10:0x14], "big"))
+        bb = h[0x23]
+        h = hca_forge.forge_comp(h, track_count=1, channel_config=0, total=bb, base=bb - stereo, stereo=stereo, hfr=0)
+        if v3:
+            h = hca_forge.forge_v3(h, 0)
+        f = hca_forge.accepted_random_stream(h, 500 + 10 * ch + k, 0.04, takes)
+        assert f is not None, (ch, k)
+        items.append(f)
+    job = Job.hca_decode(items)
+    assert job.dominant_kernel.startswith("k_hca")
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, h) in enumerate(zip(outs, items)):
+        assert bytes(o) == O.hca_decode(h), (ch, i)
+
+
+# ------------------------------------------------------------------------------------------------ b: a job may die while its kernels run
+def test_job_destroyed_with_work_in_flight(cc):
+    """cri_job_destroy waits for the job's last enqueued run before its metadata allocation is recycled into the next job
+    (ADVICE r3): a job is run on a side stream and dropped at once, a second job of the same size is planned and run right
+    behind it; both outputs are the oracle's."""
+    import gc
+    import torch
+    from pycricodecs_amd.batch import Job
+    a_items = [O.hca_crypt(O.hca_encode(synth.wav(4300 + k, 48000 * 2, 2, 48000), 1), 1, 56, KEY) for k in range(4)] * 60
+    b_items = [O.hca_encode(synth.wav(4400 + k, 48000 * 2, 1, 48000), 3) for k in range(4)] * 60
+    a_refs = [O.hca_decode(h, KEY) for h in a_items[:4]]
+    b_refs = [O.hca_decode(h) for h in b_items[:4]]
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        ja = Job.hca_decode(a_items, keys=[KEY] * len(a_items))
+        bufs_a = ja.alloc("cuda:0")
+        offs_a = ja.output_offsets.copy()
+        torch.cuda.synchronize()
+        ja.run(*bufs_a, stream=side)
+        del ja
+        gc.collect()                                               # (the handle is destroyed here, kernels possibly still running)
+        jb = Job.hca_decode(b_items)
+        outs_b, st_b = run_job(jb)
+        torch.cuda.synchronize()
+        assert not st_b.any()
+        for i in range(len(b_items)):
+            assert bytes(outs_b[i]) == b_refs[i % 4], i
+        assert int(bufs_a[3].abs().sum().item()) == 0
+        blob = bytes(bufs_a[1].cpu().numpy())
+        for i in range(len(a_items)):
+            o = int(offs_a[i])
+            assert blob[o:o + len(a_refs[i % 4])] == a_refs[i % 4], i
