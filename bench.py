@@ -62,7 +62,10 @@ def family_pcm(seed, n, ch, sr, family):
               bits, resolutions 12..15 (up to 12-bit symbols) -> int16 frame records.  What clean tonal material does.
       noise   full-scale material (white noise, +-full-scale square noise, clicks on a noise floor, loud tones in noise):
               every band is loud, the noise level is high, resolutions are low -> int8 records, maximal symbol count.
-      mixed   tonal and sparse alternating by seed (tiles hold both record forms)."""
+      mixed   tonal and sparse alternating by seed (tiles hold both record forms).
+      sfx     game-SFX shape: the tonal family with 0.05-0.5 s of DIGITAL silence (exact zeros, no noise floor) before and after the
+              sound -- at most a third of the clip each.  Through the zeros an ADX decoder's state sits at a history-dependent fixed
+              point, which is what the segmented ADX kernels' silent-run repair is for."""
     import numpy as np
     from pycricodecs_amd import synth
     if family == "mixed":
@@ -70,6 +73,14 @@ def family_pcm(seed, n, ch, sr, family):
         seed //= 2
     if family == "tonal":
         return synth.pcm16(seed, n, ch, sr)
+    if family == "sfx":
+        rng = np.random.default_rng(20_000 + seed)
+        head = min(int(rng.uniform(0.05, 0.5) * sr), n // 3)
+        tail = min(int(rng.uniform(0.05, 0.5) * sr), n // 3)
+        x = np.zeros((n, ch), dtype=np.int16)
+        if n - head - tail > 0:
+            x[head:n - tail] = synth.pcm16(seed, n - head - tail, ch, sr)      # (its own fade-in: the sound starts softly, as the family does)
+        return x
     rng = np.random.default_rng(10_000 + seed)
     kind = seed % 4
     t = np.arange(n)[:, None] / sr
@@ -744,7 +755,7 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="items per GPU (default: 10000; adx_roundtrip 1000)")
     ap.add_argument("--unique", type=int, default=None, help="distinct inputs tiled to --streams (default 64; hca_encode 16)")
     ap.add_argument("--seconds", type=float, default=None, help="seconds per item (default 10; hca_encode 30)")
-    ap.add_argument("--data", default="tonal", choices=["tonal", "sparse", "noise", "mixed"], help="signal family of the synthetic inputs (see family_pcm)")
+    ap.add_argument("--data", default="tonal", choices=["tonal", "sparse", "noise", "mixed", "sfx"], help="signal family of the synthetic inputs (see family_pcm)")
     ap.add_argument("--quality", type=int, default=1, help="HCA quality: 1 = High (the headline), 2 Middle (intensity stereo), 3 Low (HFR), 4 Lowest")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --streams (--awb-clips) items PER GPU; strong: that many in total, dealt out to the ranks (BASELINE configs[3] / [4]: a fixed batch, file-sharded 1 -> 8)")
@@ -826,7 +837,7 @@ def main():
                ms_per_step=round(dt * 1e3, 3), dtype=dtype,
                data="synthetic, %s family (%s); %d unique inputs tiled to %d, each copy in its own HBM" % (
                    args.data, {"tonal": "seeded sines + noise floor", "sparse": "pure / sparse tones and low-passed noise", "noise": "full-scale noise / square / clicks / loud tones in noise",
-                               "mixed": "tonal and sparse alternating"}[args.data], unique, streams),
+                               "mixed": "tonal and sparse alternating", "sfx": "tonal with 0.05-0.5 s of digital silence before and after"}[args.data], unique, streams),
                config=cfg, roofline=roof)
     # other rows of the same hot path and the host-core baseline: single-GPU run only (ranks of a scaling run must not wait)
     if D.rank == 0 and D.world == 1 and wl == "hca_decode" and not args.no_secondary:

@@ -925,6 +925,37 @@ __device__ __forceinline__ bool seg_row_ends(const SegLane& X, uint32_t row) {
     return row >= X.S.rows_avail || ld_be16(X.src + (uint64_t)row * X.rowb) == 0x8001u;
 }
 
+// ---- digital silence.  A block of zeros (scale word 0, codes 0: what the encoder writes for silent input, adx.cpp:231-234) makes the
+// decoder run its predictor on its own output: the state decays to a fixed point or a small limit cycle of the floor arithmetic that
+// depends on where it came from (-100, -100 maps to -100 for the standard coefficients) -- two decodes from different histories never
+// merge in there, so a speculative segment inside a silent stretch is wrong until the sound comes back.  But nothing has to be
+// decoded to know a silent stretch's end state: it is n steps of  v = (c0 * h1 >> 12) + (c1 * h2 >> 12)  from the state the stretch
+// began with, and those are walked with cycle detection (Brent: at most the transient plus two periods -- a few hundred steps).
+// k_adx_seg_decode marks the segments that are silent from their first row to their last (record word 3); k_adx_seg_fix then gives
+// every segment behind a RUN of silent ones its exact start state in one round, from the last segment with sound before the run.
+#define SEG_NO_STOP 0xFFFFFFFFu
+#define SEG_SILENT 0xFFFFFFFEu          // record word 3: no end-of-stream row, every block of the segment is zeros
+__device__ __forceinline__ uint32_t seg_stop_of(uint32_t w3) { return w3 >= SEG_SILENT ? SEG_NO_STOP : w3; }
+__device__ __forceinline__ int32_t seg_idle_step(int32_t c0, int32_t c1, int32_t h1, int32_t h2) {
+    return clamp_sym((__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12), 0x7FFF);      // seg_block with code 0
+}
+__device__ __forceinline__ uint32_t seg_idle_advance(int32_t c0, int32_t c1, uint32_t state, uint64_t n) {
+    int32_t h1, h2;
+    seg_unpack(state, h1, h2);
+    uint32_t tortoise = state, power = 1, lam = 0;
+    bool looking = true;
+    for (uint64_t step = 0; step < n;) {
+        const int32_t v = seg_idle_step(c0, c1, h1, h2);
+        h2 = h1; h1 = v; step++;
+        if (!looking) continue;
+        lam++;
+        const uint32_t cur = seg_pack(h1, h2);
+        if (cur == tortoise) { n = step + (n - step) % lam; looking = false; }     // on the cycle: only the remainder is left to walk
+        else if (lam == power) { tortoise = cur; power <<= 1; lam = 0; }
+    }
+    return seg_pack(h1, h2);
+}
+
 __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
     const uint32_t lane = threadIdx.x, g = blockIdx.x * 64 + lane;
     SegLane X;
@@ -933,8 +964,8 @@ __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
     const uint32_t n = X.valid ? X.r1 - X.w0 : 0, chain = S.first_chain + X.ch;
     int32_t h1 = 0, h2 = 0;
     if (X.valid && X.k == 0) { h1 = a.history[2 * chain]; h2 = a.history[2 * chain + 1]; }
-    uint32_t spec = seg_pack(h1, h2), stop_row = 0xFFFFFFFFu;
-    bool stopped = false;
+    uint32_t spec = seg_pack(h1, h2), stop_row = SEG_NO_STOP;
+    bool stopped = false, all_zero = true;
     uint32_t nmax = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
@@ -958,6 +989,7 @@ __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
         if (act) {
             if (row == X.r0) spec = seg_pack(h1, h2);
             if (!stopped && cends) { stopped = true; stop_row = row > X.r0 ? row : X.r0; }
+            if (row >= X.r0) all_zero = all_zero && !stopped && cword == 0 && (ccw.x | ccw.y | ccw.z | ccw.w) == 0;
             int32_t s[32];
             if (!stopped) {
                 int32_t scale, c0, c1;
@@ -973,17 +1005,28 @@ __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
     if (X.valid) {
         uint32_t* rec = a.seg_state + 4 * (uint64_t)g;
         const uint32_t e = seg_pack(h1, h2);
-        rec[0] = spec; rec[1] = e; rec[2] = e; rec[3] = stop_row;
-        if (stop_row != 0xFFFFFFFFu) atomicOr(&a.seg_flags[chain], 1u);
+        rec[0] = spec; rec[1] = e; rec[2] = e; rec[3] = stop_row != SEG_NO_STOP ? stop_row : (all_zero ? SEG_SILENT : SEG_NO_STOP);
+        if (stop_row != SEG_NO_STOP) atomicOr(&a.seg_flags[chain], 1u);
     }
 }
 
 // Decodes rows [r0, r_end) of a segment again from (h1, h2), storing them, until the state after a row equals what is stored
 // there (`true`: from that row on the stored samples are this trajectory's already).  Whole rows only can be compared.
-__device__ __forceinline__ bool seg_repair(const SegLane& X, uint32_t r_end, int32_t& h1, int32_t& h2) {
+__device__ __forceinline__ bool seg_repair(const SegLane& X, uint32_t r_end, int32_t& h1, int32_t& h2, bool silent = false) {
     const AdxStream& S = X.S;
     const int16_t* q = (const int16_t*)X.dst;
     for (uint32_t row = X.r0; row < r_end; row++) {
+        if (silent && h1 == h2) {                                    // a silent segment at a fixed point of the recurrence: the rest is that constant
+            int32_t sc, c0, c1;
+            seg_scale(S, 0, sc, c0, c1);
+            if (seg_idle_step(c0, c1, h1, h2) == h1) {
+                int32_t s[32];
+#pragma unroll
+                for (int i = 0; i < 32; i++) s[i] = h1;
+                for (; row < r_end; row++) seg_store_row(X, row, s, false);
+                return false;
+            }
+        }
         const uint8_t* p = X.src + (uint64_t)row * X.rowb + X.ch * 18;
         uint4 cw; __builtin_memcpy(&cw, p + 2, 16);
         int32_t scale, c0, c1;
@@ -1015,12 +1058,26 @@ __global__ __launch_bounds__(64) void k_adx_seg_fix(AdxArgs a, uint32_t round, u
     const uint32_t src = 1 + (round & 1), dst = 1 + ((round + 1) & 1);
     const uint32_t my_end = rec[src];
     if (X.k == 0) { rec[dst] = my_end; return; }
-    const uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - X.S.channels) + src];
+    const uint32_t C = X.S.channels;
+    uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - C) + src];
+    if (a.seg_state[4 * (uint64_t)(g - C) + 3] == SEG_SILENT) {
+        // behind a run of silent segments: the start state follows from the last segment with sound before the run (or the header's
+        // history), however long the run -- no decode, and no waiting for the run's segments to be repaired one round after the other
+        uint32_t j = X.k - 1;
+        while (j > 0 && a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + 3] == SEG_SILENT) j--;
+        const bool from_start = a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + 3] == SEG_SILENT;      // (j == 0 and silent too)
+        uint32_t state; uint32_t from_row;
+        if (from_start) { const uint32_t chain = X.S.first_chain + X.ch; state = seg_pack(a.history[2 * chain], a.history[2 * chain + 1]); from_row = 0; }
+        else { state = a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + src]; from_row = (j + 1) * X.S.seg_rows; }
+        int32_t sc, c0, c1;
+        seg_scale(X.S, 0, sc, c0, c1);
+        prev_end = seg_idle_advance(c0, c1, state, (uint64_t)(X.r0 - from_row) * 32);
+    }
     if (prev_end == rec[0]) { rec[dst] = my_end; return; }          // decoded from the right state already
     int32_t h1, h2;
     seg_unpack(prev_end, h1, h2);
-    const uint32_t stop_row = rec[3], r_end = stop_row < X.r1 ? stop_row : X.r1;
-    const bool merged = seg_repair(X, r_end, h1, h2);
+    const uint32_t stop_row = seg_stop_of(rec[3]), r_end = stop_row < X.r1 ? stop_row : X.r1;
+    const bool merged = seg_repair(X, r_end, h1, h2, rec[3] == SEG_SILENT);
     const uint32_t e = merged ? my_end : seg_pack(h1, h2);
     rec[0] = prev_end; rec[dst] = e;
     if (last && e != my_end) atomicOr(&a.seg_flags[X.S.first_chain + X.ch], 1u);     // the next segment started from a stale state
@@ -1053,13 +1110,13 @@ __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a, uint32_t fin) 
             for (uint64_t i = i0; i < i1; i++) q[i * S.channels + X.ch] = 0;
             continue;
         }
-        const uint32_t stop_row = rec[3], r_end = stop_row < X.r1 ? stop_row : X.r1;
+        const uint32_t stop_row = seg_stop_of(rec[3]), r_end = stop_row < X.r1 ? stop_row : X.r1;
         uint32_t end = rec[fin];                                     // (fin: where the last repair round left the ends)
         if (rec[0] != cur) {                                         // the segment's samples were decoded from rec[0]
             seg_unpack(cur, h1, h2);
-            if (!seg_repair(X, r_end, h1, h2)) end = seg_pack(h1, h2);
+            if (!seg_repair(X, r_end, h1, h2, rec[3] == SEG_SILENT)) end = seg_pack(h1, h2);
         }
-        if (stop_row != 0xFFFFFFFFu) stopped = true;
+        if (stop_row != SEG_NO_STOP) stopped = true;
         cur = end;
     }
 }

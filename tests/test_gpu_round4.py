@@ -269,3 +269,36 @@ def test_job_destroyed_with_work_in_flight(cc):
         for i in range(len(a_items)):
             o = int(offs_a[i])
             assert blob[o:o + len(a_refs[i % 4])] == a_refs[i % 4], i
+
+
+# ------------------------------------------------------------------------------------------------ a3: digital silence inside segmented files
+@pytest.mark.parametrize("warm", [100, 1])
+def test_adx_segmented_decode_through_runs_of_silence(cc, knobs, warm):
+    """Digital silence parks the decoder at a history-dependent fixed point of its predictor (adx.cpp:208-212 with zero codes), so
+    speculative segments inside it never merge; k_adx_seg_fix derives the state behind a RUN of silent segments from the last segment
+    with sound (cycle-detecting walk of the recurrence) instead of repairing one segment per round.  Clips with silent heads, tails
+    and gaps many segments long, mono / stereo / four channels, three coefficient sets, mode 2 (static filter 0 in silent blocks) --
+    every byte the oracle's, on the segmented kernels."""
+    from pycricodecs_amd.batch import Job
+    knobs(adx_mapping="seg", adx_warm_pct=warm)
+    rng = np.random.default_rng(77)
+    files = []
+    for k, (n, ch, mode, hp) in enumerate([(48000 * 3, 2, 3, 500), (48000 * 2, 1, 3, 500), (48000 * 3, 2, 3, 4000), (48000 * 2, 2, 2, 500), (48000 * 2, 4, 3, 100),
+                                            (48000 * 4, 2, 3, 500), (48000 * 1, 2, 3, 500), (32 * 9000, 1, 3, 20000)]):
+        x = synth.pcm16(6000 + k, n, ch, 48000).astype(np.int32)
+        cuts = sorted(int(c) for c in rng.integers(0, n, 6))
+        x[:cuts[0]] = 0                                            # head
+        x[cuts[1]:cuts[2]] = 0                                     # a gap
+        x[cuts[3]:cuts[4]] = 0                                     # another one
+        x[cuts[5]:] = 0                                            # tail
+        if k == 5:
+            x[:] = 0; x[48000:48000 + 4000] = 12000                # a click in an otherwise silent file
+        if k == 6:
+            x[:] = 0                                               # nothing but silence
+        files.append(O.adx_encode(synth.wav_bytes(x.astype(np.int16), 48000), 4, 18, mode, hp, 0, 4))
+    job = Job.adx_decode(files)
+    assert job.dominant_kernel == "k_adx_seg_decode"
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, f) in enumerate(zip(outs, files)):
+        assert bytes(o) == O.adx_decode(f), i
