@@ -175,7 +175,7 @@ def criref_all_cores(what, data, seconds, key, frames):
             "sample": "%d processes x %.0f s of the single-thread loop, all at once" % (n, seconds)}
 
 
-def cpu_baseline(kind, sample, frames, seconds=10.0):
+def cpu_baseline(kind, sample, frames, seconds=10.0):  # noqa: C901
     """kind: hcadec (sample = encrypted stream), hcaenc (sample = WAV), adxrt (sample = WAV: encode, then decode of the result).
     `frames` = the metric's units one repetition processes.  value / cores = ONE host thread; all_cores = every core at once."""
     import oracle_lib as O
@@ -213,6 +213,34 @@ def cpu_baseline(kind, sample, frames, seconds=10.0):
         reps, secs = timed_loop(lambda: O.adx_decode(O.adx_encode(sample)), seconds)
     return {"value": round(reps * frames / secs, 1), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d x %s (%d frames each), oracle/cri_oracle.c, single thread" % (reps, what, frames)}
+
+
+def cpu_baseline_awb(parts, seconds=4.0):
+    """Host-core baseline of the mixed AWB bank: the reference decodes one HCA clip and one ADX clip of the bank in a loop (single
+    thread, then every core at once); the bank's rate follows from its own mix of HCA frames and ADX block rows."""
+    import oracle_lib as O
+    if not criref() or not parts.get("hca") or not parts.get("adx"):
+        return None
+    hca = O.hca_crypt(O.hca_crypt(parts["hca"], 0, 56, KEY, parts["subkey"]), 1, 56, KEY)     # the same frames under the plain key (the tool takes no subkey)
+    adx = parts["adx"]
+    hf = int.from_bytes(hca[16:20], "big")
+    ar = (len(adx) - int.from_bytes(adx[2:4], "big") - 4) // (18 * adx[7]) - 1
+    H, A = parts["hca_frames"], parts["adx_rows"]
+
+    def rate(fn):
+        r_h, r_a = fn("hcadec", hca, hf, KEY), fn("adxdec", adx, ar, 0)
+        return (H + A) / (H / r_h + A / r_a)
+    one = lambda what, data, units, key: (lambda r, s_: r * units / s_)(*criref_bench(what, data, seconds / 2, key))
+    out = {"value": round(rate(one), 1), "unit": "frames/s (HCA frames + ADX block rows)", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
+           "sample": "reference C++ (oracle/_ref/criref), single thread: %.0f s of HCA decode of one %d-frame clip and %.0f s of ADX decode of one %d-row clip of the bank, weighted by the bank's %d HCA frames / %d ADX rows"
+                     % (seconds / 2, hf, seconds / 2, ar, H, A)}
+    try:
+        allc = lambda what, data, units, key: criref_all_cores(what, data, seconds / 2, key, units)["value"]
+        n = len(os.sched_getaffinity(0))
+        out["all_cores"] = {"value": round(rate(allc), 1), "unit": "frames/s", "cores": n, "sample": "%d processes of the same loops at once" % n}
+    except Exception as e:
+        log("all-cores baseline failed:", e)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ device helpers
@@ -487,7 +515,7 @@ def adx_roundtrip_run(D, streams, unique, seconds, family, steps, warmup, verify
     return res
 
 
-def build_awb_bank(n_total, rank, world, seed=77):
+def build_awb_bank(n_total, rank, world, seed=77, family="tonal"):
     """AFS2 bank of this rank's share of `n_total` short clips (BASELINE configs[4] shape: log-uniform 0.05-2 s, 48 kHz stereo,
     half ADX bs18/bd4, half HCA High encrypted with the bank's subkey).  The global clip list is the same on every rank;
     shares are longest-processing-time balanced by frame count (pycricodecs_amd.shard).  Returns (bank, uniq, order, subkey)."""
@@ -500,7 +528,7 @@ def build_awb_bank(n_total, rank, world, seed=77):
     durs = np.exp(rng.uniform(np.log(0.05), np.log(2.0), 24))
     uniq = []
     for u, d in enumerate(durs):
-        w = synth.wav(7000 + u, max(32, int(48000 * d) // 32 * 32), 2, 48000)
+        w = synth.wav_bytes(family_pcm(7000 + u, max(32, int(48000 * d) // 32 * 32), 2, 48000, family), 48000)
         uniq.append(("hca", O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, subkey)))
         uniq.append(("adx", O.adx_encode(w)))
     order_all = rng.integers(0, len(uniq), n_total)
@@ -519,7 +547,7 @@ def build_awb_bank(n_total, rank, world, seed=77):
     return head.ljust(hs, b"\0") + b"".join(parts), uniq, order, subkey
 
 
-def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=False):
+def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=False, family="tonal"):
     """Decode of a mixed AFS2 bank through the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM.
     With world > 1 every rank decodes its LPT share of clips x world clips and (gather=True) the decoded PCM of all
     ranks is collected on rank 0 inside the timed region -- the only collective-like step of the whole path."""
@@ -528,7 +556,7 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     from pycricodecs_amd import shard
     from pycricodecs_amd.batch import Job
     world = D.world
-    bank, uniq, order, subkey = build_awb_bank(clips if strong else clips * world, D.rank, world)      # strong: `clips` is the whole job
+    bank, uniq, order, subkey = build_awb_bank(clips if strong else clips * world, D.rank, world, family=family)      # strong: `clips` is the whole job
     n = len(order)
     hj, aj = Job.awb_decode(bank, KEY)
     d_in, ho, hscr, hst = hj.alloc(D.dev)
@@ -538,6 +566,7 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     # the two jobs are independent: the ADX one (one wave per file, as long as its longest clip) runs on a stream of its own and the
     # HCA kernels fill the rest of the chip meanwhile; both are inside the timed region (the main stream waits for the side one)
     side = torch.cuda.Stream(D.dev)
+    hj.enable_events(True); aj.enable_events(True)
 
     def step():
         main = torch.cuda.current_stream(D.dev)
@@ -547,14 +576,21 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
         main.wait_stream(side)
         if gather and world > 1:
             gathered["hca"] = shard.gather_bytes_to_root(ho[:hj.output_bytes]); gathered["adx"] = shard.gather_bytes_to_root(ao[:aj.output_bytes])
-    dt, _ = run_timed(D, step, max(steps, 1), max(warmup, 1), [])
+    dt, kms = run_timed(D, step, max(steps, 1), max(warmup, 1), [hj, aj])
     hca_units, adx_units, n_all = D.reduce([float(hj.units), float(aj.units), float(n)], "sum")
     assert int((hst < 0).sum().item()) == 0 and int((ast < 0).sum().item()) == 0
     res = {"workload": "AFS2 bank(s) of %d clips%s (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV%s"
                        % (int(n_all), " over %d GPUs, LPT-sharded" % world if world > 1 else "", ", PCM gathered on rank 0 (RCCL send/recv)" if gather and world > 1 else ""),
            "bank_bytes_rank0": len(bank), "pcm_bytes_rank0": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
            "hca_frames": int(hca_units), "adx_frames": int(adx_units), "frames_per_s": round((hca_units + adx_units) / dt, 1),
-           "clips_per_s": round(n_all / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)"}
+           "clips_per_s": round(n_all / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)", "material": family}
+    # the pieces of the line's roofline / cpu_baseline objects (this rank's jobs)
+    dom_hca = max((k for k in kms if "hca" in k), key=lambda k: kms[k], default=None)
+    dom_adx = max((k for k in kms if "adx" in k), key=lambda k: kms[k], default=None)
+    res["_roofline_parts"] = {"kernel_ms": kms, "alg_bytes": hj.algorithmic_bytes + aj.algorithmic_bytes,
+                              "alg_bytes_by_kernel": {k: v for k, v in ((dom_hca, hj.algorithmic_bytes), (dom_adx, aj.algorithmic_bytes)) if k}, "dt": dt}
+    first_of = lambda kind: next((uniq[i][1] for i in order if uniq[i][0] == kind), None)
+    res["_cpu_parts"] = {"hca": first_of("hca"), "adx": first_of("adx"), "hca_frames": int(hj.units), "adx_rows": int(aj.units), "subkey": subkey}
     if verify:
         refs = [O.hca_decode(b, KEY, subkey) if k == "hca" else O.adx_decode(b) for k, b in uniq]
         hi = [i for i in range(n) if uniq[order[i]][0] == "hca"]
@@ -649,9 +685,59 @@ def secondary_measurements(args, D):
                         "chunks_per_s": round(job.units / dt, 1), "ms_per_step": round(dt * 1e3, 3), "verified_items": v["items"]}
     del bufs
     torch.cuda.empty_cache()
-    out["awb_mixed_decode"] = awb_mixed_run(D, args.awb_clips, 3, 1)
+    r = awb_mixed_run(D, args.awb_clips, 3, 1)
+    r.pop("_roofline_parts"); r.pop("_cpu_parts")
+    out["awb_mixed_decode"] = r
     out["single_call_ms"] = single_call_latency(args.seconds)
+    out["baseline_configs"] = baseline_config_lines(args, D)
     return out
+
+
+def baseline_config_lines(args, D):
+    """Every BASELINE.json configuration that is not the headline, at the size it is written, each as a line of its own inside the
+    default run: value, ms_per_step, its own `roofline` (dominant kernel timed with HIP events in the timed steps) and `cpu_baseline`
+    (the real reference on the host's cores, a few seconds each), every output verified on the device.
+      configs[1]  ADX encode + decode round trip, 1 000 x 10 s stereo WAVs
+      configs[3]  HCA encode (High), 10 000 x 30 s stereo WAVs (57.6 GB of PCM in HBM)
+      configs[4]  mixed AWB bank, 100 000 short ADX + HCA clips on ONE GPU (the 8-GPU form is this batch dealt out: --scaling strong),
+                  tonal material and the silence-padded SFX family"""
+    import torch
+    lines = {}
+    cs = args.config_cpu_seconds
+
+    def line(r, workload, dtype, unit_bytes, cpu):
+        kms = r["kernel_ms"]
+        dom = max(kms, key=kms.get)
+        alg_dom = r.get("alg_bytes_by_kernel", {}).get(dom, r["alg_bytes"])
+        out = {"workload": workload, "value": round(r["units"] / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] * 1e3, 3), "dtype": dtype,
+               "frames_per_step": int(r["units"]), "roofline": roofline_of(alg_dom, r["alg_bytes"], kms, r["dt"], None, {"bytes_per_unit": unit_bytes}),
+               "verified": r.get("verified"), "cpu_baseline": cpu}
+        return out
+    # configs[1]
+    r = adx_roundtrip_run(D, 1000, 16, 10.0, "tonal", 3, 1)
+    lines["configs[1] adx_roundtrip"] = line(r, "BASELINE configs[1]: ADX encode + decode round trip (bs18/bd4/mode3/v4), 1000 48 kHz stereo WAVs x 10 s; a frame = one block row, counted for the encode and for the decode",
+                                             "int32", "blocksize + 2*samples_per_block = 82 B per block, encode and decode each", None if args.no_cpu else cpu_baseline("adxrt", r["sample"], 2 * r["frames_per_stream"], cs))
+    r = adx_roundtrip_run(D, 1000, 16, 10.0, "sfx", 3, 1)
+    lines["configs[1] adx_roundtrip, sfx material"] = line(r, "the same on the SFX family (0.05-0.5 s of digital silence before and after the sound)", "int32", "82 B per block, encode and decode each", None)
+    # configs[3]
+    r = hca_encode_run(D, 10000, 16, 30.0, 1, "tonal", 3, 1)
+    lines["configs[3] hca_encode"] = line(r, "BASELINE configs[3]: HCA encode (v2.0, quality High), 10000 48 kHz stereo WAVs x 30 s", "f32",
+                                          "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"], None if args.no_cpu else cpu_baseline("hcaenc", r["sample"], r["frames_per_stream"], cs))
+    r.pop("job", None)
+    torch.cuda.empty_cache()
+    # configs[4]
+    for fam in ("tonal", "sfx"):
+        r = awb_mixed_run(D, args.config_awb_clips, 3, 1, family=fam)
+        rp, cp = r.pop("_roofline_parts"), r.pop("_cpu_parts")
+        kms = rp["kernel_ms"]
+        dom = max(kms, key=kms.get)
+        lines["configs[4] awb_mixed" + ("" if fam == "tonal" else ", sfx material")] = {
+            "workload": "BASELINE configs[4] on one GPU: " + r["workload"], "value": r["frames_per_s"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "dtype": "f32+int32",
+            "frames_per_step": r["hca_frames"] + r["adx_frames"], "clips_per_s": r["clips_per_s"], "bank_bytes": r["bank_bytes_rank0"], "pcm_bytes": r["pcm_bytes_rank0"],
+            "roofline": roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], None,
+                                    {"bytes_per_unit": "HCA frame: frame_size + 4096 B; ADX block row: 2 x 82 B (stereo)"}),
+            "verified": r.get("verified"), "cpu_baseline": None if (args.no_cpu or fam != "tonal") else cpu_baseline_awb(cp, cs)}
+    return lines
 
 
 def single_call_latency(seconds):
@@ -766,6 +852,8 @@ def main():
     ap.add_argument("--secondary-streams", type=int, default=1000)
     ap.add_argument("--host-streams", type=int, default=10000, help="streams of the host-memory secondary (host output buffers: 1.92 MB each)")
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
+    ap.add_argument("--config-awb-clips", type=int, default=100000, help="clips of the configs[4] line inside the default run (one GPU)")
+    ap.add_argument("--config-cpu-seconds", type=float, default=4.0, help="seconds of reference CPU work per baseline of the configs lines (single thread; again on all cores)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)
@@ -787,8 +875,15 @@ def main():
     t_setup = time.time()
 
     if wl == "awb_mixed":                                      # BASELINE configs[4]; its own metric line
-        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify, strong=strong)
+        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify, strong=strong, family=args.data if args.data in ("tonal", "sfx") else "tonal")
+        rp, cp = r.pop("_roofline_parts"), r.pop("_cpu_parts")
         if D.rank == 0:
+            kms = rp["kernel_ms"]
+            dom = max(kms, key=kms.get)
+            common = dict(common, roofline=roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], None,
+                                                       {"bytes_per_unit": "HCA frame: frame_size + 4096 B; ADX block row: 2 x 82 B (stereo); rank 0's jobs"}))
+            if not args.no_cpu:
+                common["cpu_baseline"] = cpu_baseline_awb(cp)
             print(json.dumps(dict(common, metric="audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", value=r["frames_per_s"], unit="frames/s",
                                   ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (24 unique durations x 2 codecs, tiled; tonal family)",
                                   config=r)), flush=True)
