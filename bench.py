@@ -515,15 +515,14 @@ def adx_roundtrip_run(D, streams, unique, seconds, family, steps, warmup, verify
     return res
 
 
-def build_awb_bank(n_total, rank, world, seed=77, family="tonal"):
-    """AFS2 bank of this rank's share of `n_total` short clips (BASELINE configs[4] shape: log-uniform 0.05-2 s, 48 kHz stereo,
-    half ADX bs18/bd4, half HCA High encrypted with the bank's subkey).  The global clip list is the same on every rank;
-    shares are longest-processing-time balanced by frame count (pycricodecs_amd.shard).  Returns (bank, uniq, order, subkey)."""
-    import struct
+def awb_clip_plan(n_total, rank, world, seed=77, family="tonal"):
+    """The mixed bank's clips and who decodes which: 48 unique clips (24 log-uniform durations 0.05-2 s x {HCA High encrypted with the
+    bank's subkey, ADX bs18/bd4}), the global list of n_total draws from them (the same on every rank), and this rank's share of that
+    list -- longest-processing-time balanced by frame count (pycricodecs_amd.shard).  Returns (uniq, order_all, mine, subkey)."""
     import numpy as np
     import oracle_lib as O
     from pycricodecs_amd import shard, synth
-    subkey, align = 0x2468, 0x20
+    subkey = 0x2468
     rng = np.random.default_rng(seed)
     durs = np.exp(rng.uniform(np.log(0.05), np.log(2.0), 24))
     uniq = []
@@ -533,7 +532,17 @@ def build_awb_bank(n_total, rank, world, seed=77, family="tonal"):
         uniq.append(("adx", O.adx_encode(w)))
     order_all = rng.integers(0, len(uniq), n_total)
     wts = [shard.hca_weight(u[1]) if u[0] == "hca" else shard.adx_weight(u[1]) // 2 for u in uniq]
-    mine = shard.my_items([wts[i] for i in order_all], rank, world) if world > 1 else range(n_total)
+    mine = shard.my_items([wts[i] for i in order_all], rank, world) if world > 1 else list(range(n_total))
+    return uniq, order_all, mine, subkey
+
+
+def build_awb_bank(n_total, rank, world, seed=77, family="tonal"):
+    """AFS2 bank of this rank's share of `n_total` short clips (BASELINE configs[4] shape, awb_clip_plan).  Returns (bank, uniq, order,
+    subkey): order[i] = the unique clip behind the bank's item i."""
+    import struct
+    import numpy as np
+    uniq, order_all, mine, subkey = awb_clip_plan(n_total, rank, world, seed, family)
+    align = 0x20
     order = [int(order_all[i]) for i in mine]
     n = len(order)
     hs0 = 16 + 2 * n + 4 * (n + 1)
