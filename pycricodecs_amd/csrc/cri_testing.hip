@@ -73,7 +73,48 @@ __global__ __launch_bounds__(256) void k_test_adx_quant(int bitdepth, int d_min,
     if (bad) atomicAdd(&counts[1], bad);
 }
 
+// Counter calibration (tools/prof_r04.sh): streams of a known byte count in the access widths the product kernels use, so that
+// rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled per width before they are compared with byte counts (MI355X_MICROARCH.md, HBM:
+// on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads; other widths are "uncalibrated").
+template <typename T> __global__ __launch_bounds__(256) void k_test_stream_read(const T* src, uint64_t n, uint32_t* sink) {
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const T v = src[i];
+        const uint32_t* w = (const uint32_t*)&v;
+        for (uint32_t k = 0; k < sizeof(T) / 4; k++) acc ^= w[k];
+    }
+    if (acc == 0x9E3779B9u) *sink = acc;                   // (keeps the loads)
+}
+template <typename T> __global__ __launch_bounds__(256) void k_test_stream_write(T* dst, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        T v; uint32_t* w = (uint32_t*)&v;
+        for (uint32_t k = 0; k < sizeof(T) / 4; k++) w[k] = (uint32_t)i + k;
+        dst[i] = v;
+    }
+}
+
 }  // namespace cri
+
+// reads (and, separately, writes) `bytes` of device memory `reps` times with 4-, 8- and 16-byte accesses per lane; the kernels are
+// k_test_stream_read<unsigned int | uint2 | uint4> and k_test_stream_write<...> in the profiler's output
+extern "C" int cri_test_stream(uint64_t bytes, int reps) {
+    void* buf = nullptr; uint32_t* sink = nullptr;
+    bytes &= ~(uint64_t)255;
+    if (!bytes || hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) return CRI_ERR_HIP;
+    (void)hipMemset(buf, 1, bytes);
+    const dim3 grid(256 * 32), block(256);
+    for (int r = 0; r < reps; r++) {
+        hipLaunchKernelGGL(cri::k_test_stream_read<uint32_t>, grid, block, 0, 0, (const uint32_t*)buf, bytes / 4, sink);
+        hipLaunchKernelGGL(cri::k_test_stream_read<uint2>, grid, block, 0, 0, (const uint2*)buf, bytes / 8, sink);
+        hipLaunchKernelGGL(cri::k_test_stream_read<uint4>, grid, block, 0, 0, (const uint4*)buf, bytes / 16, sink);
+        hipLaunchKernelGGL(cri::k_test_stream_write<uint32_t>, grid, block, 0, 0, (uint32_t*)buf, bytes / 4);
+        hipLaunchKernelGGL(cri::k_test_stream_write<uint2>, grid, block, 0, 0, (uint2*)buf, bytes / 8);
+        hipLaunchKernelGGL(cri::k_test_stream_write<uint4>, grid, block, 0, 0, (uint4*)buf, bytes / 16);
+    }
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : CRI_ERR_HIP;
+    (void)hipFree(buf); (void)hipFree(sink);
+    return rc;
+}
 
 // form 0 / 1 as above; returns 0 and fills cases, mismatches and (when there is one) the first mismatch {delta, scale, got, want}
 extern "C" int cri_test_adx_quantisers(int form, int bitdepth, int d_min, int d_max, unsigned long long* cases, unsigned long long* mismatches, int32_t first4[4]) {
