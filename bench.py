@@ -374,27 +374,51 @@ def roofline_of(alg_bytes, alg_bytes_path, kernel_ms, dt, traffic=None, extra=No
     return r
 
 
-def committed_traffic(units, dom):
-    """HBM bytes per step from the committed rocprofv3 counter passes of this same command (PMC counters cannot be collected from
-    inside the process): the newest profiles/r*_traffic.json, path total and dominant kernel."""
+def committed_traffic(units, dom, workload="hca_decode"):
+    """HBM bytes per step from the committed rocprofv3 counter passes of this same path (PMC counters cannot be collected from inside
+    the process): the newest profiles/r*_traffic.json -- per-unit bytes of the workload's kernels (FETCH_SIZE + WRITE_SIZE, separate
+    --pmc passes, scaled per access width by known calibration streams, every dispatch of a step summed) x this run's units.
+    workload: hca_decode | hca_decode_sparse | hca_encode | adx_roundtrip | adx_roundtrip_sfx (units = block rows, each counted once)."""
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not tfiles:
         return None
     with open(tfiles[-1]) as fh:
         tj = json.load(fh)
-    ks = tj.get("kernels", {})
-    total = tj.get("total_hbm_bytes_per_frame") or sum(k["hbm_bytes_per_frame"] for k in ks.values())
+    wl = tj.get("workloads", {}).get(workload)
+    if wl is None and workload == "hca_decode":                 # (round-3 files: the headline's kernels only)
+        wl = {"kernels": {k: dict(v, hbm_bytes_per_unit=v.get("hbm_bytes_per_frame")) for k, v in tj.get("kernels", {}).items()},
+              "total_hbm_bytes_per_unit": tj.get("total_hbm_bytes_per_frame"), "unit": "frame"}
+    if not wl or not wl.get("total_hbm_bytes_per_unit"):
+        return None
+    ks, total = wl["kernels"], wl["total_hbm_bytes_per_unit"]
     out = {"traffic": int(round(total * units)),
-           "traffic_source": "profiles/%s: %.0f B/frame over the path's kernels (FETCH_SIZE with the gfx950 correction + WRITE_SIZE, separate --pmc passes) x %d frames"
-                             % (os.path.basename(tfiles[-1]), total, units)}
+           "traffic_source": "profiles/%s, %s: %.1f B per %s over the path's kernels (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, calibrated per access width, dispatches summed per step; 1000-item batch) x %d units; algorithmic %s B"
+                             % (os.path.basename(tfiles[-1]), workload, total, wl.get("unit", "unit"), units, wl.get("algorithmic_bytes_per_unit", "?"))}
     key = dom if dom in ks else next((k for k in ks if k.startswith(dom) or dom.startswith(k)), None)
-    if key:
-        out["traffic_dominant_kernel"] = int(round(ks[key]["hbm_bytes_per_frame"] * units))
+    if key and ks[key].get("hbm_bytes_per_unit"):
+        out["traffic_dominant_kernel"] = int(round(ks[key]["hbm_bytes_per_unit"] * units))
     return out
 
 
-def committed_valu(units, kernel_ms):
-    """What bounds the HCA decode kernels is VALU issue, not HBM: from the committed SQ counter passes of this path
+def committed_traffic_awb(hca_frames, adx_rows):
+    """The mixed bank has no counter pass of its own: its traffic is composed from the per-unit figures of the same kernels in the HCA
+    decode pass (per frame) and the ADX round trip's decode kernels (per block row)."""
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not tfiles:
+        return None
+    with open(tfiles[-1]) as fh:
+        w = json.load(fh).get("workloads", {})
+    h = (w.get("hca_decode") or {}).get("total_hbm_bytes_per_unit")
+    a = sum(v.get("hbm_bytes_per_unit") or 0.0 for k, v in (w.get("adx_roundtrip") or {}).get("kernels", {}).items() if "decode" in k or "seg_fix" in k or "seg_serial" in k)
+    if not h or not a:
+        return None
+    return {"traffic": int(round(h * hca_frames + a * adx_rows)),
+            "traffic_source": "profiles/%s: %.1f B per HCA frame (hca_decode pass) x %d + %.1f B per ADX block row (decode kernels of the adx_roundtrip pass) x %d"
+                              % (os.path.basename(tfiles[-1]), h, hca_frames, a, adx_rows)}
+
+
+def committed_valu(units, kernel_ms, workload="hca_decode"):
+    """What bounds the HCA kernels is VALU issue, not HBM: from the committed SQ counter passes of this path
     (profiles/r*_pmc_1000streams.json) the wave64 VALU instructions per frame and `busy` = the share of a kernel's cycles its SIMDs
     spend issuing them (4 cycles each on one of 1024 SIMDs, against GRBM_GUI_ACTIVE: clock-independent).  floor_ms = the time this
     run's kernels would take if VALU issue were all they did (busy x measured time)."""
@@ -404,8 +428,8 @@ def committed_valu(units, kernel_ms):
     with open(files[-1]) as fh:
         pj = json.load(fh)
     per, busy, floor = {}, {}, 0.0
-    for name, k in pj.get("kernels", {}).items():
-        cls = "k_hca_parse" if "parse" in name else ("k_hca_transform" if "transform" in name else None)
+    for name, k in (pj.get("workloads", {}).get(workload) or (pj.get("kernels", {}) if workload == "hca_decode" else {})).items():
+        cls = "k_hca_parse" if "parse" in name else ("k_hca_transform" if "transform" in name else ("k_hca_encode" if "k_hca_encode" in name else None))
         if not cls or "VALU_per_frame" not in k:
             continue
         per[cls] = k["VALU_per_frame"]
@@ -652,7 +676,8 @@ def secondary_measurements(args, D):
     import hca_forge
     nw = max(1, n // 4)
     for label, ch, v3, q in (("hca_decode_6ch", 6, False, 1), ("hca_decode_8ch", 8, False, 1), ("hca_decode_v3_noise_fill", 2, True, 1), ("hca_decode_3ch", 3, False, 1),
-                             ("hca_decode_6ch_middle", 6, False, 2), ("hca_decode_5ch_middle", 5, False, 2)):      # (Middle: joint stereo + HFR, the wide joint form)
+                             ("hca_decode_6ch_middle", 6, False, 2), ("hca_decode_5ch_middle", 5, False, 2),
+                             ("hca_decode_6ch_v3_noise_fill", 6, True, 1)):      # (Middle: joint stereo + HFR, the wide joint form)
         plain = [O.hca_encode(family_wav(8000 + 10 * ch + u, args.seconds, "tonal", ch=ch), q) for u in range(4)]
         if v3:
             plain = [hca_forge.forge_v3(h, 0) for h in plain]
@@ -714,24 +739,28 @@ def baseline_config_lines(args, D):
     lines = {}
     cs = args.config_cpu_seconds
 
-    def line(r, workload, dtype, unit_bytes, cpu):
+    def line(r, workload, dtype, unit_bytes, cpu, traffic_key=None):
         kms = r["kernel_ms"]
         dom = max(kms, key=kms.get)
         alg_dom = r.get("alg_bytes_by_kernel", {}).get(dom, r["alg_bytes"])
+        traffic = committed_traffic(int(r["units"]) // (2 if traffic_key.startswith("adx") else 1), dom, traffic_key) if traffic_key else None
+        extra = {"bytes_per_unit": unit_bytes}
+        if traffic_key == "hca_encode":
+            extra.update(committed_valu(int(r["units"]), kms, "hca_encode") or {})
         out = {"workload": workload, "value": round(r["units"] / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] * 1e3, 3), "dtype": dtype,
-               "frames_per_step": int(r["units"]), "roofline": roofline_of(alg_dom, r["alg_bytes"], kms, r["dt"], None, {"bytes_per_unit": unit_bytes}),
+               "frames_per_step": int(r["units"]), "roofline": roofline_of(alg_dom, r["alg_bytes"], kms, r["dt"], traffic, extra),
                "verified": r.get("verified"), "cpu_baseline": cpu}
         return out
     # configs[1]
     r = adx_roundtrip_run(D, 1000, 16, 10.0, "tonal", 3, 1)
     lines["configs[1] adx_roundtrip"] = line(r, "BASELINE configs[1]: ADX encode + decode round trip (bs18/bd4/mode3/v4), 1000 48 kHz stereo WAVs x 10 s; a frame = one block row, counted for the encode and for the decode",
-                                             "int32", "blocksize + 2*samples_per_block = 82 B per block, encode and decode each", None if args.no_cpu else cpu_baseline("adxrt", r["sample"], 2 * r["frames_per_stream"], cs))
+                                             "int32", "blocksize + 2*samples_per_block = 82 B per block, encode and decode each", None if args.no_cpu else cpu_baseline("adxrt", r["sample"], 2 * r["frames_per_stream"], cs), "adx_roundtrip")
     r = adx_roundtrip_run(D, 1000, 16, 10.0, "sfx", 3, 1)
-    lines["configs[1] adx_roundtrip, sfx material"] = line(r, "the same on the SFX family (0.05-0.5 s of digital silence before and after the sound)", "int32", "82 B per block, encode and decode each", None)
+    lines["configs[1] adx_roundtrip, sfx material"] = line(r, "the same on the SFX family (0.05-0.5 s of digital silence before and after the sound)", "int32", "82 B per block, encode and decode each", None, "adx_roundtrip_sfx")
     # configs[3]
     r = hca_encode_run(D, 10000, 16, 30.0, 1, "tonal", 3, 1)
     lines["configs[3] hca_encode"] = line(r, "BASELINE configs[3]: HCA encode (v2.0, quality High), 10000 48 kHz stereo WAVs x 30 s", "f32",
-                                          "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"], None if args.no_cpu else cpu_baseline("hcaenc", r["sample"], r["frames_per_stream"], cs))
+                                          "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"], None if args.no_cpu else cpu_baseline("hcaenc", r["sample"], r["frames_per_stream"], cs), "hca_encode")
     r.pop("job", None)
     torch.cuda.empty_cache()
     # configs[4]
@@ -743,7 +772,7 @@ def baseline_config_lines(args, D):
         lines["configs[4] awb_mixed" + ("" if fam == "tonal" else ", sfx material")] = {
             "workload": "BASELINE configs[4] on one GPU: " + r["workload"], "value": r["frames_per_s"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "dtype": "f32+int32",
             "frames_per_step": r["hca_frames"] + r["adx_frames"], "clips_per_s": r["clips_per_s"], "bank_bytes": r["bank_bytes_rank0"], "pcm_bytes": r["pcm_bytes_rank0"],
-            "roofline": roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], None,
+            "roofline": roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], committed_traffic_awb(r["hca_frames"], r["adx_frames"]),
                                     {"bytes_per_unit": "HCA frame: frame_size + 4096 B; ADX block row: 2 x 82 B (stereo)"}),
             "verified": r.get("verified"), "cpu_baseline": None if (args.no_cpu or fam != "tonal") else cpu_baseline_awb(cp, cs)}
     return lines
@@ -889,7 +918,7 @@ def main():
         if D.rank == 0:
             kms = rp["kernel_ms"]
             dom = max(kms, key=kms.get)
-            common = dict(common, roofline=roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], None,
+            common = dict(common, roofline=roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], committed_traffic_awb(r["hca_frames"], r["adx_frames"]),
                                                        {"bytes_per_unit": "HCA frame: frame_size + 4096 B; ADX block row: 2 x 82 B (stereo); rank 0's jobs"}))
             if not args.no_cpu:
                 common["cpu_baseline"] = cpu_baseline_awb(cp)
@@ -932,10 +961,17 @@ def main():
     units_all = D.reduce([float(units)], "sum")[0]             # the whole job's units (weak: world x this rank's; strong: the fixed batch)
     dom = max(kms, key=kms.get)
     alg_dom = r.get("alg_bytes_by_kernel", {}).get(dom, r["alg_bytes"])
-    traffic = committed_traffic(units, dom) if (wl == "hca_decode" and args.quality == 1 and args.data == "tonal") else None
+    traffic = None
+    if args.quality == 1:
+        if wl == "hca_decode" and args.data in ("tonal", "sparse"):
+            traffic = committed_traffic(units, dom, "hca_decode" if args.data == "tonal" else "hca_decode_sparse")
+        elif wl == "hca_encode" and args.data == "tonal":
+            traffic = committed_traffic(units, dom, "hca_encode")
+        elif wl == "adx_roundtrip" and args.data in ("tonal", "sfx"):
+            traffic = committed_traffic(units // 2, dom, "adx_roundtrip" if args.data == "tonal" else "adx_roundtrip_sfx")
     extra = {"bytes_per_unit": unit_bytes}
-    if wl == "hca_decode":
-        extra.update(committed_valu(units, kms) or {})
+    if wl in ("hca_decode", "hca_encode"):
+        extra.update(committed_valu(units, kms, wl) or {})
     roof = roofline_of(alg_dom, r["alg_bytes"], kms, dt, traffic, extra)
     out = dict(common, metric="audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline", value=round(units_all / dt, 1), unit="frames/s",
                ms_per_step=round(dt * 1e3, 3), dtype=dtype,

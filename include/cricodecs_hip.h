@@ -210,7 +210,10 @@ int cri_job_run_floats(cri_job* job, const void* d_in, void* d_out, void* d_scra
  * first_record_offset + g * record_bytes + flags_offset of frame g (0 <= g < frames) has narrow_flag set when that frame's
  * quantised lines went through scratch in the narrow (int8) form.  Returns the number of groups (fills at most cap). */
 typedef struct cri_hca_group_info {
-    uint32_t channels, frames, record_bytes, flags_offset, narrow_flag, narrow_capable, plain, pad;
+    uint32_t channels, frames, record_bytes, flags_offset, narrow_flag, narrow_capable, plain;
+    uint32_t transform_form;      /* which transform kernel takes the group: 0 k_hca_transform_generic, 1 k_hca_transform<.>, 2 / 3 / 4 the
+                                     in-lane kernel k_hca_transform_plain (plain / joint stereo + HFR / + v3.0 noise fill), | 8 its wide form
+                                     (a wave per four channels) */
     uint64_t first_record_offset;
     uint64_t lines_offset;        /* the group's quantised lines, tile-major (64 frames per tile) */
     uint64_t code_desc_offset;    /* the group's band code descriptions: [tile][channel][block 8][frame 64][band 16] bytes, low nibble =

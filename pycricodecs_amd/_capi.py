@@ -36,7 +36,7 @@ class UsmChunk(C.Structure):
 
 
 class HcaGroupInfo(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("channels", "frames", "record_bytes", "flags_offset", "narrow_flag", "narrow_capable", "plain", "pad")] + \
+    _fields_ = [(n, C.c_uint32) for n in ("channels", "frames", "record_bytes", "flags_offset", "narrow_flag", "narrow_capable", "plain", "transform_form")] + \
                [("first_record_offset", C.c_uint64), ("lines_offset", C.c_uint64), ("code_desc_offset", C.c_uint64)]
 
 

@@ -270,6 +270,13 @@ class Job:
             narrow += int(((fl & g.narrow_flag) != 0).sum().item())
         return {"frames": frames, "narrow": narrow}
 
+    def transform_forms(self):
+        """HCA decode: the transform kernel of every format group (cri_hca_group_info.transform_form: 0 generic, 1 general,
+        2 / 3 / 4 in-lane plain / joint / noise fill, | 8 wide)."""
+        arr = (_capi.HcaGroupInfo * 64)()
+        n = self._L.cri_job_hca_groups(self._h, arr, 64)
+        return [int(g.transform_form) for g in arr[:n]]
+
     def enable_events(self, on=True):
         self._L.cri_job_enable_events(self._h, 1 if on else 0)
 

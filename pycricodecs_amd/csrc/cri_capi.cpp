@@ -477,9 +477,9 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         a.narrow = (!a.noise_fill && (a.channels <= 2 || a.plain)) ? 1 : 0;         // (plain formats of any channel count: k_hca_transform_plain in channel groups)
         a.pairs_even = 1;
         for (uint32_t c = 0; c < F.channels; c += 2) if (F.type[c] == CRI_CH_SECONDARY) a.pairs_even = 0;
-        // in-lane instances: 1 / 2 / 4 channels with pairs on even channels (joint, or noise fill); every other joint layout without
-        // noise fill goes to the wide joint form -- groups of up to four consecutive channels, cut so that no pair is split
-        a.inlane = (!a.plain && ((a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) || (a.channels >= 3 && !a.noise_fill))) ? 1 : 0;
+        // in-lane instances: 1 / 2 / 4 channels with pairs on even channels (joint, or noise fill); every other joint or noise-fill layout
+        // goes to the wide joint form -- groups of up to four consecutive channels, cut so that no pair is split
+        a.inlane = (!a.plain && ((a.pairs_even && (a.channels == 1 || a.channels == 2 || a.channels == 4)) || a.channels >= 3)) ? 1 : 0;
         a.wide_waves = 0;
         for (uint32_t cb = 0; cb < F.channels; a.wide_waves++) {
             uint32_t n = F.channels - cb < 4 ? F.channels - cb : 4;
@@ -1580,7 +1580,7 @@ extern "C" int cri_job_hca_groups(const cri_job* j, cri_hca_group_info* out, int
             cri_hca_group_info g; memset(&g, 0, sizeof g);
             g.channels = a.channels; g.frames = a.frames; g.record_bytes = hca_record_bytes(a.channels);
             g.flags_offset = HCA_REC_TAIL(a.channels) + 8; g.narrow_flag = HCA_REC_NARROW; g.narrow_capable = a.narrow;
-            g.plain = a.plain; g.first_record_offset = j->hca_group_first_record[n];
+            g.plain = a.plain; g.transform_form = hca_transform_form(a); g.first_record_offset = j->hca_group_first_record[n];
             g.lines_offset = a.qc_offset; g.code_desc_offset = a.resg_offset;
             out[n] = g;
         }

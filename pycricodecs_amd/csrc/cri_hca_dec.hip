@@ -1599,15 +1599,16 @@ struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[
 // lane reaches its first noise band of a subframe through a table of the generator's powers (HCA_LCG_POW).
 template <int C, bool FLT, bool JOINT, bool WIDE = false, bool NOISE = false>
 __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAIN_WAVES) void k_hca_transform_plain(HcaDecArgs a) {
-    static_assert(!WIDE || (C == 4 && !NOISE), "the wide form is four channels per wave");
+    static_assert(!WIDE || C == 4, "the wide form is four channels per wave");
     static_assert(!NOISE || JOINT, "noise fill stages the spectrum like the joint form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t NG = 4 / C;                         // groups = frames in flight
     const uint32_t CT = WIDE ? a.channels : (uint32_t)C;   // channels of the records, the line tiles and the PCM interleave
     const uint32_t wv = WIDE ? threadIdx.x >> 6 : 0u;
-    constexpr uint32_t WAVE_LDS = JOINT ? HCA_PLAIN_JOINT_LDS_BYTES : HCA_PLAIN_LDS_BYTES;
+    constexpr uint32_t WAVE_LDS = NOISE ? HCA_PLAIN_JOINT_LDS_BYTES + 512 + 512 + 64 : (JOINT ? HCA_PLAIN_JOINT_LDS_BYTES : HCA_PLAIN_LDS_BYTES);
     uint8_t* smem = smem_all + wv * WAVE_LDS;
     uint16_t* pcmw = (uint16_t*)(smem_all + (WIDE ? (blockDim.x >> 6) * WAVE_LDS : 0u));      // WIDE: the shared [128][CT] piece, then 128 B of dump
+    uint32_t* xnd = (uint32_t*)((uint8_t*)pcmw + 2048 + 128);     // WIDE + NOISE: [wave][unit] noise draws per subframe of every wave's channels (64 bytes)
     constexpr bool NW = true;                              // int8 lines (HCA_REC_NARROW) are read by all three instances
     const Fmt F = load_fmt(a.formats + a.format);
     const uint32_t lane = threadIdx.x & 63, u = lane >> 4, l16 = lane & 15, g = u / C, c = u % C;
@@ -1822,10 +1823,23 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             // generator state at the start of each unit's next subframe: its frame's draws before it (k_hca_noise_scan), the whole
             // subframes before it (the halo step starts at subframe 7) and the channels below it -- all wave-uniform, scalar work
             const uint32_t sf0 = cur_step < 0 ? 7u : 0u;
+            uint32_t others_all = 0, others_below = 0;       // WIDE: the frame's channels in the workgroup's other waves (all of them / the lower ones)
+            if (WIDE) {
+#pragma unroll
+                for (uint32_t v = 0; v < 4; v++) if (v >= CN) noise_nd[v] = 0;      // (dummy units repeat the last channel: they draw nothing)
+                if (lane < 4) xnd[wv * 4 + lane] = lane == 0 ? noise_nd[0] : (lane == 1 ? noise_nd[1] : (lane == 2 ? noise_nd[2] : noise_nd[3]));
+                __syncthreads();
+                for (uint32_t w = 0; w < (blockDim.x >> 6); w++) {
+                    if (w == wv) continue;
+                    const uint32_t t = xnd[w * 4] + xnd[w * 4 + 1] + xnd[w * 4 + 2] + xnd[w * 4 + 3];
+                    others_all += t; others_below += w < wv ? t : 0u;
+                }
+                __syncthreads();                           // (the slots are written again in the next step's setup)
+            }
 #pragma unroll
             for (uint32_t v = 0; v < 4; v++) {
                 const uint32_t gv = v / C;
-                uint32_t per_sf = 0, below_c = 0;
+                uint32_t per_sf = others_all, below_c = others_below;
 #pragma unroll
                 for (uint32_t w = 0; w < 4; w++) if (w / C == gv) { per_sf += noise_nd[w]; if (w < v) below_c += noise_nd[w]; }
                 const uint32_t st = lcg_jump(1u, __builtin_amdgcn_readlane(p.dr, v) + sf0 * per_sf + below_c);
@@ -2122,53 +2136,54 @@ size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
     return plain ? base : base + (size_t)C * 128 * 4 + 2048 + 512 + 64 + C * 128 + 128 + 128 + ((C * 8 + 15) & ~15) + (C * 4 + 4) * 4 + 2 * C * 128 + 64;
 }
 
+// Which transform kernel a format group takes (also reported to callers: cri_job_hca_groups)
+uint32_t hca_transform_form(const HcaDecArgs& a) {
+    const bool in_regs = a.channels <= 8 && (a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even));
+    if (!in_regs) return HCA_TR_GENERIC;
+    const bool small = a.channels == 1 || a.channels == 2 || a.channels == 4;
+    if (a.plain) return small ? HCA_TR_INLANE_PLAIN : (HCA_TR_INLANE_PLAIN | HCA_TR_WIDE);       // 3, 5, 6, 7, 8 channels: a wave per four channels, whole sample frames out
+    if (a.inlane) {
+        const bool wide = a.channels == 3 || a.channels > 4 || !a.pairs_even;                      // the wide joint form: a wave per group of channels
+        return (a.noise_fill ? HCA_TR_INLANE_NOISE : HCA_TR_INLANE_JOINT) | (wide ? HCA_TR_WIDE : 0u);
+    }
+    return HCA_TR_GENERAL;
+}
+
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s) {
     if (!a.frames) return;
     if (a.noise_fill) hipLaunchKernelGGL(k_hca_noise_scan, dim3(a.stream_end - a.stream_begin), dim3(64), 0, s, a);
-    const bool in_regs = a.channels <= 8 && (a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even));
-    if (in_regs) {
-        const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
-        const bool flt = a.float_out != nullptr;
-        const uint32_t nruns = a.run_count ? a.run_count : a.runs;
-#define CRI_LAUNCH_TR(P, CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform<P, CH, true>), dim3(nruns), dim3(64), lds, s, a); \
-                                  else hipLaunchKernelGGL((k_hca_transform<P, CH, false>), dim3(nruns), dim3(64), lds, s, a); } while (0)
-#define CRI_LAUNCH_PL(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, false>), dim3(nruns), dim3(64), HCA_PLAIN_LDS, s, a); \
-                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, false>), dim3(nruns), dim3(64), HCA_PLAIN_LDS, s, a); } while (0)
-#define CRI_LAUNCH_PJ(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true>), dim3(nruns), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); \
-                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_JOINT_LDS, s, a); } while (0)
-#define CRI_LAUNCH_PN(CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, true, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_NOISE_LDS, s, a); \
-                               else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, true, false, true>), dim3(nruns), dim3(64), HCA_PLAIN_NOISE_LDS, s, a); } while (0)
-        if (a.plain) switch (a.channels) {
-            case 1: CRI_LAUNCH_PL(1); break;
-            case 2: CRI_LAUNCH_PL(2); break;
-            case 4: CRI_LAUNCH_PL(4); break;
-            default: {                                     // 3, 5, 6, 7, 8 channels: a wave per four channels, whole sample frames out
-                const uint32_t nw = a.wide_waves;
-                const size_t wlds = nw * HCA_PLAIN_LDS + 2048 + 128;
-                if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
-                else hipLaunchKernelGGL((k_hca_transform_plain<4, false, false, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
-            } break;
-        } else if (a.inlane && !a.noise_fill && (a.channels == 3 || a.channels > 4 || !a.pairs_even)) {      // the wide joint form: a wave per group of channels
-            const uint32_t nw = a.wide_waves;
-            const size_t wlds = nw * HCA_PLAIN_JOINT_LDS + 2048 + 128;
-            if (flt) hipLaunchKernelGGL((k_hca_transform_plain<4, true, true, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
-            else hipLaunchKernelGGL((k_hca_transform_plain<4, false, true, true>), dim3(nruns), dim3(64 * nw), wlds, s, a);
-        } else if (a.inlane && a.noise_fill) switch (a.channels) {
-            case 1: CRI_LAUNCH_PN(1); break; case 2: CRI_LAUNCH_PN(2); break; default: CRI_LAUNCH_PN(4); break;
-        } else if (a.inlane) switch (a.channels) {
-            case 1: CRI_LAUNCH_PJ(1); break; case 2: CRI_LAUNCH_PJ(2); break; default: CRI_LAUNCH_PJ(4); break;
-        } else switch (a.channels) {
-            case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;
-            case 6: CRI_LAUNCH_TR(false, 6); break; default: CRI_LAUNCH_TR(false, 8); break;
-        }
-#undef CRI_LAUNCH_TR
-#undef CRI_LAUNCH_PL
-#undef CRI_LAUNCH_PJ
-#undef CRI_LAUNCH_PN
-    } else {
+    const uint32_t form = hca_transform_form(a);
+    if (form == HCA_TR_GENERIC) {
         size_t lds = (size_t)a.channels * (2 * 128 + 2 * TR_DSTRIDE) * 4 + a.channels * 256 + ((a.channels * 8 + 15) & ~15u) + a.channels * (8 + 256) + 16;
         hipLaunchKernelGGL(k_hca_transform_generic, dim3(a.frames), dim3(64), lds, s, a);
+        return;
     }
+    const size_t lds = hca_transform_lds_bytes(a.channels, a.plain != 0);
+    const bool flt = a.float_out != nullptr;
+    const uint32_t nruns = a.run_count ? a.run_count : a.runs;
+    const uint32_t nw = a.wide_waves;
+#define CRI_LAUNCH_TR(P, CH) do { if (flt) hipLaunchKernelGGL((k_hca_transform<P, CH, true>), dim3(nruns), dim3(64), lds, s, a); \
+                                  else hipLaunchKernelGGL((k_hca_transform<P, CH, false>), dim3(nruns), dim3(64), lds, s, a); } while (0)
+#define CRI_LAUNCH_IL(CH, JOINT, WIDE, NOISE, THREADS, BYTES) do { if (flt) hipLaunchKernelGGL((k_hca_transform_plain<CH, true, JOINT, WIDE, NOISE>), dim3(nruns), dim3(THREADS), BYTES, s, a); \
+                                                                   else hipLaunchKernelGGL((k_hca_transform_plain<CH, false, JOINT, WIDE, NOISE>), dim3(nruns), dim3(THREADS), BYTES, s, a); } while (0)
+#define CRI_LAUNCH_124(JOINT, NOISE, BYTES) switch (a.channels) { case 1: CRI_LAUNCH_IL(1, JOINT, false, NOISE, 64, BYTES); break; \
+                                                                  case 2: CRI_LAUNCH_IL(2, JOINT, false, NOISE, 64, BYTES); break; default: CRI_LAUNCH_IL(4, JOINT, false, NOISE, 64, BYTES); break; }
+    switch (form) {
+        case HCA_TR_INLANE_PLAIN: CRI_LAUNCH_124(false, false, HCA_PLAIN_LDS); break;
+        case HCA_TR_INLANE_JOINT: CRI_LAUNCH_124(true, false, HCA_PLAIN_JOINT_LDS); break;
+        case HCA_TR_INLANE_NOISE: CRI_LAUNCH_124(true, true, HCA_PLAIN_NOISE_LDS); break;
+        case HCA_TR_INLANE_PLAIN | HCA_TR_WIDE: CRI_LAUNCH_IL(4, false, true, false, 64 * nw, nw * HCA_PLAIN_LDS + 2048 + 128 + 64); break;
+        case HCA_TR_INLANE_JOINT | HCA_TR_WIDE: CRI_LAUNCH_IL(4, true, true, false, 64 * nw, nw * HCA_PLAIN_JOINT_LDS + 2048 + 128 + 64); break;
+        case HCA_TR_INLANE_NOISE | HCA_TR_WIDE: CRI_LAUNCH_IL(4, true, true, true, 64 * nw, nw * HCA_PLAIN_NOISE_LDS + 2048 + 128 + 64); break;
+        default:                                           // the general in-register transform: spectra assembled through LDS
+            switch (a.channels) {
+                case 1: CRI_LAUNCH_TR(false, 1); break; case 2: CRI_LAUNCH_TR(false, 2); break; case 4: CRI_LAUNCH_TR(false, 4); break;
+                case 6: CRI_LAUNCH_TR(false, 6); break; default: CRI_LAUNCH_TR(false, 8); break;
+            }
+    }
+#undef CRI_LAUNCH_TR
+#undef CRI_LAUNCH_IL
+#undef CRI_LAUNCH_124
 }
 
 }  // namespace cri

@@ -302,3 +302,40 @@ def test_adx_segmented_decode_through_runs_of_silence(cc, knobs, warm):
     assert not st.any() and not job.host_status.any()
     for i, (o, f) in enumerate(zip(outs, files)):
         assert bytes(o) == O.adx_decode(f), i
+
+
+# ------------------------------------------------------------------------------------------------ a20: v3.0 noise fill on the wide in-lane form
+@pytest.mark.parametrize("ch,q", [(3, 1), (5, 1), (6, 1), (6, 2), (7, 1), (8, 1), (8, 2)])
+def test_hca_v3_noise_fill_on_wide_layouts(cc, ch, q):
+    """reconstruct_noise (hca.cpp:1602-1635) for 3 and 5 .. 8 channels runs on the wide instance of the in-lane transform: the
+    generator's draws run on through a frame's channels, so the workgroup's waves (four channels each) trade their draw counts per
+    step.  Streams re-headed as v3.0 with min_resolution 0 (every band under the noise level is reconstructed), longer than a run
+    of eight frames, encrypted and plain: PCM and the floats before the int16 conversion equal to the oracle's, bit for bit."""
+    import hca_forge
+    import torch
+    from pycricodecs_amd.batch import Job
+    items, keys = [], []
+    for k, n in enumerate((1024 * 19 + 300, 5000, 1024 * 9)):
+        h = hca_forge.forge_v3(O.hca_encode(synth.wav(8800 + 10 * ch + k, n, ch, 48000), q), 0)
+        try:
+            O.hca_decode(h)
+        except O.OracleError:
+            continue                                               # (a layout the reference rejects under a v3.0 header)
+        if k == 1:
+            h = O.hca_crypt(h, 1, 56, KEY)
+        items.append(h); keys.append(KEY if k == 1 else 0)
+    if not items:
+        pytest.skip("the reference rejects this layout under a v3.0 header")
+    job = Job.hca_decode(items, keys=keys)
+    assert all(f == (4 | 8) for f in job.transform_forms()), job.transform_forms()
+    bufs = job.alloc("cuda:0")
+    d_f, offs = job.run_floats(*bufs)
+    torch.cuda.synchronize()
+    assert int(bufs[3].abs().sum().item()) == 0
+    outs = job.split(bytes(bufs[1].cpu().numpy()))
+    fl = d_f.cpu().numpy()
+    for i, (h, key) in enumerate(zip(items, keys)):
+        assert bytes(outs[i]) == O.hca_decode(h, key), (ch, q, i)
+        want = O.hca_decode_float(h, key)
+        got = fl[int(offs[i]):int(offs[i + 1])]
+        assert got.size == want.size and np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).reshape(-1).view(np.uint32)), (ch, q, i)
