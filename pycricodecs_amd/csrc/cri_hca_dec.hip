@@ -193,13 +193,8 @@ __device__ __forceinline__ void feed_issue(BitFeed& f, uint32_t n, bool ask, uin
         if (want0) c0 = load_chunk_guarded(f.next, f.in_end);
         if (want1) c1 = load_chunk_guarded(f.next + 16, f.in_end);
     } else {
-#ifdef HCA_ABL_NOLOAD
-        if (want0) c0 = make_uint4((uint32_t)(uintptr_t)f.next, 1, 2, 3);                       // (timing experiment: no input loads)
-        if (want1) c1 = make_uint4((uint32_t)(uintptr_t)f.next, 5, 6, 7);
-#else
         if (want0) c0 = ld_u128_unaligned(f.next);
         if (__any(want1)) { if (want1) c1 = ld_u128_unaligned(f.next + 16); }
-#endif
     }
     if (ask) {
         const int adv = (int)(n > 1 ? nb0 + nb1 : (n > 0 ? nb0 : 0u));
@@ -219,13 +214,8 @@ __device__ __forceinline__ void feed_issue_wave(BitFeed& f, uint32_t n, bool ask
     const uint8_t* p0 = f.next;
     const uint8_t* p1 = f.next + 16;
     const uint32_t sh0 = p0 > lim ? (uint32_t)(p0 - lim) : 0u, sh1 = p1 > lim ? (uint32_t)(p1 - lim) : 0u;
-#ifdef HCA_ABL_NOLOAD
-    if (__any(want0)) c0 = make_uint4((uint32_t)(uintptr_t)f.next, 1, 2, 3);
-    if (__any(want1)) c1 = make_uint4((uint32_t)(uintptr_t)f.next, 5, 6, 7);
-#else
     if (__any(want0)) c0 = ld_u128_unaligned(p0 > lim ? lim : p0);
     if (__any(want1)) c1 = ld_u128_unaligned(p1 > lim ? lim : p1);
-#endif
     if (ask) {
         const int adv = (int)(n > 1 ? nb0 + nb1 : (n > 0 ? nb0 : 0u));
         f.next += adv; f.bytes_left = left - adv;
@@ -357,9 +347,6 @@ __device__ __forceinline__ void flush16(const uint32_t* ostage, uint8_t* recq, u
         const uint32_t* src = ostage + wq * OST + fr;
         const uint4 v = make_uint4(src[0], src[OST], src[2 * OST], src[3 * OST]);
         uint4* dst = (uint4*)(recq + (size_t)it * rb16 + byte_off);
-#ifdef HCA_ABL_NOSTORE
-        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)          // (timing experiment: the stores practically never happen)
-#endif
         if (all) *dst = v;
         else if (fr < nvalid && wq < nwords) *dst = v;
     }
@@ -377,9 +364,6 @@ __device__ __forceinline__ void flush16_qc(const uint32_t* ostage, uint8_t* qc_t
         const uint32_t* src = ostage + wq * OST + fr;
         const uint4 v = make_uint4(src[0], src[OST], src[2 * OST], src[3 * OST]);
         uint4* dst = (uint4*)(qc_tile + qoff + it * 1024 + lane * 16);
-#ifdef HCA_ABL_NOSTORE
-        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
-#endif
         // (streaming stores: nobody reads the lines before the transform kernel, and the wave waits for its stores at the bottom
         //  of the next block together with its loads -- 9.17 -> 8.80 ms for the kernel)
         typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -656,11 +640,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
                 const uint32_t thresh = (nt & 0x7F) + ((uint32_t)needtab[nc * 8 + nb] & 0x7F) + 2;
                 const uint4 mv = mv_next;
                 pend.run(ostage, recq, qc_tile, rb16, nvalid, lane);      // the previous block's lines
-#ifdef HCA_ABL_NOMETA
-                mv_next = make_uint4(0x82828282u + nc, 0x82828282u, 0x82828282u, 0x82828282u + nb);   // (timing experiment: no code-description loads)
-#else
                 mv_next = metag[(nc * 8 + nb) * 64];
-#endif
                 uint4 c0, c1;
                 if (ck == 0 || __any(fd.wr - bb.rd < thresh)) feed_request(fd, bb, ck == 0, thresh, c0, c1);   // (most blocks: nothing to ask for)
                 ck = ck + 1 == HCA_FEED_SYNC ? 0 : ck + 1;
@@ -1986,18 +1966,12 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
         if (WIDE) {                                        // the workgroup's 256 * CT bytes: 16 per thread
             if (threadIdx.x * 16 < 256 * CT) {
                 const uint4 vw = ((const uint4*)pcmw)[threadIdx.x];
-#ifdef HCA_ABL_NOPCM
-                if (vw.x == 0x12345678u && vw.y == 0x9abcdef0u)
-#endif
                 *(u4u*)((uint32_t*)(dst + (uint64_t)(pend_n00 - st.delay) * CT * 2) + 4 * threadIdx.x) = u4u{vw.x, vw.y, vw.z, vw.w};
             }
             pend_n00 = 0xFFFFFFFFu;
             return;
         }
         const uint4 v = ((const uint4*)pcm)[lane];
-#ifdef HCA_ABL_NOPCM
-        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)      // (timing experiment: the stores practically never happen)
-#endif
         *(u4u*)((uint32_t*)(dst + (uint64_t)(pend_n00 - st.delay) * C * 2) + gk * h * 512 * C + wi) = u4u{v.x, v.y, v.z, v.w};
         pend_n00 = 0xFFFFFFFFu;
     };
@@ -2027,11 +2001,7 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
                     const bool more = s + 1 < (int)h;
                     p = rec_run + (next_rows + (more ? lane_off(my_narrow(pre)) : loff)); ld8 = NW && (more ? all_narrow(pre) : step_narrow);
                 }
-#ifdef HCA_ABL_NOLINES
-                q.x = (uint32_t)(uintptr_t)p & 0x03030303u; q.y = 0x01010101u;      // (timing experiment: no line loads)
-#else
                 if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);             // (keep the load here: the compiler would sink it behind most of the DCT)
             dct4_inplace(x, L);
