@@ -887,28 +887,39 @@ __device__ __forceinline__ void seg_block(const uint4& cw, int32_t scale, int32_
 // a row's samples to the WAV: sample i of channel ch at ((row * 32 + i) * C + ch) * 2.  Whole rows of mono / stereo files leave
 // as 64 contiguous bytes per lane (stereo: the two lanes of a pair trade halves, so that lane ch stores half ch of the row's
 // 128 interleaved bytes); anything else sample by sample.  `fast` must be the same in both lanes of a stereo pair.
+// a whole row of a mono / stereo file as the 64 contiguous bytes this lane owns (stereo: the two lanes of a pair trade halves, so that
+// lane ch holds half ch of the row's 128 interleaved bytes)
+__device__ __forceinline__ void seg_row_pack(const SegLane& X, const int32_t (&s)[32], uint32_t (&o)[16]) {
+    uint32_t P[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) P[j] = __builtin_amdgcn_perm((uint32_t)s[2 * j + 1], (uint32_t)s[2 * j], 0x05040100u);
+    if (X.S.channels == 2) {
+        const bool hi = X.ch != 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t keep = hi ? P[8 + j] : P[j], send = hi ? P[j] : P[8 + j];
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // the pair's other lane (lane ^ 1)
+            const uint32_t L = hi ? recv : keep, R = hi ? keep : recv;
+            o[2 * j] = __builtin_amdgcn_perm(R, L, 0x05040100u);
+            o[2 * j + 1] = __builtin_amdgcn_perm(R, L, 0x07060302u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) o[j] = P[j];
+    }
+}
+__device__ __forceinline__ uint8_t* seg_row_address(const SegLane& X, uint32_t row) {
+    const uint32_t C = X.S.channels;
+    return X.dst + ((uint64_t)row * 32 * C + (C == 2 ? X.ch * 32 : 0)) * 2;
+}
+// a row's samples to the WAV: sample i of channel ch at ((row * 32 + i) * C + ch) * 2.  Whole rows of mono / stereo files leave
+// as 64 contiguous bytes per lane; anything else sample by sample.  `fast` must be the same in both lanes of a stereo pair.
 __device__ __forceinline__ void seg_store_row(const SegLane& X, uint32_t row, const int32_t (&s)[32], bool fast) {
     const uint32_t C = X.S.channels;
     if (fast && C <= 2) {
-        uint32_t P[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) P[j] = __builtin_amdgcn_perm((uint32_t)s[2 * j + 1], (uint32_t)s[2 * j], 0x05040100u);
         uint32_t o[16];
-        if (C == 2) {
-            const bool hi = X.ch != 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t keep = hi ? P[8 + j] : P[j], send = hi ? P[j] : P[8 + j];
-                const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // the pair's other lane (lane ^ 1)
-                const uint32_t L = hi ? recv : keep, R = hi ? keep : recv;
-                o[2 * j] = __builtin_amdgcn_perm(R, L, 0x05040100u);
-                o[2 * j + 1] = __builtin_amdgcn_perm(R, L, 0x07060302u);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; j++) o[j] = P[j];
-        }
-        uint4* q = (uint4*)(X.dst + ((uint64_t)row * 32 * C + (C == 2 ? X.ch * 32 : 0)) * 2);
+        seg_row_pack(X, s, o);
+        uint4* q = (uint4*)seg_row_address(X, row);
 #pragma unroll
         for (int j = 0; j < 4; j++) q[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
         return;
@@ -957,6 +968,8 @@ __device__ __forceinline__ uint32_t seg_idle_advance(int32_t c0, int32_t c1, uin
 }
 
 __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t seg_stage[64 * 80];      // a row of 64 bytes per lane, 80 apart (off each other's banks)
+    __shared__ uint8_t* seg_to[64];
     const uint32_t lane = threadIdx.x, g = blockIdx.x * 64 + lane;
     SegLane X;
     seg_locate(a, g, X);
@@ -984,6 +997,7 @@ __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
     for (uint32_t t = 0; t < nmax; t++) {
         const bool act = t < n;
         const uint32_t row = X.w0 + t;
+        uint8_t* row_to = nullptr;                                   // where this lane's staged row goes (null: nothing staged)
         const uint4 ccw = cw; const uint32_t cword = word; const bool cends = ends;
         fetch(row + 1, act && t + 1 < n && !stopped && !cends);
         if (act) {
@@ -999,8 +1013,28 @@ __global__ __launch_bounds__(64) void k_adx_seg_decode(AdxArgs a) {
 #pragma unroll
                 for (int i = 0; i < 32; i++) s[i] = 0;                 // rows never reached decode to silence
             }
-            if (row >= X.r0) seg_store_row(X, row, s, (uint64_t)(row + 1) * 32 <= S.samples);
+            if (row >= X.r0) {
+                if (S.channels <= 2 && (uint64_t)(row + 1) * 32 <= S.samples) {      // a whole row: through the wave's staging piece (below)
+                    uint32_t o[16];
+                    seg_row_pack(X, s, o);
+                    uint4* sl = (uint4*)(seg_stage + lane * 80);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sl[j] = make_uint4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+                    row_to = seg_row_address(X, row);
+                } else seg_store_row(X, row, s, false);
+            }
         }
+        // The lanes' rows lie megabytes apart; stored lane by lane each instruction wrote 64 sixteen-byte pieces (1.46 x the PCM in
+        // WRITE_SIZE).  Through LDS, four consecutive lanes store one lane's 64 bytes -- eight a stereo pair's whole 128-byte line.
+        seg_to[lane] = row_to;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t L = 16 * j + (lane >> 2), qq = lane & 3;
+            uint8_t* to = seg_to[L];
+            if (to) *(uint4*)(to + 16 * qq) = *(const uint4*)(seg_stage + L * 80 + 16 * qq);
+        }
+        wave_lds_sync();
     }
     if (X.valid) {
         uint32_t* rec = a.seg_state + 4 * (uint64_t)g;
