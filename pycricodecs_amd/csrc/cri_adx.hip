@@ -1335,10 +1335,15 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass
         uint32_t wn = X.valid && X.r1 > X.r0 ? X.r0 - warm_from : 0, wmax = wn;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)wmax, o); wmax = t > wmax ? t : wmax; }
+        // (rows fetched one ahead, as in the segment's loop below: two thirds of a lane's rows are warm-up rows, and a lane alone on
+        //  its SIMD waited a memory round trip for every one of them)
+        uint32_t wcur[16] = {};
+        bool wcur_ok = wn > 0 && enc_lane_fetch(X, warm_from, wcur);
         for (uint32_t t = 0; t < wmax; t++) {
             if (t < wn) {
                 int32_t x[32];
-                enc_lane_load(X, warm_from + t, x);
+                if (wcur_ok) enc_lane_unpack(X, wcur, x); else enc_lane_load(X, warm_from + t, x);
+                wcur_ok = t + 1 < wn && enc_lane_fetch(X, warm_from + t + 1, wcur);
                 uint32_t word, cw[4];
                 enc_lane_block(S, x, h1, h2, word, cw);
             }
