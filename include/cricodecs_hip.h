@@ -94,7 +94,11 @@ int cri_get_device(void);         /* the calling thread's current device, -1 wit
 /* ---------------------------------------------------------------------------------------------------------
  * Batch jobs, device resident.  A job is built on the host from the items' headers only, then run any number
  * of times on device buffers (inputs already in HBM, outputs stay in HBM); nothing in cri_job_run allocates
- * or synchronises, so it can be captured in a hipGraph.
+ * or synchronises, so it can be captured in a hipGraph (tests/test_gpu_round4.py::test_job_run_captured_in_a_hip_graph
+ * replays one capture per job kind).
+ * Lifetime: a run's kernels read the job's metadata.  cri_job_destroy waits for the last run that was ENQUEUED through
+ * cri_job_run (an event behind its last kernel) before that memory is reused -- a job may be destroyed while its work is in
+ * flight.  A run captured into a graph leaves no such event: the job must outlive every launch of a graph that holds it.
  *
  * Items are described AFS2-style: one blob + offsets[n+1]; item i = blob[offsets[i], offsets[i+1]).
  * The device input handed to cri_job_run must be a byte-identical copy of that blob.

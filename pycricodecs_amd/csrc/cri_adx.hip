@@ -1488,7 +1488,7 @@ void launch_adx_encode_seg(const AdxArgs& a, hipStream_t s) {
 
 void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s) {
     if (!a.seg_lanes) return;
-    constexpr uint32_t ROUNDS = 3;
+    constexpr uint32_t ROUNDS = 6;      // (a round with nothing to repair costs a launch; a chain that is still moving after the last one costs its whole file on the wave-per-file kernel -- 1.6 ms for a 2 s clip, however large the job)
     hipLaunchKernelGGL(k_adx_seg_decode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a);
     for (uint32_t r = 0; r < ROUNDS; r++) hipLaunchKernelGGL(k_adx_seg_fix, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, r, r + 1 == ROUNDS ? 1u : 0u);
     // Flagged chains.  Histories do not always merge: through digital silence the decoder's state just sits where the last sound left
