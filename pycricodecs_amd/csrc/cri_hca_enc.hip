@@ -161,7 +161,9 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const uint8_t
 
 // CT = channels of the format (1 .. 8); workgroup = FPG frames x CT waves
 template <int CT>
-__global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT), ENC_MIN_WAVES_PER_SIMD) void k_hca_encode(HcaEncArgs a) {
+// (five and six channels: workgroups of five / six waves fill a CU's sixteen register-limited wave slots with two workgroups -- 12 waves; at five
+//  waves per SIMD three fit, and the spills that budget costs are the smaller loss: 153 -> see DESIGN section 2)
+__global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT), (CT == 5 || CT == 6) ? ENC_MIN_WAVES_PER_SIMD + 1 : ENC_MIN_WAVES_PER_SIMD) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t C = CT;
     constexpr bool XCH = C > 1;                            // the frame's waves exchange through LDS, a workgroup barrier each time
