@@ -1432,6 +1432,7 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
         HcaEncArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
         a.channels = F.channels; a.frame_size = F.frame_size; a.crc_chunk = (F.frame_size - 2 + 63) / 64;
+        a.joint = F.stereo_bands > 0 ? 1u : 0u;
         j->hca_enc_crc_off.push_back((uint32_t)crcmul.size());
         for (uint32_t l = 0; l < 64; l++) {
             uint32_t v = crc_xpow_bytes(a.crc_chunk * (63 - l));

@@ -111,7 +111,7 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 #define ENC_CH_SFAC 6400     // uint8[128]
 #define ENC_CH_HAVG 6528     // float[8]
 #define ENC_CH_HFRS 6560     // int[8]
-#define ENC_CH_RATIO 6592    // float[8]
+#define ENC_CH_RATIO 6592    // float[8]       (with the two pieces before it: the 24 sums of EncodeIntensityStereo)
 #define ENC_CH_BYTES 6624
 
 struct EncFmt {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     float* sp = (float*)(chb + ENC_CH_SPEC);
     int16_t* stg = (int16_t*)(chb + ENC_CH_STG);
     uint8_t* sfac = chb + ENC_CH_SFAC;
-    float* havg = (float*)(chb + ENC_CH_HAVG); int* hfrs = (int*)(chb + ENC_CH_HFRS); float* ratio_l = (float*)(chb + ENC_CH_RATIO);
+    float* havg = (float*)(chb + ENC_CH_HAVG); int* hfrs = (int*)(chb + ENC_CH_HFRS);
     const uint32_t tidf = c * 64 + lane;                   // thread within the frame
 #ifdef CRI_ENC_PROFILE
     unsigned long long prof_acc[16] = {0}; unsigned long long prof_t = __builtin_readcyclecounter();
@@ -343,30 +343,54 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         __syncthreads();                                   // both channels' spectra are in LDS
         if (mytype == CRI_CH_PRIMARY && c + 1 < C) {
             float* lsp = sp; float* rsp = (float*)(chb + ENC_CH_BYTES + ENC_CH_SPEC);
+            // the three sums of a subframe are three chains of sequential adds (hca.cpp:2571-2577): a lane each -- lanes 0-7 sum |l|,
+            // 8-15 |r|, 16-23 |l + r| -- eight bands fetched ahead of the adds
+            float* sums = havg;                                // [24] (the HFR averages use this piece later)
+            if (lane < 24) {
+                const uint32_t sfl = lane & 7, kind = lane >> 3;
+                const float* l = lsp + sfl * 128; const float* r = rsp + sfl * 128;
+                float acc = 0;
+                uint32_t b = F.base;
+                for (; b + 8 <= F.total; b += 8) {
+                    float t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const float lv = l[b + k], rv = r[b + k]; t[k] = fabsf(kind == 0 ? lv : (kind == 1 ? rv : lv + rv)); }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc += t[k];
+                }
+                for (; b < F.total; b++) { const float lv = l[b], rv = r[b]; acc += fabsf(kind == 0 ? lv : (kind == 1 ? rv : lv + rv)); }
+                sums[lane] = acc;
+            }
+            wave_lds_sync();
+            float myratio = 1.0f;                              // lanes 0-7: the subframe's ratio
             if (lane < 8) {
-                const float* l = lsp + lane * 128; const float* r = rsp + lane * 128;
-                float el = 0, er = 0, et = 0;
-                for (uint32_t b = F.base; b < F.total; b++) { el += fabsf(l[b]); er += fabsf(r[b]); et += fabsf(l[b] + r[b]); }
+                const float el = sums[lane], er = sums[8 + lane];
+                float et = sums[16 + lane];
                 et *= 2;
                 const float elr = er + el;
                 const float stored = 2 * el / elr;
                 float ratio = elr / et;
                 if (ratio < 0.5) ratio = 0.5f;
                 else if ((double)ratio > sqrt(2.0) / 2) ratio = (float)(sqrt(2.0) / 2);
+                // the first entry of the descending table below the stored value (hca.cpp:2591-2593) = one more than the entries 1 .. 12 at or above it
                 int q = 1;
-                if (er > 0 || el > 0) { while (q < 13 && T.ibounds[q] >= stored) q++; }
-                else { q = 0; ratio = 1; }
+#pragma unroll
+                for (int k = 1; k < 13; k++) q += T.ibounds[k] >= stored ? 1 : 0;
+                if (!(er > 0 || el > 0)) { q = 0; ratio = 1; }
                 X_inten[(c + 1) * 8 + lane] = (uint8_t)q;
-                ratio_l[lane] = ratio;
+                myratio = ratio;
             }
-            wave_lds_sync();
-            for (uint32_t sf = 0; sf < 8; sf++) {
-                const float ratio = ratio_l[sf];
-                for (uint32_t b = F.base + lane; b < F.total; b += 64) {
-                    const float s = lsp[sf * 128 + b] + rsp[sf * 128 + b];
-                    lsp[sf * 128 + b] = s * ratio;
-                    rsp[sf * 128 + b] = 0;
-                }
+            // (l + r) * ratio into the primary, zeros into the secondary: a lane takes a band of all eight subframes, everything
+            // fetched before anything is stored
+            float rt[8];
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) rt[sf] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(myratio), sf));
+            for (uint32_t b = F.base + lane; b < F.total; b += 64) {
+                float sv[8];
+#pragma unroll
+                for (int sf = 0; sf < 8; sf++) sv[sf] = lsp[sf * 128 + b] + rsp[sf * 128 + b];
+#pragma unroll
+                for (int sf = 0; sf < 8; sf++) { lsp[sf * 128 + b] = sv[sf] * rt[sf]; rsp[sf * 128 + b] = 0; }
             }
         }
         __syncthreads();
@@ -747,8 +771,10 @@ size_t hca_encode_lds_per_frame(uint32_t C, uint32_t frame_size) {
     return ENC_X_BYTES + ((nwords * 4 + 15) & ~(size_t)15) + (size_t)C * ENC_CH_BYTES;
 }
 // frames per workgroup
-uint32_t hca_encode_frames_per_group(uint32_t C, uint32_t frame_size) {
-    uint32_t fpg = C >= ENC_MAX_WAVES ? 1 : ENC_MAX_WAVES / C;
+uint32_t hca_encode_frames_per_group(uint32_t C, uint32_t frame_size, bool joint = false) {
+    // (formats with intensity stereo: the pair's secondary waits at two barriers while the primary sums -- with a second frame in the
+    //  workgroup four waves wait for the slowest of four; one frame per workgroup measured +4 % there, -3 % on plain formats)
+    uint32_t fpg = (C >= ENC_MAX_WAVES || (joint && C > 1)) ? 1 : ENC_MAX_WAVES / C;
     while (fpg > 1 && HCA_ET_BYTES + 16 + fpg * hca_encode_lds_per_frame(C, frame_size) > 160 * 1024) fpg--;
     return fpg;
 }
@@ -760,8 +786,8 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
     if (!a.frames || a.channels < 1 || a.channels > 8) return;
     HcaEncArgs b = a;
     b.lds_per_frame = (uint32_t)hca_encode_lds_per_frame(a.channels, a.frame_size);
-    b.frames_per_group = hca_encode_frames_per_group(a.channels, a.frame_size);
-    const size_t lds = hca_encode_lds_bytes(a.channels, a.frame_size);
+    b.frames_per_group = hca_encode_frames_per_group(a.channels, a.frame_size, a.joint != 0);
+    const size_t lds = HCA_ET_BYTES + 16 + b.frames_per_group * hca_encode_lds_per_frame(a.channels, a.frame_size);
     if (lds > 160 * 1024) return;
     const dim3 grid((a.frames + b.frames_per_group - 1) / b.frames_per_group), block(64 * a.channels * b.frames_per_group);
     switch (a.channels) {

@@ -11,7 +11,7 @@ for v in ${VARIANTS:-base -DENC_MAX_WAVES=2 -DENC_ABL_NOBARRIER -DENC_ABL_STEPS=
   /opt/rocm/bin/hipcc $FLAGS $f -x hip -c pycricodecs_amd/csrc/cri_hca_enc.hip -o $L/cri_hca_enc.o 2>/dev/null || { echo "$v: compile failed"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $L/cri_host.o $L/cri_hca_dec.o $L/cri_hca_enc.o $L/cri_adx.o $L/cri_misc.o $L/cri_capi.o -o $L/libcricodecs_hip.so -Wl,-rpath,/opt/rocm/lib
   for ch in ${CHS:-2}; do
-  r=$(timeout 300 python tools/debug/enc_time.py $ch 2>&1 | tail -1)
+  r=$(timeout 300 python tools/debug/enc_time.py $ch ${QUAL:-1} 2>&1 | tail -1)
   echo "$v ch=$ch: $r"
   done
 done

@@ -9,8 +9,9 @@ from pycricodecs_amd import synth, _capi
 from pycricodecs_amd.batch import Job
 lib = _capi.lib()
 ch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+quality = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ws = [synth.wav(i, 480000, ch, 48000) for i in range(8)] * (25 if ch <= 2 else 6)
-job = Job.hca_encode(ws, quality=1)
+job = Job.hca_encode(ws, quality=quality)
 bufs = job.alloc("cuda:0")
 job.run(*bufs); torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()
@@ -25,4 +26,4 @@ names = ["tables + sample staging", "  barrier behind it", "mdct", "intensity st
 tot = sum(out[:12])
 for n, v in zip(names, list(out[:12])):
     print("%-56s %5.1f %%  %8.0f wave-cycles/frame" % (n, 100.0 * v / tot, v / (3.0 * job.units)))
-print("total %.0f wave-cycles per frame (%d channels)" % (tot / (3.0 * job.units), ch))
+print("total %.0f wave-cycles per frame (%d channels, quality %d)" % (tot / (3.0 * job.units), ch, quality))
