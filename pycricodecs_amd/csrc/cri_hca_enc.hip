@@ -106,13 +106,14 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 #define ENC_X_ROWTOT 128     // uint[64]    bits of the 8 x C rows of spectra, in stream order (subframe, channel)
 #define ENC_X_INTEN 384      // uint8[8][8] intensity indices (written by the pair's primary, packed by the secondary)
 #define ENC_X_BYTES 448
-#define ENC_CH_SPEC 0        // float[8][128]  the channel's spectra (MDCT output); afterwards int[130]: boundary-search prefix
-#define ENC_CH_STG 4096      // int16[1152]    the frame's samples of this channel, 128 of history first
-#define ENC_CH_SFAC 6400     // uint8[128]
-#define ENC_CH_HAVG 6528     // float[8]
-#define ENC_CH_HFRS 6560     // int[8]
-#define ENC_CH_RATIO 6592    // float[8]       (with the two pieces before it: the 24 sums of EncodeIntensityStereo)
-#define ENC_CH_BYTES 6624
+#define ENC_CH_SPEC 0        // one piece, three lives: int16[1152] the frame's samples of this channel (128 of history first) until the MDCT has read them;
+#define ENC_CH_STG 0         // float2[8][72] the MDCT's change of places; float[8][128] the channel's spectra (MDCT output); afterwards int[130]: the
+                             // boundary search's prefix
+#define ENC_CH_SFAC 4608     // uint8[128]
+#define ENC_CH_HAVG 4736     // float[8]
+#define ENC_CH_HFRS 4768     // int[8]
+#define ENC_CH_RATIO 4800    // float[8]       (with the two pieces before it: the 24 sums of EncodeIntensityStereo)
+#define ENC_CH_BYTES 4832
 
 struct EncFmt {
     uint32_t frame_size, total, base, stereo, groups, bpg, hfr_band_count, types;
@@ -152,8 +153,11 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const uint8_t
     hbits = min_len; dbits = min_db;
 }
 
-#ifndef ENC_MIN_WAVES_PER_SIMD
-#define ENC_MIN_WAVES_PER_SIMD 4   // register budget (measured: held to 5 waves the kernel spills and loses 6 %)
+// register budget = waves per SIMD the kernel is compiled for, by channel count (measured, tools/debug/enc_ablate.sh)
+#ifdef ENC_MIN_WAVES_PER_SIMD
+#define ENC_WAVES_PER_SIMD(CT) ENC_MIN_WAVES_PER_SIMD
+#else
+#define ENC_WAVES_PER_SIMD(CT) ((CT) >= 5 ? 6 : 5)
 #endif
 #ifndef ENC_MAX_WAVES
 #define ENC_MAX_WAVES 4      // waves of a workgroup when a frame has fewer channels than that (mono: 4 frames, stereo: 2)
@@ -161,9 +165,9 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, const uint8_t
 
 // CT = channels of the format (1 .. 8); workgroup = FPG frames x CT waves
 template <int CT>
-// (five and six channels: workgroups of five / six waves fill a CU's sixteen register-limited wave slots with two workgroups -- 12 waves; at five
-//  waves per SIMD three fit, and the spills that budget costs are the smaller loss: 153 -> see DESIGN section 2)
-__global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT), (CT == 5 || CT == 6) ? ENC_MIN_WAVES_PER_SIMD + 1 : ENC_MIN_WAVES_PER_SIMD) void k_hca_encode(HcaEncArgs a) {
+// (waves per SIMD by channel count: 96 registers -- a few spilled -- for five waves up to four channels, 80 for six from five channels on,
+//  where workgroups of 5 .. 8 waves otherwise leave wave slots empty; the channel regions' LDS (4.8 KB each) leaves room for either)
+__global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT), ENC_WAVES_PER_SIMD(CT)) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t C = CT;
     constexpr bool XCH = C > 1;                            // the frame's waves exchange through LDS, a workgroup barrier each time
