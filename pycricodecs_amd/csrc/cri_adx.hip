@@ -1228,16 +1228,29 @@ __device__ __forceinline__ void enc_lane_load(const EncLane& X, uint32_t row, in
 }
 // ChannelFrame::Encode (adx.cpp:215-273) of one block on registers: the scale word, the 16 code bytes as four little-endian
 // words, the new history.  (The quantiser is k_adx_encode's float form: exact for |delta| capped at (limit + 2) * scale.)
-__device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t (&x)[32], int32_t& h1, int32_t& h2, uint32_t& word, uint32_t (&cw)[4]) {
+// Pass A (adx.cpp:221-230) takes the range of the residuals against the RAW samples before each one -- only the first two of a block see the
+// encoder's own state (its reconstruction of the block before).  enc_lane_range_tail is the part that depends on nothing but the block's own
+// samples (residuals 2 .. 31): k_adx_lane_encode computes it for the NEXT row inside the current row's iteration, where it fills the issue slots
+// that the serial chain of pass B leaves empty (a lane alone on its SIMD issues a dependent instruction every other slot at best).
+__device__ __forceinline__ void enc_lane_range_tail(const AdxStream& S, const int32_t (&x)[32], int32_t& mn, int32_t& mx) {
     const int32_t c0 = S.coef0, c1 = S.coef1;
-    int32_t mn = 0, mx = 0, p1 = h1, p2 = h2;
+    mn = 0; mx = 0;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {                                   // pass A: residual range against the RAW history
-        const int32_t r = ((int32_t)((uint32_t)x[i] << 12) - __mul24(c0, p1) - __mul24(c1, p2)) >> 12;
+    for (int i = 2; i < 32; i++) {
+        const int32_t r = ((int32_t)((uint32_t)x[i] << 12) - __mul24(c0, x[i - 1]) - __mul24(c1, x[i - 2])) >> 12;
         mn = r < mn ? r : mn; mx = r > mx ? r : mx;
-        p2 = p1; p1 = x[i];
     }
-    if (!mn && !mx) { word = 0; cw[0] = cw[1] = cw[2] = cw[3] = 0; h1 = x[31]; h2 = x[30]; return; }      // adx.cpp:231-234: the history stays raw
+}
+__device__ __forceinline__ void enc_lane_block_pre(const AdxStream& S, const int32_t (&x)[32], int32_t mn, int32_t mx, int32_t& h1, int32_t& h2, uint32_t& word, uint32_t (&cw)[4]) {
+    const int32_t c0 = S.coef0, c1 = S.coef1;
+    {   // the first two residuals: against the state the block starts from
+        const int32_t r0 = ((int32_t)((uint32_t)x[0] << 12) - __mul24(c0, h1) - __mul24(c1, h2)) >> 12;
+        const int32_t r1 = ((int32_t)((uint32_t)x[1] << 12) - __mul24(c0, x[0]) - __mul24(c1, h1)) >> 12;
+        mn = r0 < mn ? r0 : mn; mx = r0 > mx ? r0 : mx;
+        mn = r1 < mn ? r1 : mn; mx = r1 > mx ? r1 : mx;
+    }
+    const bool silent = !mn && !mx;                               // adx.cpp:231-234: a block of zeros, and the history stays raw (selected at the end:
+                                                                  // no branch, so that the caller's independent work can share this block's schedule)
     const int32_t qa = mx / 7, qb = (int32_t)((uint32_t)(-mn) >> 3);
     uint32_t scale = (uint32_t)(qa > qb ? qa : qb) & 0xFFFF;
     if (scale > 0x1000) scale = 0x1000;
@@ -1271,7 +1284,15 @@ __device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t
         }
         cw[w] = __builtin_bswap32(acc);
     }
-    h1 = g1; h2 = g2;
+    h1 = silent ? x[31] : g1; h2 = silent ? x[30] : g2;
+    word = silent ? 0u : word;
+#pragma unroll
+    for (int w = 0; w < 4; w++) cw[w] = silent ? 0u : cw[w];
+}
+__device__ __forceinline__ void enc_lane_block(const AdxStream& S, const int32_t (&x)[32], int32_t& h1, int32_t& h2, uint32_t& word, uint32_t (&cw)[4]) {
+    int32_t mn, mx;
+    enc_lane_range_tail(S, x, mn, mx);
+    enc_lane_block_pre(S, x, mn, mx, h1, h2, word, cw);
 }
 // the row's blocks to the file.  Stereo: the pair's 36 bytes are nine aligned words; lane ch 0 stores words 0..4 (the last one
 // carries its own last two code bytes and the partner's scale word), lane ch 1 words 5..8.
@@ -1305,8 +1326,9 @@ __device__ __forceinline__ void enc_lane_store(const EncLane& X, uint32_t row, u
 // so a round reads what the round before left while it writes its own.  A file in which an end state still moved in the last
 // round is flagged (seg_flags = rounds) and walked in order by k_adx_lane_encode_serial.
 //   rec[0] = the state the segment's bytes were encoded from, rec[1] / rec[2] = its end state after the even / odd rounds
-__global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass) {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_adx_lane_encode(AdxArgs a, uint32_t pass) {
+    // (four waves to the workgroup, nothing shared between them: see launch_adx_encode_lane)
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EncLane X;
     enc_lane_locate(a, g, X);
     const AdxStream& S = X.S;
@@ -1335,17 +1357,31 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass
         uint32_t wn = X.valid && X.r1 > X.r0 ? X.r0 - warm_from : 0, wmax = wn;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)wmax, o); wmax = t > wmax ? t : wmax; }
-        // (rows fetched one ahead, as in the segment's loop below: two thirds of a lane's rows are warm-up rows, and a lane alone on
-        //  its SIMD waited a memory round trip for every one of them)
+        // (the same pipeline as the segment's loop below: two thirds of a lane's rows are warm-up rows)
+        int32_t wa[32]; int32_t wmn = 0, wmx = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) wa[i] = 0;
         uint32_t wcur[16] = {};
-        bool wcur_ok = wn > 0 && enc_lane_fetch(X, warm_from, wcur);
+        bool wcur_ok = false;
+        if (wn > 0) {
+            enc_lane_load(X, warm_from, wa);
+            enc_lane_range_tail(S, wa, wmn, wmx);
+            wcur_ok = wn > 1 && enc_lane_fetch(X, warm_from + 1, wcur);
+        }
         for (uint32_t t = 0; t < wmax; t++) {
             if (t < wn) {
-                int32_t x[32];
-                if (wcur_ok) enc_lane_unpack(X, wcur, x); else enc_lane_load(X, warm_from + t, x);
-                wcur_ok = t + 1 < wn && enc_lane_fetch(X, warm_from + t + 1, wcur);
+                const bool has_next = t + 1 < wn, next_whole = wcur_ok;
+                int32_t xb[32];
+                enc_lane_unpack(X, wcur, xb);
+                wcur_ok = t + 2 < wn && enc_lane_fetch(X, warm_from + t + 2, wcur);
+                int32_t qmn, qmx;
                 uint32_t word, cw[4];
-                enc_lane_block(S, x, h1, h2, word, cw);
+                enc_lane_range_tail(S, xb, qmn, qmx);
+                enc_lane_block_pre(S, wa, wmn, wmx, h1, h2, word, cw);
+                if (has_next && !next_whole) { enc_lane_load(X, warm_from + t + 1, xb); enc_lane_range_tail(S, xb, qmn, qmx); }
+#pragma unroll
+                for (int i = 0; i < 32; i++) wa[i] = xb[i];
+                wmn = qmn; wmx = qmx;
             }
         }
         if (X.valid) rec[0] = seg_pack(h1, h2);
@@ -1367,21 +1403,37 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode(AdxArgs a, uint32_t pass
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)nmax, o); nmax = t > nmax ? t : nmax; }
     bool merged = false;
-    uint32_t cur[16] = {};                                           // the current row's raw words, fetched one row ahead
-    bool cur_ok = nrows > 0 && enc_lane_fetch(X, X.r0, cur);
+    // The current row's samples (xa) and the tail of its residual range come from the iteration before; the next row's raw words (cur) were
+    // asked for two rows ahead.  One iteration = unpack the next row, ask for the one after it, then ONE block of code in which the next row's
+    // range (independent work) and this row's serial pass B share the schedule.
+    int32_t xa[32]; int32_t pmn = 0, pmx = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) xa[i] = 0;
+    uint32_t cur[16] = {};
+    bool cur_ok = false;
+    if (nrows > 0) {
+        enc_lane_load(X, X.r0, xa);
+        enc_lane_range_tail(S, xa, pmn, pmx);
+        cur_ok = nrows > 1 && enc_lane_fetch(X, X.r0 + 1, cur);
+    }
     for (uint32_t t = 0; t < nmax; t++) {
         const bool act = run && t < nrows && !merged;
         if (__builtin_expect(!__any(act), 0)) break;
         if (act) {
             const uint32_t row = X.r0 + t;
-            int32_t x[32];
-            if (cur_ok) enc_lane_unpack(X, cur, x); else enc_lane_load(X, row, x);
-            // (the next row's words are asked for AFTER this row's have been taken out of their registers: the compiler waits for every
-            //  outstanding load at that point, and these must not be among them)
-            cur_ok = t + 1 < nrows && enc_lane_fetch(X, row + 1, cur);
+            const bool has_next = t + 1 < nrows, next_whole = cur_ok;
+            int32_t xb[32];
+            enc_lane_unpack(X, cur, xb);                             // (meaningless without a next row: nothing reads it then)
+            cur_ok = t + 2 < nrows && enc_lane_fetch(X, row + 2, cur);
+            int32_t qmn, qmx;
             uint32_t word, cw[4];
-            enc_lane_block(S, x, h1, h2, word, cw);
+            enc_lane_range_tail(S, xb, qmn, qmx);
+            enc_lane_block_pre(S, xa, pmn, pmx, h1, h2, word, cw);
             enc_lane_store(X, row, word, cw, pair);
+            if (has_next && !next_whole) { enc_lane_load(X, row + 1, xb); enc_lane_range_tail(S, xb, qmn, qmx); }      // (a row cut by the end of the input)
+#pragma unroll
+            for (int i = 0; i < 32; i++) xa[i] = xb[i];
+            pmn = qmn; pmx = qmx;
             if (((row + 1) & 3) == 0 || row + 1 == X.r1) {
                 uint32_t* c = ck + (uint64_t)((row + 4) / 4 - 1) * 2;
                 const uint32_t now = seg_pack(h1, h2);
@@ -1473,7 +1525,10 @@ __global__ __launch_bounds__(64) void k_adx_lane_encode_serial(AdxArgs a, uint32
 void launch_adx_encode_lane(const AdxArgs& a, hipStream_t s) {
     if (!a.seg_lanes) return;
     constexpr uint32_t ROUNDS = 4;
-    for (uint32_t pass = 0; pass <= ROUNDS; pass++) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, pass);
+    // (A lane's row is one long dependent chain at the SIMD's full issue rate: the launch takes (the most waves any SIMD was given) x (a
+    //  lane's rows).  Workgroups of four waves land one wave to a SIMD; single-wave workgroups were found two deep on some SIMDs at 625
+    //  waves -- 20 000 files of 1 s: 4.6 ms against 2.8.)
+    for (uint32_t pass = 0; pass <= ROUNDS; pass++) hipLaunchKernelGGL(k_adx_lane_encode, dim3((a.seg_lanes + 255) / 256), dim3(256), 0, s, a, pass);
     hipLaunchKernelGGL(k_adx_lane_encode_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a, ROUNDS);
 }
 

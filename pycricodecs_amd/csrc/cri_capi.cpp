@@ -105,6 +105,13 @@ struct Knobs {
     uint64_t adx_warm_pct = 100;                 // segmented ADX chains: warm-up length in per cent of the planner's
     uint64_t adx_seglen = 0;                     // ... least segment length (decode: in warm-ups, default 3; lane encode: per cent of the warm-up, default 50)
 };
+// SIMDs of the calling thread's device (CUs x 4): the ADX lane kernels run one row after the other in a lane and are bound by instruction
+// issue per SIMD, so what a dispatch costs is (waves per SIMD, rounded UP) x (rows of its longest lane) -- 1.4 waves per SIMD cost what 2 do
+static uint32_t device_simds() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 1024;
+    return (uint32_t)cus * 4;
+}
 static int adx_mapping_of(const char* e) {
     if (!e) return ADX_MAP_AUTO;
     const char* names[] = {"", "chain", "file", "seg", "lane", "wave"};
@@ -1185,7 +1192,32 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
             if (lanes_long >= 98304) short_segments = false;
         }
         auto lane_warm = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (640ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4) : (uint64_t)0; };
-        auto lane_lmin = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (lane_warm(g) * seg_pct / 100 + 3) / 4 * 4)
+        // The least segment length.  With a warm-up the kernel's time is (waves per SIMD, rounded up) x (warm-up + segment): the planner
+        // tries segment lengths from half a warm-up to the whole file and keeps the cheapest -- 1000 files of 10 s: 480 rows (1000 waves on
+        // 1024 SIMDs, 2.2 ms) instead of 320 (1469 waves: every SIMD with two of them sets the pace, 3.4 ms); 12 500 files of 1 s: no cut at
+        // all (391 waves of 1500 rows, 2.8 ms against 4.4).  (adx_seglen, tests only, fixes it instead.)
+        uint64_t best_pct = seg_pct;
+        if (short_segments && !knobs().adx_seglen) {
+            const uint32_t nsimd = device_simds();
+            uint64_t best_cost = ~0ull;
+            for (uint64_t cand = 50; cand <= 6400; cand = cand * 9 / 8 + 1) {
+                uint64_t lanes_c = 0, longest = 0;
+                for (const AdxStream& S : streams) {
+                    const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
+                    if (g <= 0 || !S.frames) { lanes_c += S.channels; longest = std::max<uint64_t>(longest, S.frames); continue; }
+                    const uint64_t warm = lane_warm(g), lmin = std::max<uint64_t>(4, (warm * cand / 100 + 3) / 4 * 4);
+                    uint64_t rows = (std::max<uint64_t>((S.frames + p_target - 1) / p_target, lmin) + 3) / 4 * 4;
+                    if (rows > S.frames) rows = S.frames;
+                    lanes_c += (uint64_t)S.channels * ((S.frames + rows - 1) / rows);
+                    // (a cut file pays the warm-up and, in the repair rounds, about as much again: some lane of nearly every wave has to
+                    //  re-encode until it meets its checkpoints -- measured: 12 500 files of 1 s in two segments 4.7 ms, uncut 2.8)
+                    longest = std::max<uint64_t>(longest, rows + (rows < S.frames ? 2 * warm : 0));
+                }
+                const uint64_t waves = (lanes_c + 63) / 64, cost = ((waves + nsimd - 1) / nsimd) * longest;
+                if (cost < best_cost) { best_cost = cost; best_pct = cand; }
+            }
+        }
+        auto lane_lmin = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (lane_warm(g) * best_pct / 100 + 3) / 4 * 4)
                                                                  : std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4); };
         uint32_t lanes = 0, chains = 0; uint64_t rounds = 0;
         std::vector<int16_t> hist2;
