@@ -103,6 +103,7 @@ struct Knobs {
     // test-only
     int no_inlane = 0;                           // joint / wide / noise formats on the general transform kernels instead of the in-lane ones
     uint64_t adx_warm_pct = 100;                 // segmented ADX chains: warm-up length in per cent of the planner's
+    uint64_t host_pull_wgs = 0;                  // the pipelined host path's upload kernel: workgroups (0: the planner's choice)
     uint64_t adx_seglen = 0;                     // ... least segment length (decode: in warm-ups, default 3; lane encode: per cent of the warm-up, default 50)
 };
 // SIMDs of the calling thread's device (CUs x 4): the ADX lane kernels run one row after the other in a lane and are bound by instruction
@@ -203,6 +204,11 @@ struct cri_job {
     // (MetaPool).  Every cri_job_run leaves an event behind its last kernel; the destructor waits for it before anything is
     // recycled.  A run that is being CAPTURED into a hipGraph records nothing (a captured event cannot be waited for): a job must
     // outlive the launches of a graph that holds it (include/cricodecs_hip.h).
+    // The pipelined host path of jobs that cannot be cut inside (run_host_core): the same work planned again as a few jobs over
+    // consecutive ranges of the items, made on the first host run that wants them and kept.
+    bool partable = false, parts_tried = false;
+    std::vector<cri_job*> host_parts;
+    std::vector<uint32_t> host_part_first;       // [parts + 1] first item of each part
     hipEvent_t last_run = nullptr;
     void note_run(hipStream_t s) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -211,6 +217,7 @@ struct cri_job {
         (void)hipEventRecord(last_run, s);
     }
     ~cri_job() {
+        for (cri_job* part : host_parts) delete part;
         if (last_run) { (void)hipEventSynchronize(last_run); (void)hipEventDestroy(last_run); }
         for (auto& v : class_events) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
@@ -759,11 +766,15 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
 
 extern "C" int cri_job_create_adx_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, cri_job** out) {
     if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
-    return create_adx_decode(ItemSrc::from_blob(blob, offsets, n), out);
+    const int rc = create_adx_decode(ItemSrc::from_blob(blob, offsets, n), out);
+    if (!rc) (*out)->partable = true;
+    return rc;
 }
 extern "C" int cri_job_create_adx_decode_items(const cri_items* items, cri_job** job) {
     ItemSrc it; int rc = ItemSrc::from_items(items, it);
-    return rc ? rc : create_adx_decode(it, job);
+    if (!rc) rc = create_adx_decode(it, job);
+    if (!rc) (*job)->partable = true;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ AWB (AFS2) front door
@@ -1799,6 +1810,41 @@ bool hca_decode_sliceable(const cri_job* j) {
     return true;
 }
 
+// The parts of a job the pipelined path cannot cut inside (an ADX decode job's lanes are laid out by length, not by item: a range of
+// its lanes is not a range of its input): the same items planned again as K jobs over consecutive item ranges of about equal traffic.
+// A part addresses the parent's device input by the parent's own offsets and writes its output where the parent would -- item
+// outputs are 64-byte aligned pieces back to back in both, which the builder checks, part by part.
+bool host_parts_ready(cri_job* j, const HostSrc& src) {
+    if (!j->partable || j->kind != CRI_JOB_ADX_DECODE || j->n < 8) return false;
+    if (j->parts_tried) return !j->host_parts.empty();
+    j->parts_tried = true;
+    uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) / HOST_SLICE_BYTES);
+    K = K < 4 ? 4 : (K > 64 ? 64 : K);
+    if (K > j->n / 2) K = j->n / 2;
+    const uint64_t total = j->in_bytes + j->out_bytes;
+    std::vector<uint32_t> first{0};
+    for (uint32_t i = 1; i < j->n; i++) {
+        const uint64_t at = j->in_offsets[i] + j->out_offsets[i];
+        if (at >= total / K * first.size() && first.size() < K) first.push_back(i);
+    }
+    first.push_back(j->n);
+    bool good = true;
+    for (size_t p = 0; p + 1 < first.size() && good; p++) {
+        const uint32_t i0 = first[p], i1 = first[p + 1];
+        ItemSrc ps;
+        ps.blob = src.blob; ps.offsets = j->in_offsets.data() + i0; ps.n = i1 - i0;
+        if (src.items) { ps.ptrs = src.items->ptrs + i0; ps.lens = src.items->lens + i0; }
+        cri_job* part = nullptr;
+        if (create_adx_decode(ps, &part) || !part) { good = false; break; }
+        j->host_parts.push_back(part);
+        good = part->out_bytes == j->out_offsets[i1] - j->out_offsets[i0];
+        for (uint32_t i = i0; i < i1 && good; i++) good = part->out_offsets[i - i0] == j->out_offsets[i] - j->out_offsets[i0] && part->host_status[i - i0] == j->host_status[i];
+    }
+    if (!good) { for (cri_job* part : j->host_parts) delete part; j->host_parts.clear(); return false; }
+    j->host_part_first = first;
+    return true;
+}
+
 int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_copy, int32_t* status) {
     DeviceGuard guard(j->device);
     if (!guard.ok()) return CRI_ERR_HIP;
@@ -1831,8 +1877,13 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
     //    the call as well.
     // 72 ms for the same job (12.9 M frames/s; the download alone is 67).  The tests run both orders.
     const uint64_t slice_min = knobs().host_slice_min;
-    const bool sliced = hca_decode_sliceable(j) && out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
-    if (!sliced) {
+    const bool large = out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
+    const bool sliced = large && hca_decode_sliceable(j);
+    const bool parted = large && !sliced && host_parts_ready(j, src);
+    if (parted) for (const cri_job* part : j->host_parts) if (!A.ensure(2, part->scratch_bytes)) rc = CRI_ERR_HIP;
+    d_scr = (uint8_t*)A.buf[2];
+    if (rc) { if (&A == &own) own.destroy(); return rc; }
+    if (!sliced && !parted) {
         if (gaps && !j->items_packed) ok(hipMemsetAsync(d_in, 0, j->in_bytes, A.s_run));
         if (!rc) rc = upload_range(j, src, d_in, 0, j->in_bytes, cursor, A.s_run);
         // bytes no kernel writes (alignment gaps, undecoded tails) are defined as zero
@@ -1840,14 +1891,14 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, A.s_run);
         if (!rc && out_copy) ok(hipMemcpyAsync(out, d_out, out_copy, hipMemcpyDeviceToHost, A.s_run));
     } else {
-        // ---- pipelined: the group cut into slices of whole parse tiles; three streams, two events per slice
-        const HcaDecArgs base = j->hca_dec[0];
+        // ---- pipelined: the group cut into slices of whole parse tiles (or the job into its parts); three streams, two events per slice
+        const HcaDecArgs base = sliced ? j->hca_dec[0] : HcaDecArgs{};
         const auto& S = j->hca_streams_host;
         const uint32_t tiles = (base.frames + 63) / 64, ns = (uint32_t)S.size();
         uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) / HOST_SLICE_BYTES);
         K = K < 4 ? 4 : (K > 64 ? 64 : K);
         if (K > tiles) K = tiles;
-        const uint32_t TS = (tiles + K - 1) / K, nslices = (tiles + TS - 1) / TS;
+        const uint32_t TS = sliced ? (tiles + K - 1) / K : 1, nslices = sliced ? (tiles + TS - 1) / TS : (uint32_t)j->host_parts.size();
         for (uint32_t k = 0; k < 2 * nslices + 2; k++) if (!A.event(k)) rc = CRI_ERR_HIP;
         // Page-locked views of the caller's buffers (see the comment above): what is page-locked already is used as it is, a pageable
         // blob or output buffer is locked for the duration of the call, anything else goes through the staging ring.
@@ -1864,10 +1915,13 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
             launch_scatter_images((const uint8_t*)j->d_img.p, (const uint64_t*)j->d_img_off.p, (const uint64_t*)j->d_img_dst.p, j->n_images, d_out, A.s_run);
         uint64_t in_pos = 0, out_pos = 0;
         uint32_t s_need = 0, s_done = 0;                         // streams whose input is up / whose PCM is down
+        // (8 workgroups pull 19 GB/s: enough when the output is 6x the input and more -- HCA -- but not for ADX's 3.6x, where the upload
+        //  of 1000 x 10 s became the longest stage: 44 ms; 16 workgroups: 37 ms, the downloads still at their rate; 32 begin to cost them)
+        const uint32_t pull_wgs = knobs().host_pull_wgs ? (uint32_t)knobs().host_pull_wgs : (j->in_bytes * 5 > j->out_bytes ? 16u : 8u);
         uint32_t slot = 0;
         // device-input bytes [lo, hi) go up on the upload stream
         auto upload = [&](uint64_t lo, uint64_t hi) {
-            if (pull_src) { launch_pull_host(d_in + lo, pull_src + lo, hi - lo, A.s_up); return; }
+            if (pull_src) { launch_pull_host(d_in + lo, pull_src + lo, hi - lo, A.s_up, pull_wgs); return; }
             while (lo < hi && !rc) {
                 const uint64_t n = hi - lo < piece_max ? hi - lo : piece_max;
                 uint8_t* st = (uint8_t*)A.stage[slot];
@@ -1885,7 +1939,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
                     }
                     if (at < lo + n) memset(st + (at - lo), 0, lo + n - at);
                 }
-                launch_pull_host(d_in + lo, st, n, A.s_up);
+                launch_pull_host(d_in + lo, st, n, A.s_up, pull_wgs);
                 ok(hipEventRecord(A.stage_free[slot], A.s_up));
                 A.stage_busy[slot] = true;
                 slot = (slot + 1) % HOST_STAGE_SLOTS;
@@ -1911,8 +1965,26 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
             if (in_end > in_pos) { upload(in_pos, in_end); in_pos = in_end; }
             ok(hipEventRecord(A.event(2 * u), A.s_up));
         };
-        if (!rc) slice_up(0);
-        for (uint32_t k = 0, t0 = 0; t0 < tiles && !rc; k++, t0 += TS) {
+        if (parted) {
+            // part k's items go up while part k - 1 decodes and part k - 2's output comes down
+            auto part_up = [&](uint32_t u) {
+                const uint64_t in_end = j->in_offsets[j->host_part_first[u + 1]];
+                if (in_end > in_pos) { upload(in_pos, in_end); in_pos = in_end; }
+                ok(hipEventRecord(A.event(2 * u), A.s_up));
+            };
+            if (!rc) part_up(0);
+            for (uint32_t k = 0; k < nslices && !rc; k++) {
+                const uint32_t i0 = j->host_part_first[k], i1 = j->host_part_first[k + 1];
+                if (k + 1 < nslices) part_up(k + 1);
+                ok(hipStreamWaitEvent(A.s_run, A.event(2 * k), 0));
+                const int prc = cri_job_run(j->host_parts[k], d_in, d_out + j->out_offsets[i0], d_scr, d_st ? d_st + i0 : nullptr, A.s_run);
+                if (prc && !rc) rc = prc;
+                ok(hipEventRecord(A.event(2 * k + 1), A.s_run)); ok(hipStreamWaitEvent(A.s_down, A.event(2 * k + 1), 0));
+                if (j->out_offsets[i1] > out_pos) { download(out_pos, j->out_offsets[i1]); out_pos = j->out_offsets[i1]; }
+            }
+        }
+        if (sliced && !rc) slice_up(0);
+        for (uint32_t k = 0, t0 = 0; sliced && t0 < tiles && !rc; k++, t0 += TS) {
             const uint32_t t1 = t0 + TS < tiles ? t0 + TS : tiles;
             const uint64_t frames_end = (uint64_t)t1 * 64 < base.frames ? (uint64_t)t1 * 64 : base.frames;
             hipEvent_t e_up = A.event(2 * k), e_run = A.event(2 * k + 1);
@@ -2108,6 +2180,7 @@ extern "C" int cri_test_set(const char* key, long long value) {
     else if (!strcmp(key, "no_inlane")) k.no_inlane = (int)value;
     else if (!strcmp(key, "adx_warm_pct")) k.adx_warm_pct = (uint64_t)value;
     else if (!strcmp(key, "adx_seglen")) k.adx_seglen = (uint64_t)value;
+    else if (!strcmp(key, "host_pull_wgs")) k.host_pull_wgs = (uint64_t)value;
     else return CRI_ERR_INVALID_ARG;
     return 0;
 }

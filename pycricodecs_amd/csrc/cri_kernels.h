@@ -109,7 +109,7 @@ void launch_pcm_convert(const ConvertArgs& a, hipStream_t s);
 void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const uint64_t* dst_off, uint32_t n, uint8_t* out, hipStream_t s);
 // copies item bodies verbatim (crypt: headers are patched on the host image, frames by the kernel)
 void launch_fill_i32(int32_t* p, int32_t v, uint32_t n, hipStream_t s);
-void launch_pull_host(uint8_t* dst, const uint8_t* src_host, uint64_t bytes, hipStream_t s);
+void launch_pull_host(uint8_t* dst, const uint8_t* src_host, uint64_t bytes, hipStream_t s, uint32_t max_wg = 8);
 
 // USM audio (@SFA) chunk streams, usm.py: byte segments copied between a container and contiguous streams, with the audio
 // mask (32 bytes, usm.py:112-117) XORed over bytes [mask_begin, mask_end) of a segment

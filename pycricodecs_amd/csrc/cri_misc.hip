@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(256) k_pull_host(uint8_t* __restrict__ dst, co
     if (tid < head) dst[tid] = src[tid];
     if (tid < bytes - tail0) dst[tail0 + tid] = src[tail0 + tid];
 }
-void launch_pull_host(uint8_t* dst, const uint8_t* src, uint64_t bytes, hipStream_t s) {
+void launch_pull_host(uint8_t* dst, const uint8_t* src, uint64_t bytes, hipStream_t s, uint32_t max_wg) {
     if (!bytes) return;
     uint64_t wg = (bytes / 16 + 255) / 256 / 8;
-    wg = wg < 1 ? 1 : (wg > 8 ? 8 : wg);    // 8 workgroups: 19 GB/s, and the downloads beside it keep their rate (cri_capi.cpp, run_host_core)
+    wg = wg < 1 ? 1 : (wg > max_wg ? max_wg : wg);    // 8 workgroups: 19 GB/s, and the downloads beside it keep their rate (cri_capi.cpp, run_host_core)
     hipLaunchKernelGGL(k_pull_host, dim3((uint32_t)wg), dim3(256), 0, s, dst, src, bytes);
 }
 

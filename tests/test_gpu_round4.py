@@ -339,3 +339,59 @@ def test_hca_v3_noise_fill_on_wide_layouts(cc, ch, q):
         want = O.hca_decode_float(h, key)
         got = fl[int(offs[i]):int(offs[i + 1])]
         assert got.size == want.size and np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).reshape(-1).view(np.uint32)), (ch, q, i)
+
+
+# ------------------------------------------------------------------------------------------------ the pipelined host path, ADX decode
+@pytest.mark.parametrize("order", ["pipelined", "pipelined-small-pieces", "one-piece"])
+def test_adx_decode_run_host_in_parts(cc, knobs, order):
+    """An ADX decode job cannot be cut inside (its lanes are laid out by length, not by item), so its pipelined host path plans the
+    items again as a few jobs over consecutive item ranges (run_host_core, host_parts_ready) that write where the whole job would:
+    bytes and statuses equal the device-resident run's and the oracle's -- from separate items (staged in small pieces too), from a
+    pageable blob and from a page-locked one, into pageable and page-locked memory, with items the host rejects among them."""
+    from pycricodecs_amd import _capi
+    from pycricodecs_amd.batch import Job, pinned_array
+    knobs(host_slice_min=(1 << 62) if order == "one-piece" else 0)
+    if order == "pipelined-small-pieces":
+        knobs(host_stage_piece=1000)
+    rng = np.random.default_rng(91)
+    wavs = [synth.wav(700 + k, int(rng.integers(40, 60000)), 1 + k % 2, 48000) for k in range(10)]
+    uniq = [O.adx_encode(w) for w in wavs] + [O.adx_encode(wavs[2], bitdepth=8), O.adx_encode(wavs[3], mode=4)]
+    items = [uniq[int(k)] for k in rng.integers(0, len(uniq), 90)]
+    items[11] = b"\x80\x00" + bytes(64)                          # rejected on the host
+    items[57] = uniq[1][:40]                                    # a header cut short
+    job = Job.adx_decode(items)
+    assert job.host_status[11] != 0 and job.host_status[57] != 0
+    want, st_dev = run_job(job)
+    st_want = np.where(job.host_status != 0, job.host_status, st_dev)
+    refs = {id(u): O.adx_decode(u) for u in uniq}
+    for i, it in enumerate(items):
+        if id(it) in refs:
+            assert bytes(want[i]) == refs[id(it)], i
+    for rep in range(2):                                        # (the second call finds the parts made by the first)
+        outs, st = job.run_host()
+        assert (st == st_want).all()
+        for i, (a, b) in enumerate(zip(outs, want)):
+            assert bytes(a) == bytes(b), (rep, i)
+    buf = pinned_array(job.output_bytes)
+    outs, st = job.run_host(out=buf)
+    for i, (a, b) in enumerate(zip(outs, want)):
+        assert bytes(a) == bytes(b), i
+    blob = job.blob
+    status = (C.c_int32 * job.n)()
+    buf[:] = 0xEE
+    assert _capi.lib().cri_job_run_host_into(job._h, blob, buf.ctypes.data, status) == 0
+    assert (np.array(status[:job.n]) == st_want).all()
+    for i, (a, b) in enumerate(zip(job.split(memoryview(buf)), want)):
+        assert bytes(a) == bytes(b), i
+    pin_in = pinned_array(len(blob))
+    pin_in[:] = np.frombuffer(blob, dtype=np.uint8)
+    page_out = np.full(job.output_bytes, 0xEE, dtype=np.uint8)
+    assert _capi.lib().cri_job_run_host_into(job._h, pin_in.ctypes.data, page_out.ctypes.data, status) == 0
+    for i, (a, b) in enumerate(zip(job.split(memoryview(page_out)), want)):
+        assert bytes(a) == bytes(b), i
+    o = job.output_offsets                                      # bytes no kernel writes are zero
+    for i in range(job.n - 1):
+        end = int(o[i]) + len(want[i])
+        assert not page_out[end:int(o[i + 1])].any(), i
+    del outs
+    del buf, pin_in
