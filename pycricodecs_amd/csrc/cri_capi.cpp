@@ -207,6 +207,8 @@ struct cri_job {
     // The pipelined host path of jobs that cannot be cut inside (run_host_core): the same work planned again as a few jobs over
     // consecutive ranges of the items, made on the first host run that wants them and kept.
     bool partable = false, parts_tried = false;
+    std::vector<uint64_t> part_keys;             // HCA decode: the caller's keys / subkeys, for the parts
+    std::vector<uint16_t> part_subkeys;
     std::vector<cri_job*> host_parts;
     std::vector<uint32_t> host_part_first;       // [parts + 1] first item of each part
     hipEvent_t last_run = nullptr;
@@ -530,14 +532,24 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
     return 0;
 }
 
+// (what the pipelined host path needs to plan a job that is not one format group again as parts: host_parts_ready)
+static void hca_decode_keep_keys(cri_job* j, const uint64_t* keys, const uint16_t* subkeys) {
+    if (keys) j->part_keys.assign(keys, keys + j->n);
+    if (subkeys) j->part_subkeys.assign(subkeys, subkeys + j->n);
+    j->partable = true;
+}
 extern "C" int cri_job_create_hca_decode(const uint8_t* blob, const uint64_t* offsets, uint32_t n, const uint64_t* keys,
                                          const uint16_t* subkeys, cri_job** job) {
     if (!blob || !offsets) return CRI_ERR_INVALID_ARG;
-    return create_hca_decode(ItemSrc::from_blob(blob, offsets, n), keys, subkeys, nullptr, job);
+    const int rc = create_hca_decode(ItemSrc::from_blob(blob, offsets, n), keys, subkeys, nullptr, job);
+    if (!rc) hca_decode_keep_keys(*job, keys, subkeys);
+    return rc;
 }
 extern "C" int cri_job_create_hca_decode_items(const cri_items* items, const uint64_t* keys, const uint16_t* subkeys, cri_job** job) {
     ItemSrc it; int rc = ItemSrc::from_items(items, it);
-    return rc ? rc : create_hca_decode(it, keys, subkeys, nullptr, job);
+    if (!rc) rc = create_hca_decode(it, keys, subkeys, nullptr, job);
+    if (!rc) hca_decode_keep_keys(*job, keys, subkeys);
+    return rc;
 }
 
 
@@ -1811,11 +1823,12 @@ bool hca_decode_sliceable(const cri_job* j) {
 }
 
 // The parts of a job the pipelined path cannot cut inside (an ADX decode job's lanes are laid out by length, not by item: a range of
-// its lanes is not a range of its input): the same items planned again as K jobs over consecutive item ranges of about equal traffic.
+// its lanes is not a range of its input; an HCA decode job of several format groups runs them one after the other, each over items
+// from anywhere): the same items planned again as K jobs over consecutive item ranges of about equal traffic.
 // A part addresses the parent's device input by the parent's own offsets and writes its output where the parent would -- item
 // outputs are 64-byte aligned pieces back to back in both, which the builder checks, part by part.
 bool host_parts_ready(cri_job* j, const HostSrc& src) {
-    if (!j->partable || j->kind != CRI_JOB_ADX_DECODE || j->n < 8) return false;
+    if (!j->partable || (j->kind != CRI_JOB_ADX_DECODE && j->kind != CRI_JOB_HCA_DECODE) || j->n < 8) return false;
     if (j->parts_tried) return !j->host_parts.empty();
     j->parts_tried = true;
     uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) / HOST_SLICE_BYTES);
@@ -1835,7 +1848,9 @@ bool host_parts_ready(cri_job* j, const HostSrc& src) {
         ps.blob = src.blob; ps.offsets = j->in_offsets.data() + i0; ps.n = i1 - i0;
         if (src.items) { ps.ptrs = src.items->ptrs + i0; ps.lens = src.items->lens + i0; }
         cri_job* part = nullptr;
-        if (create_adx_decode(ps, &part) || !part) { good = false; break; }
+        const int prc = j->kind == CRI_JOB_ADX_DECODE ? create_adx_decode(ps, &part)
+                      : create_hca_decode(ps, j->part_keys.empty() ? nullptr : j->part_keys.data() + i0, j->part_subkeys.empty() ? nullptr : j->part_subkeys.data() + i0, nullptr, &part);
+        if (prc || !part) { good = false; break; }
         j->host_parts.push_back(part);
         good = part->out_bytes == j->out_offsets[i1] - j->out_offsets[i0];
         for (uint32_t i = i0; i < i1 && good; i++) good = part->out_offsets[i - i0] == j->out_offsets[i] - j->out_offsets[i0] && part->host_status[i - i0] == j->host_status[i];

@@ -395,3 +395,35 @@ def test_adx_decode_run_host_in_parts(cc, knobs, order):
         assert not page_out[end:int(o[i + 1])].any(), i
     del outs
     del buf, pin_in
+
+
+@pytest.mark.parametrize("order", ["pipelined", "pipelined-small-pieces"])
+def test_hca_decode_of_mixed_formats_run_host_in_parts(cc, knobs, order):
+    """An HCA decode job of several format groups (channel counts, qualities, keys) runs its groups one after the other, each over
+    items from anywhere in the batch: the pipelined host path plans it again as parts over item ranges, like an ADX decode job."""
+    from pycricodecs_amd.batch import Job
+    knobs(host_slice_min=0)
+    if order == "pipelined-small-pieces":
+        knobs(host_stage_piece=1500)
+    rng = np.random.default_rng(17)
+    uniq, keys = [], []
+    for k, (ch, q, key) in enumerate([(2, 1, KEY), (1, 1, 0), (2, 4, KEY), (6, 1, 0), (2, 2, 12345), (4, 3, KEY), (2, 1, 0)]):
+        h = O.hca_encode(synth.wav(900 + k, int(rng.integers(3000, 40000)), ch, 48000), q)
+        uniq.append(O.hca_crypt(h, 1, 56, key) if key else h); keys.append(key)
+    pick = rng.integers(0, len(uniq), 60)
+    items = [uniq[int(k)] for k in pick]
+    item_keys = [keys[int(k)] for k in pick]
+    items[9] = b"HCA\0" + bytes(100)
+    job = Job.hca_decode(items, keys=item_keys)
+    assert len(job.transform_forms()) > 3
+    want, st_dev = run_job(job)
+    st_want = np.where(job.host_status != 0, job.host_status, st_dev)
+    refs = [O.hca_decode(u, k) for u, k in zip(uniq, keys)]
+    for i, k in enumerate(pick):
+        if i != 9:
+            assert bytes(want[i]) == refs[int(k)], i
+    for rep in range(2):
+        outs, st = job.run_host()
+        assert (st == st_want).all()
+        for i, (a, b) in enumerate(zip(outs, want)):
+            assert bytes(a) == bytes(b), (rep, i)
