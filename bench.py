@@ -663,6 +663,7 @@ def secondary_measurements(args, D):
     # (first: the 44 GB of device buffers it needs are allocated while the device's memory is still in large pieces -- at the end of
     #  this list, after dozens of jobs' buffers have come and gone, the same downloads ran 10 % slower)
     out["hca_decode_host"] = host_path_run(min(args.streams, args.host_streams), uq, args.seconds)
+    out["adx_decode_host"] = host_path_run(min(1000, args.streams), uq, args.seconds, codec="adx")
     for label, q, fam in (("hca_decode_sparse_spectra", 1, "sparse"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_noise", 1, "noise"), ("hca_decode_middle", 2, "tonal"),
                           ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
         r = hca_decode_run(D, n, uq, args.seconds, q, fam, 3, 1)
@@ -807,8 +808,8 @@ def single_call_latency(seconds):
             "HcaCrypt": [ms(lambda: cc.HcaCrypt(hca, 0, hs, 0, KEY, 0)), None]}
 
 
-def host_path_run(streams, unique, seconds):
-    """PCIe-inclusive: HCA decode of `streams` encrypted streams from HOST memory to host memory -- what a caller without device
+def host_path_run(streams, unique, seconds, codec="hca"):
+    """PCIe-inclusive: HCA (or ADX) decode of `streams` items from HOST memory to host memory -- what a caller without device
     buffers sees.  Two forms: the items' own `bytes` objects up (cri_job_run_host_items), WAVs down into a pageable numpy buffer
     (what Job.run_host() does for a Python caller); and one host blob up, WAVs down into page-locked memory (cri_job_run_host_into).
     Job planning (header parse of every item) is outside the timed call, as for the device-resident line."""
@@ -816,10 +817,16 @@ def host_path_run(streams, unique, seconds):
     import oracle_lib as O
     from pycricodecs_amd.batch import Job, pinned_array
     from pycricodecs_amd import _capi
-    uniq = make_hca_streams(unique, seconds, 0, 1, "tonal")
-    items = tile(uniq, streams)
-    job = Job.hca_decode(items, keys=[KEY] * len(items))
-    refs = [O.hca_decode(h, KEY) for h in uniq]
+    if codec == "adx":
+        uniq = [O.adx_encode(family_wav(3000 + u, seconds, "tonal")) for u in range(unique)]
+        items = tile(uniq, streams)
+        job = Job.adx_decode(items)
+        refs = [O.adx_decode(a) for a in uniq]
+    else:
+        uniq = make_hca_streams(unique, seconds, 0, 1, "tonal")
+        items = tile(uniq, streams)
+        job = Job.hca_decode(items, keys=[KEY] * len(items))
+        refs = [O.hca_decode(h, KEY) for h in uniq]
     step = max(1, streams // 97)
 
     def timed(out, joined):
@@ -844,7 +851,9 @@ def host_path_run(streams, unique, seconds):
     job.blob                                                   # the batch as one host blob (built once)
     t_blob, _ = timed(pin, True)
     del pin
-    res = {"workload": "HCA decode of %d x %.0f s encrypted stereo streams from host memory to host memory" % (streams, seconds),
+    res = {"workload": ("ADX decode of %d x %.0f s stereo files from host memory to host memory (pipelined as parts over item ranges)" if codec == "adx" else
+                        "HCA decode of %d x %.0f s encrypted stereo streams from host memory to host memory") % (streams, seconds),
+           "share_of_link_rate": round(job.output_bytes / 57e9 / t_items, 3),
            "frames_per_s": round(job.units / t_items, 1), "ms": round(t_items * 1e3, 2),
            "form": "the items' own bytes objects (pageable) in, WAVs into a pageable numpy buffer: cri_job_run_host_items",
            "blob_form": {"frames_per_s": round(job.units / t_blob, 1), "ms": round(t_blob * 1e3, 2),

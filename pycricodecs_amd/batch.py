@@ -314,7 +314,8 @@ class Job:
         return self.split(memoryview(out)), np.array(status[:self.n], dtype=np.int32)
 
     def item_length(self, blob, i):
-        """True byte length of output item i (offsets are 64-byte aligned, so the item carries its own size)."""
+        """True byte length of output item i (items are placed with gaps between them -- a decoded WAV so that its samples start a
+        128-byte line -- so the item carries its own size)."""
         o = int(self.output_offsets[i])
         if self.kind in ("adx_decode", "hca_decode"):
             return int.from_bytes(blob[o + 4:o + 8], "little") + 8 if blob[o:o + 4] == b"RIFF" else 0

@@ -366,6 +366,11 @@ struct ItemSrc {
     uint64_t off(uint32_t i) const { return offsets[i]; }   // device offset of item i
 };
 
+// Where a decoded WAV goes in the device output: the first free byte moved up so that the SAMPLES behind the header start a 128-byte
+// line -- the decoders store PCM in pieces of whole sample rows, and with the items themselves aligned every piece began 44 bytes
+// into a line: each line of the output was written in two parts by two store instructions a row apart (k_adx_seg_decode: 1.27 ms
+// per 1000 x 10 s with those stores, 0.71 with stores that hit the cache).  The gap before an item is zero like every byte no kernel writes.
+static uint64_t wav_item_start(uint64_t free_from, uint32_t header_bytes) { return align_up(free_from + header_bytes, 128) - header_bytes; }
 static cri_job* new_job(uint32_t kind, const uint64_t* offsets, uint32_t n) {
     int device = -1;
     if (hipGetDevice(&device) != hipSuccess || device < 0) return nullptr;    // (callers return CRI_ERR_HIP)
@@ -450,6 +455,8 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         // output WAV
         uint32_t ls = h.loop_start_frame * 1024 + h.loop_start_delay - h.delay;
         uint32_t le = h.loop_end_frame * 1024 + (1024 - h.loop_end_padding) - h.delay;
+        out_pos = wav_item_start(out_pos, h.loop_flag ? 0x70 : 0x2C);
+        j->out_offsets[i] = out_pos;
         Image im; im.dst = out_pos; im.bytes.assign(h.loop_flag ? 0x70 : 0x2C, 0);
         uint32_t wh = wav_write_header(im.bytes.data(), h.channels, h.rate, spc, h.loop_flag != 0, ls, le);
         j->images.push_back(std::move(im));
@@ -458,10 +465,11 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
         S.delay = h.delay; S.samples = spc; S.item = i; S.float_offset = float_pos;
         float_pos += (uint64_t)frames * 1024 * h.channels;
         streams.push_back(S);
-        out_pos = align_up(out_pos + wh + (uint64_t)spc * h.channels * 2, 64);
+        out_pos = out_pos + wh + (uint64_t)spc * h.channels * 2;
         j->units += frames;
         j->alg_bytes += (uint64_t)frames * (h.frame_size + 2048ull * h.channels);
     }
+    out_pos = align_up(out_pos, 64);
     j->out_offsets[n] = out_pos;
     j->float_offsets[n] = float_pos;
     // true (unaligned) end of each item for consumers: offsets[i+1] is the aligned start of the next item, so the
@@ -695,6 +703,8 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
         int rc = adx_parse_header(d, len, h);
         if (rc) { j->host_status[i] = rc; continue; }
         if ((uint64_t)h.sample_count * h.channels * 2 > 0x7FFFFF00ull) { j->host_status[i] = CRI_ERR_INVALID_ARG; continue; }
+        out_pos = wav_item_start(out_pos, h.looping ? 0x70 : 0x2C);
+        j->out_offsets[i] = out_pos;
         Image im; im.dst = out_pos; im.bytes.assign(h.looping ? 0x70 : 0x2C, 0);
         uint32_t wh = wav_write_header(im.bytes.data(), h.channels, h.rate, h.sample_count, h.looping, h.loop_start, h.loop_end);
         j->images.push_back(std::move(im));
@@ -711,10 +721,11 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
         if (!(h.blocksize == 18 && h.bitdepth == 4 && h.channels <= 2)) all_std = false;
         pend.push_back(S);
         for (uint32_t c = 0; c < h.channels; c++) { pend_hist.push_back(h.history[2 * c]); pend_hist.push_back(h.history[2 * c + 1]); }
-        out_pos = align_up(out_pos + wh + (uint64_t)h.sample_count * h.channels * 2, 64);
+        out_pos = out_pos + wh + (uint64_t)h.sample_count * h.channels * 2;
         j->units += h.blocks; j->units2 += (uint64_t)h.blocks * h.channels;
         j->alg_bytes += (uint64_t)h.blocks * h.channels * (h.blocksize + 2ull * h.samples_per_block);
     }
+    out_pos = align_up(out_pos, 64);
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     if (adx_plan_segments(pend, false)) {
         // segmented chains: every (segment, channel) of every file is a lane; no LDS staging, no padding besides even pair starts
@@ -1852,15 +1863,18 @@ bool host_parts_ready(cri_job* j, const HostSrc& src) {
                       : create_hca_decode(ps, j->part_keys.empty() ? nullptr : j->part_keys.data() + i0, j->part_subkeys.empty() ? nullptr : j->part_subkeys.data() + i0, nullptr, &part);
         if (prc || !part) { good = false; break; }
         j->host_parts.push_back(part);
-        good = part->out_bytes == j->out_offsets[i1] - j->out_offsets[i0];
-        for (uint32_t i = i0; i < i1 && good; i++) good = part->out_offsets[i - i0] == j->out_offsets[i] - j->out_offsets[i0] && part->host_status[i - i0] == j->host_status[i];
+        // (an item starts where its samples are line-aligned, wav_item_start: the part's layout is the parent's moved by whole lines)
+        const uint64_t base = j->out_offsets[i0] - part->out_offsets[0];
+        good = base % 128 == 0 && j->out_offsets[i0] >= part->out_offsets[0];
+        for (uint32_t i = i0; i < i1 && good; i++) good = part->out_offsets[i - i0] + base == j->out_offsets[i] && part->host_status[i - i0] == j->host_status[i];
     }
     if (!good) { for (cri_job* part : j->host_parts) delete part; j->host_parts.clear(); return false; }
     j->host_part_first = first;
     return true;
 }
 
-int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_copy, int32_t* status) {
+// (out_from: the single-file calls copy one item out, from where it starts in the device output)
+int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_copy, int32_t* status, uint64_t out_from = 0) {
     DeviceGuard guard(j->device);
     if (!guard.ok()) return CRI_ERR_HIP;
     HostArena* shared = arena_of(j->device);
@@ -1874,7 +1888,8 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         return CRI_ERR_HIP;
     }
     uint8_t* d_in = (uint8_t*)A.buf[0]; uint8_t* d_out = (uint8_t*)A.buf[1]; uint8_t* d_scr = (uint8_t*)A.buf[2]; int32_t* d_st = (int32_t*)A.buf[3];
-    if (out_copy > j->out_bytes) out_copy = j->out_bytes;
+    if (out_from > j->out_bytes) out_from = j->out_bytes;
+    if (out_copy > j->out_bytes - out_from) out_copy = j->out_bytes - out_from;
     const bool gaps = src.items && j->n && j->in_bytes;       // an items layout may leave bytes between the items: they are defined as zero
     uint32_t cursor = 0;
     // Large single-format HCA decode jobs are PIPELINED (CRICODECS_HOST_SLICE_MIN = the job size, bytes in + out, from which; 0 = always,
@@ -1892,7 +1907,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
     //    the call as well.
     // 72 ms for the same job (12.9 M frames/s; the download alone is 67).  The tests run both orders.
     const uint64_t slice_min = knobs().host_slice_min;
-    const bool large = out_copy == j->out_bytes && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
+    const bool large = out_copy == j->out_bytes && !out_from && j->in_bytes + j->out_bytes >= slice_min && !j->events_on;
     const bool sliced = large && hca_decode_sliceable(j);
     const bool parted = large && !sliced && host_parts_ready(j, src);
     if (parted) for (const cri_job* part : j->host_parts) if (!A.ensure(2, part->scratch_bytes)) rc = CRI_ERR_HIP;
@@ -1904,7 +1919,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
         // bytes no kernel writes (alignment gaps, undecoded tails) are defined as zero
         if (j->out_bytes) ok(hipMemsetAsync(d_out, 0, j->out_bytes, A.s_run));
         if (!rc) rc = cri_job_run(j, d_in, d_out, d_scr, d_st, A.s_run);
-        if (!rc && out_copy) ok(hipMemcpyAsync(out, d_out, out_copy, hipMemcpyDeviceToHost, A.s_run));
+        if (!rc && out_copy) ok(hipMemcpyAsync(out, d_out + out_from, out_copy, hipMemcpyDeviceToHost, A.s_run));
     } else {
         // ---- pipelined: the group cut into slices of whole parse tiles (or the job into its parts); three streams, two events per slice
         const HcaDecArgs base = sliced ? j->hca_dec[0] : HcaDecArgs{};
@@ -1992,7 +2007,7 @@ int run_host_core(cri_job* j, const HostSrc& src, uint8_t* out, uint64_t out_cop
                 const uint32_t i0 = j->host_part_first[k], i1 = j->host_part_first[k + 1];
                 if (k + 1 < nslices) part_up(k + 1);
                 ok(hipStreamWaitEvent(A.s_run, A.event(2 * k), 0));
-                const int prc = cri_job_run(j->host_parts[k], d_in, d_out + j->out_offsets[i0], d_scr, d_st ? d_st + i0 : nullptr, A.s_run);
+                const int prc = cri_job_run(j->host_parts[k], d_in, d_out + (j->out_offsets[i0] - j->host_parts[k]->out_offsets[0]), d_scr, d_st ? d_st + i0 : nullptr, A.s_run);
                 if (prc && !rc) rc = prc;
                 ok(hipEventRecord(A.event(2 * k + 1), A.s_run)); ok(hipStreamWaitEvent(A.s_down, A.event(2 * k + 1), 0));
                 if (j->out_offsets[i1] > out_pos) { download(out_pos, j->out_offsets[i1]); out_pos = j->out_offsets[i1]; }
@@ -2105,7 +2120,7 @@ static int run_single(cri_job* j, const uint8_t* in, uint8_t** out, size_t* out_
         res = (uint8_t*)malloc(item_len ? item_len : 1);
         if (!res) rc = CRI_ERR_NOMEM;
     }
-    if (!rc) { HostSrc src; src.blob = in; rc = run_host_core(j, src, res, item_len, &st); }
+    if (!rc) { HostSrc src; src.blob = in; rc = run_host_core(j, src, res, item_len, &st, j->out_offsets[0]); }
     if (!rc) rc = st;
     cri_job_destroy(j);
     if (rc) { free(res); return rc; }

@@ -82,8 +82,8 @@ def test_lpt_is_deterministic_and_balanced():
 def _awb_worker(rank, world, port, n_total, q):
     """One rank of `bench.py --gpus 8 --workload awb_mixed --scaling strong`, with the oracle standing in for the device: the rank
     builds its AFS2 bank from its LPT share of the fixed batch (bench.build_awb_bank), indexes it with the library's host-side reader,
-    "decodes" every item with the oracle into the job's output layout (items in bank order, 64-byte aligned -- the rule
-    tests/test_gpu_round2.py::test_shard_jobs_equal_the_unsharded_batch holds the device planner to) and sends the PCM to rank 0
+    "decodes" every item with the oracle into the job's output layout (items in bank order, each placed so that the samples behind its
+    WAV header start a 128-byte line: cri_capi.cpp, wav_item_start -- the GPU tests hold the device planner to the same bytes) and sends the PCM to rank 0
     through the path's one exchange step (shard.gather_bytes_to_root)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -106,8 +106,10 @@ def _awb_worker(rank, world, port, n_total, q):
         assert item == data and kinds[i] == (awb.KIND_HCA if kind == "hca" else awb.KIND_ADX)
         if u not in refs:
             refs[u] = O.hca_decode(data, B.KEY, subkey) if kind == "hca" else O.adx_decode(data)
-        pcm += refs[u] + bytes(-len(refs[u]) % 64)
+        hdr = 0x70 if refs[u][0x24:0x28] == b"smpl" else 0x2C
+        pcm += bytes(-(len(pcm) + hdr) % 128) + refs[u]
         frames += shard.hca_weight(data) if kind == "hca" else shard.adx_weight(data) // 2
+    pcm += bytes(-len(pcm) % 64)
     t = torch.frombuffer(pcm, dtype=torch.uint8) if pcm else torch.zeros(0, dtype=torch.uint8)
     got, goffs = shard.gather_bytes_to_root(t)
     load = torch.tensor([float(frames)], dtype=torch.float64)
@@ -133,9 +135,10 @@ def _awb_worker(rank, world, port, n_total, q):
                     kind, data = uniq[u]
                     all_refs[u] = O.hca_decode(data, B.KEY, subkey) if kind == "hca" else O.adx_decode(data)
                 w = all_refs[u]
+                pos += -(pos + (0x70 if w[0x24:0x28] == b"smpl" else 0x2C)) % 128
                 ok = ok and part[pos:pos + len(w)] == w
-                pos += len(w) + (-len(w) % 64)
-            ok = ok and pos == len(part)
+                pos += len(w)
+            ok = ok and pos + (-pos % 64) == len(part)
         q.put((owned.tolist(), float(mx.item()), float(tot.item()), ok, [int(x) for x in goffs]))
     dist.destroy_process_group()
 
