@@ -184,7 +184,11 @@ uint32_t cri_job_kind(const cri_job* job);
 uint32_t cri_job_items(const cri_job* job);
 uint64_t cri_job_input_bytes(const cri_job* job);
 uint64_t cri_job_output_bytes(const cri_job* job);
-const uint64_t* cri_job_output_offsets(const cri_job* job); /* n+1 entries */
+/* n+1 entries: item i starts at offsets[i] in d_out; offsets[n] = cri_job_output_bytes.  Bytes between items are zero after a run.
+ * Encoded files start on 64-byte boundaries; a decoded WAV is placed so that the SAMPLES behind its header start a 128-byte line
+ * (offsets[0] is 84 for a 44-byte header): the decoders' stores then write whole lines.  An item's length is its own
+ * (RIFF size + 8, the ADX / HCA file's header fields; cri_job_item_sizes for jobs whose items carry none). */
+const uint64_t* cri_job_output_offsets(const cri_job* job);
 const uint64_t* cri_job_input_offsets(const cri_job* job);  /* n+1 entries: where cri_job_run expects item i in d_in */
 const int32_t* cri_job_host_status(const cri_job* job);     /* n entries, header-stage result per item */
 uint64_t cri_job_scratch_bytes(const cri_job* job);         /* device scratch the run needs (may be 0) */

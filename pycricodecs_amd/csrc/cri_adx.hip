@@ -395,11 +395,13 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
     __shared__ __attribute__((aligned(16))) int32_t dl[R][2][32];      // [frame][half][sample] code * scale
     __shared__ __attribute__((aligned(16))) int32_t ol[R][2][32];      // [frame][half][sample] decoded samples
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][K * 36];
-    const AdxStream S = a.streams[a.wpf_order ? a.wpf_order[blockIdx.x] : blockIdx.x];
+    // As the segmented decoder's fallback (a.seg_flags set) the launch is a fixed number of workgroups that walk k_adx_seg_list's list of
+    // the files with a flagged chain -- usually empty: a workgroup per file that looked at its flags and left cost the 100 000-clip bank
+    // 1.4 ms of every step.
+    const uint32_t n_mine = a.seg_flags ? a.seg_flags[a.chains] : gridDim.x;
+    for (uint32_t li = blockIdx.x; li < n_mine; li += gridDim.x) {
+    const AdxStream S = a.streams[a.seg_flags ? a.seg_flags[a.chains + 1 + li] : (a.wpf_order ? a.wpf_order[li] : li)];
     const uint32_t lane = threadIdx.x, half = lane >> 5, s = lane & 31, C = S.channels;
-    if (a.seg_flags) {                                     // the segmented decoder's fallback: only files with a flagged chain, from their first block
-        if (C > 2 || !(a.seg_flags[S.first_chain] | (C == 2 ? a.seg_flags[S.first_chain + 1] : 0u))) return;
-    }
     const bool act = half < C;
     const uint32_t chain = S.first_chain + (act ? half : 0);
     int32_t h1 = a.history[2 * chain], h2 = a.history[2 * chain + 1];
@@ -580,6 +582,16 @@ __global__ __launch_bounds__(64) void k_adx_decode_wpf(AdxArgs a) {
     }
     // rows never reached (EOF marker / truncated input) decode to silence
     for (uint64_t i = (uint64_t)done * 32 * C + lane; i < (uint64_t)S.samples * C; i += 64) ((int16_t*)out)[i] = 0;
+    wave_lds_sync();
+    }
+}
+// the files the fallback decodes again: mono / stereo files with a flagged chain (seg_flags[chains] = their number, the list behind it)
+__global__ void k_adx_seg_list(AdxArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_streams) return;
+    const uint32_t C = a.streams[i].channels, fc = a.streams[i].first_chain;
+    if (C > 2 || !(a.seg_flags[fc] | (C == 2 ? a.seg_flags[fc + 1] : 0u))) return;
+    a.seg_flags[a.chains + 1 + atomicAdd(&a.seg_flags[a.chains], 1u)] = i;
 }
 
 // a chain's state between two rows: its two history samples
@@ -1551,7 +1563,8 @@ void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s) {
     // segment inside them inconsistent.  Such files are decoded again by the wave-per-file kernel from their first block (8.5 ms for
     // 10 s: what every file cost before the segments); only layouts it does not take (more than two channels) walk their segments
     // lane by lane.
-    hipLaunchKernelGGL(k_adx_decode_wpf, dim3(a.n_streams), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_adx_seg_list, dim3((a.n_streams + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_adx_decode_wpf, dim3(a.n_streams < 1024 ? a.n_streams : 1024), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_adx_seg_serial, dim3((a.chains + 63) / 64), dim3(64), 0, s, a, 1 + (ROUNDS & 1));
 }
 

@@ -587,11 +587,9 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
     const int m = knobs().adx_mapping;
     if (m == ADX_MAP_CHAIN || m == ADX_MAP_FILE) return false;
     if (streams.empty()) return false;
-    uint64_t chains = 0;
     for (const AdxStream& S : streams) {
         if (!(S.blocksize == 18 && S.bitdepth == 4 && (S.mode == 2 || S.mode == 3 || (encode && S.mode == 4)))) return false;
         if (encode && S.channels > 2) return false;
-        chains += S.channels;
     }
     const uint64_t warm_pct = knobs().adx_warm_pct;              // (100 outside the parity tests)
     if (encode) {
@@ -612,16 +610,51 @@ static bool adx_plan_segments(std::vector<AdxStream>& streams, bool encode) {
         }
         return any || m == ADX_MAP_SEG;
     }
-    const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains);
     const uint64_t seg_mult = knobs().adx_seglen ? knobs().adx_seglen : 3;      // least segment length in warm-ups
+    auto warm_of = [&](int64_t g) { return std::max<uint64_t>(1, (56000ull * warm_pct / 100 / (uint64_t)g + 31) / 32); };
+    auto g_of = [](const AdxStream& S) { return S.mode == 2 ? (int64_t)64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1; };     // (mode 2: the slowest of the four static filters)
+    // The segment length: a launch takes the LONGER of (its longest lane: one row after the other, ~3 issue times a row at the two or
+    // three waves per SIMD these launches have) and (all lanes' rows over all SIMDs).  A bank of 100 000 clips of 0.05-2 s has lanes
+    // enough uncut, but then its 2 s clips are lanes of 3000 rows that the launch waits for (3.7 ms; the clips cut: see DESIGN section 2)
+    // -- so the length is chosen per job over a few candidates (in warm-ups), never below seg_mult of them.
+    // (candidate 0 is the rule of round 3 -- lanes enough for four waves per SIMD, segments of seg_mult warm-ups at least -- and stays
+    //  unless a cap beats it by a fifth: between plans of similar cost the repairs decide, and they favour the shorter segments it makes)
+    uint64_t chains = 0;
+    for (const AdxStream& S : streams) chains += S.channels;
+    const uint64_t p_target = std::max<uint64_t>(1, 262144 / chains);
+    auto rows_of = [&](const AdxStream& S, uint64_t cand, uint64_t warm) {
+        return cand ? std::max<uint64_t>(seg_mult, cand) * warm : std::max<uint64_t>((S.frames + p_target - 1) / p_target, seg_mult * warm);
+    };
+    uint64_t cap_mult = 0;                                           // a segment's most rows, in warm-ups (0: the rule above)
+    {
+        const uint32_t nsimd = device_simds();
+        uint64_t best = ~0ull;
+        for (uint64_t cand : {(uint64_t)0, (uint64_t)48, (uint64_t)24, (uint64_t)12, (uint64_t)8, (uint64_t)6, (uint64_t)4, (uint64_t)3}) {
+            uint64_t longest = 0, total = 0;
+            for (const AdxStream& S : streams) {
+                const int64_t g = g_of(S);
+                uint64_t rows = S.frames, segs = 1, warm = 0;
+                if (g > 0 && S.frames) {
+                    warm = warm_of(g);
+                    rows = std::min<uint64_t>(S.frames, rows_of(S, cand, warm));
+                    segs = (S.frames + rows - 1) / rows;
+                }
+                longest = std::max<uint64_t>(longest, rows + (segs > 1 ? warm : 0));
+                total += (uint64_t)S.channels * (S.frames + (segs - 1) * warm);
+            }
+            const uint64_t cost = std::max<uint64_t>(3 * longest, total / 64 / nsimd);
+            if (cand == 0) best = cost - cost / 5;
+            else if (cost < best) { best = cost; cap_mult = cand; }
+        }
+    }
     bool any = false;
     for (AdxStream& S : streams) {
-        const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;     // (mode 2: the slowest of the four static filters)
+        const int64_t g = g_of(S);
         S.rows_avail = (uint32_t)std::min<uint64_t>(S.frames, (S.src_end - S.src_offset) / (18ull * S.channels));
         S.seg_rows = S.frames; S.seg_count = S.frames ? 1 : 0; S.warm_rows = 0;
         if (g <= 0 || !S.frames) continue;                           // no decay (high-pass 0): one segment, i.e. the plain serial decode
-        const uint64_t warm = std::max<uint64_t>(1, (56000ull * warm_pct / 100 / (uint64_t)g + 31) / 32);
-        const uint64_t rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, seg_mult * warm);
+        const uint64_t warm = warm_of(g);
+        const uint64_t rows = rows_of(S, cap_mult, warm);
         if (rows >= S.frames) continue;
         S.seg_rows = (uint32_t)rows; S.seg_count = (uint32_t)((S.frames + rows - 1) / rows); S.warm_rows = (uint32_t)warm;
         any = true;
@@ -747,7 +780,7 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
         j->adx.chains = chains; j->adx.seg_lanes = lanes; j->adx.n_streams = (uint32_t)streams.size();
         j->adx_streams = (uint32_t)streams.size();
         j->adx_seg_flags_offset = align_up(16ull * lanes, 256);
-        j->scratch_bytes = j->adx_seg_flags_offset + align_up(4ull * chains, 256);
+        j->scratch_bytes = j->adx_seg_flags_offset + align_up(4ull * (chains + 1 + streams.size()), 256);      // flags, then the fallback's list (k_adx_seg_list)
         if (history.empty()) history.assign(2, 0);
         int rc = 0;
         if ((rc = j->d_adx_streams.upload(streams)) || (rc = j->d_seg_chain.upload(seg_first)) || (rc = j->d_history.upload(history)) || (rc = j->upload_images())) { delete j; return rc; }
@@ -1581,7 +1614,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
                 a.seg_first = (const uint32_t*)j->d_seg_chain.p; a.seg_state = (uint32_t*)d_scratch;
                 a.seg_flags = (uint32_t*)((uint8_t*)d_scratch + j->adx_seg_flags_offset);
                 j->mark(0, true, s);
-                launch_fill_i32((int32_t*)a.seg_flags, 0, a.chains, s);
+                launch_fill_i32((int32_t*)a.seg_flags, 0, a.chains + 1, s);
                 launch_adx_decode_seg(a, s);
                 j->mark(0, false, s);
                 break;
