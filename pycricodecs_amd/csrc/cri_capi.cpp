@@ -104,6 +104,7 @@ struct Knobs {
     int no_inlane = 0;                           // joint / wide / noise formats on the general transform kernels instead of the in-lane ones
     uint64_t adx_warm_pct = 100;                 // segmented ADX chains: warm-up length in per cent of the planner's
     uint64_t host_pull_wgs = 0;                  // the pipelined host path's upload kernel: workgroups (0: the planner's choice)
+    uint64_t hca_run = 0;                        // HCA decode: frames of a transform run (0: the planner's choice of 8 / 16 / 32)
     uint64_t adx_seglen = 0;                     // ... least segment length (decode: in warm-ups, default 3; lane encode: per cent of the warm-up, default 50)
 };
 // SIMDs of the calling thread's device (CUs x 4): the ADX lane kernels run one row after the other in a lane and are bound by instruction
@@ -483,14 +484,22 @@ static int create_hca_decode(const ItemSrc& it, const uint64_t* keys, const uint
     for (size_t b = 0; b < streams.size();) {
         size_t e = b; uint32_t frames = 0, runs = 0;
         const HcaFormat& F = formats[streams[b].format];
+        // A transform wave walks a RUN of consecutive frames of one stream; every run starts with a pass that only rebuilds the
+        // overlap state (the halo), so long runs are cheaper -- where the group has waves enough to fill the chip many times over:
+        // transform of 4.69 M frames 10.6 ms at 8 frames, 10.2 at 16, 10.05 at 32, 10.65 at 64; 1.88 M frames 4.06 / 3.89 / 3.97;
+        // 469 k and fewer: no gain, and 30 k frames lose (0.085 / 0.100 / 0.142 ms)  (tools/debug/dec_runs.py).
+        uint64_t group_frames = 0;
+        for (size_t k = b; k < streams.size() && streams[k].format == streams[b].format; k++) group_frames += streams[k].frames;
+        uint32_t run_frames = group_frames >= 3000000 ? 32u : (group_frames >= 1200000 ? 16u : 8u);
+        if (knobs().hca_run) run_frames = (uint32_t)knobs().hca_run;
         while (e < streams.size() && streams[e].format == streams[b].format) {
             streams[e].first_frame = frames; streams[e].first_run = runs; streams[e].scratch_offset = scratch;
-            frames += streams[e].frames; runs += (streams[e].frames + 7) / 8;
+            frames += streams[e].frames; runs += (streams[e].frames + run_frames - 1) / run_frames;
             scratch += (uint64_t)streams[e].frames * F.record_bytes;
             e++;
         }
         HcaDecArgs a; memset(&a, 0, sizeof a);
-        a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames; a.runs = runs;
+        a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames; a.runs = runs; a.run_frames = run_frames;
         a.n_cipher = j->n_cipher; a.channels = F.channels;
         a.cipher_identity = cipher_identity ? 1 : 0; a.in_bytes = j->in_bytes;
         a.plain = (F.bands_per_hfr_group == 0 && F.stereo_bands == 0) ? 1 : 0;
@@ -2243,6 +2252,7 @@ extern "C" int cri_test_set(const char* key, long long value) {
     else if (!strcmp(key, "no_inlane")) k.no_inlane = (int)value;
     else if (!strcmp(key, "adx_warm_pct")) k.adx_warm_pct = (uint64_t)value;
     else if (!strcmp(key, "adx_seglen")) k.adx_seglen = (uint64_t)value;
+    else if (!strcmp(key, "hca_run")) k.hca_run = (uint64_t)value;
     else if (!strcmp(key, "host_pull_wgs")) k.host_pull_wgs = (uint64_t)value;
     else return CRI_ERR_INVALID_ARG;
     return 0;

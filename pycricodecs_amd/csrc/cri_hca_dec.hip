@@ -767,7 +767,6 @@ __device__ __forceinline__ int32_t cvt_trunc_x86(float v) {
 #undef CRI_TABLE_QUAL
 #define CRI_TABLE_QUAL static __device__ const
 #include "cri_imdct_tables.h"
-#define HCA_RUN 8
 #define TR_DSTRIDE 144     // floats between the DCT-output ring's rows: the four slots of a pass touch the same columns of four
                            // rows, and a 128-float stride would put them all on the same LDS banks
 
@@ -1105,7 +1104,7 @@ __global__ __launch_bounds__(64) void k_hca_noise_scan(HcaDecArgs a) {
 // k_hca_transform: register-resident IMDCT, wavefront shuffles for the butterflies (1, 2, 4 channels; 6, 8 when every
 // stereo pair starts on an even channel, so that a pair always shares a pass)
 // ------------------------------------------------------------------------------------------------------------
-// A wave owns a run of up to HCA_RUN consecutive frames of one stream and walks its 8*C transforms per frame four at a
+// A wave owns a run of up to a.run_frames (8, 16 or 32: the planner, cri_capi.cpp) consecutive frames of one stream and walks its 8*C transforms per frame four at a
 // time: transform slot j = lane >> 4, and the 16 lanes of a slot hold the 128 spectral lines of that transform, 8
 // consecutive bands per lane (physical position p = lane16 * 8 + reg).  The 128-point DCT-IV of hca.cpp:1898-1980 is run
 // in its in-place form (tools/gen_tables.py, imdct_inplace_maps): 14 butterfly stages between positions differing in one
@@ -1364,8 +1363,8 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
     const uint32_t run = blockIdx.x + a.run_begin;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= run) lo = mid; else hi = mid; }
     const HcaStream st = a.streams[lo];
-    const uint32_t f0 = (run - st.first_run) * HCA_RUN;
-    const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
+    const uint32_t f0 = (run - st.first_run) * a.run_frames;
+    const uint32_t nf = st.frames - f0 < a.run_frames ? st.frames - f0 : a.run_frames;
     const uint8_t* rec0 = a.scratch + st.scratch_offset;
 
     // per-lane constants; small tables the setup indexes go to LDS
@@ -1539,7 +1538,7 @@ __global__ __launch_bounds__(64, C > 4 ? 2 : (PLAIN ? 4 : 3)) void k_hca_transfo
 //     out[63-k] = w[63-k]*d[127-k] + w[64+k]*prev[k]        out[64+k] = w[64+k]*d[127-k] - w[63-k]*prev[k]
 // where prev[k] is the same position of the same channel's previous subframe.  So when a transform slot (16 lanes) always
 // follows the same channel through consecutive subframes, the overlap state is four registers per lane, the window is
-// eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of HCA_RUN
+// eight per-lane constants, and nothing but the PCM staging goes through LDS.  The wave still owns a run of a.run_frames
 // frames, but its 4 slots ("units") are 4/C groups x C channels: each group takes a contiguous part of the run and walks
 // it frame by frame, subframe by subframe, after one halo pass (the subframe before its first one).
 // k steps of the decoder's generator as one affine map, k = 0 .. 128: r_k = v[k].x * r + v[k].y
@@ -1613,8 +1612,8 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
     const uint32_t run = blockIdx.x + a.run_begin;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_run <= run) lo = mid; else hi = mid; }
     const HcaStream st = a.streams[lo];
-    const uint32_t f0 = (run - st.first_run) * HCA_RUN;
-    const uint32_t nf = st.frames - f0 < HCA_RUN ? st.frames - f0 : HCA_RUN;
+    const uint32_t f0 = (run - st.first_run) * a.run_frames;
+    const uint32_t nf = st.frames - f0 < a.run_frames ? st.frames - f0 : a.run_frames;
     const uint8_t* rec0 = a.scratch + st.scratch_offset;
     const uint32_t h = (nf + NG - 1) / NG;                 // frames per group (the last groups may get fewer, or none)
 

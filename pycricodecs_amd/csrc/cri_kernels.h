@@ -18,7 +18,8 @@ struct HcaDecArgs {
     uint32_t format;               // format index of this launch
     uint32_t stream_begin, stream_end;   // streams of this format
     uint32_t frames;               // total frames of this format group
-    uint32_t runs;                 // total runs (8 consecutive frames of one stream) of this format group
+    uint32_t runs;                 // total runs (run_frames consecutive frames of one stream) of this format group
+    uint32_t run_frames;           // 8, 16 or 32: frames of a run (the planner's choice by the group's size)
     uint32_t n_cipher;
     uint32_t cipher_identity;      // 1: every stream of the job is unencrypted (one identity table): the intake skips the lookups
     uint32_t pad0;

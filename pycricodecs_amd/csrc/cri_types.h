@@ -1,6 +1,7 @@
 // cri_types.h -- plain structs shared by the host planner (cri_host.cpp / cri_capi.cpp) and the HIP kernels
 // (cri_kernels.hip).  Everything here is POD and is uploaded to HBM verbatim.
 #pragma once
+
 #include <stdint.h>
 
 enum { CRI_CH_DISCRETE = 0, CRI_CH_PRIMARY = 1, CRI_CH_SECONDARY = 2 };
@@ -31,7 +32,7 @@ struct HcaStream {
     uint32_t item;                 // index of the batch item (for status reporting)
     uint32_t src_in_scratch;       // encode: src_offset is relative to the job scratch (converted PCM16)
     uint32_t first_frame;          // global frame number of this stream's frame 0 within its format group
-    uint32_t first_run;            // global number of this stream's first run of HCA_RUN (8) frames within its format group
+    uint32_t first_run;            // global number of this stream's first run (HcaDecArgs.run_frames frames) within its format group
     // encode, looping input (hca.cpp:2990-3107): the encoder's input is the sequence
     //   enc_pre_zero zeros | first sample up to enc_pre | `samples` of main audio | enc_post samples from enc_loop_src | zeros
     uint32_t enc_loop;             // 1: use the sequence above (0: main audio then zeros)

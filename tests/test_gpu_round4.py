@@ -427,3 +427,43 @@ def test_hca_decode_of_mixed_formats_run_host_in_parts(cc, knobs, order):
         assert (st == st_want).all()
         for i, (a, b) in enumerate(zip(outs, want)):
             assert bytes(a) == bytes(b), (rep, i)
+
+
+# ------------------------------------------------------------------------------------------------ transform runs of 16 and 32 frames
+@pytest.mark.parametrize("run", [16, 32])
+def test_hca_decode_with_long_transform_runs(cc, knobs, run):
+    """The planner gives large format groups transform runs of 16 or 32 frames instead of 8 (cri_capi.cpp: fewer halo passes); the
+    parity batches are far too small for that, so the knob forces it: every transform form -- in-lane plain / joint / noise fill, the
+    wide instances, the general kernels -- over streams shorter than, equal to and several times a
+    run, encrypted and plain, PCM and the floats before the int16 conversion bit for bit the oracle's."""
+    import hca_forge
+    import torch
+    from pycricodecs_amd.batch import Job
+    knobs(hca_run=run)
+    items, keys = [], []
+    specs = [(2, 1, False), (1, 1, False), (2, 3, False), (2, 4, False), (4, 1, False), (6, 1, False), (6, 2, False), (8, 1, False),
+             (2, 1, True), (6, 1, True), (3, 2, True)]
+    for k, (ch, q, v3) in enumerate(specs):
+        for m, n in enumerate((1024 * (run - 1) + 17, 1024 * run, 1024 * (2 * run + 3) + 500, 3000)):
+            h = O.hca_encode(synth.wav(9100 + 10 * k + m, n, ch, 48000), q)
+            if v3:
+                h = hca_forge.forge_v3(h, 0)
+                try:
+                    O.hca_decode(h)
+                except O.OracleError:
+                    continue
+            key = KEY if (k + m) % 2 else 0
+            items.append(O.hca_crypt(h, 1, 56, key) if key else h); keys.append(key)
+    job = Job.hca_decode(items, keys=keys)
+    assert len(set(job.transform_forms())) >= 4, job.transform_forms()
+    bufs = job.alloc("cuda:0")
+    d_f, offs = job.run_floats(*bufs)
+    torch.cuda.synchronize()
+    assert int(bufs[3].abs().sum().item()) == 0
+    outs = job.split(bytes(bufs[1].cpu().numpy()))
+    fl = d_f.cpu().numpy()
+    for i, (h, key) in enumerate(zip(items, keys)):
+        assert bytes(outs[i]) == O.hca_decode(h, key), (run, i)
+        want = O.hca_decode_float(h, key)
+        mine = fl[int(offs[i]):int(offs[i + 1])]
+        assert mine.size == want.size and np.array_equal(mine.view(np.uint32), np.asarray(want, dtype=np.float32).reshape(-1).view(np.uint32)), (run, i)
