@@ -118,7 +118,7 @@ typedef struct cri_adx_encode_params {
 /* Items given one by one instead of as one blob (the *_items creators): n host pointers + lengths -- several items may point
  * at the same host bytes, so a batch that repeats files costs no host copy, and a binding can pass its list of buffers as it
  * is.  offsets[n+1] places the items in the DEVICE input handed to cri_job_run (item i at offsets[i], offsets[n] = its size;
- * offsets[i+1] - offsets[i] >= lens[i], e.g. the 64-byte aligned output offsets of the job that produced them); NULL =
+ * offsets[i+1] - offsets[i] >= lens[i], e.g. the output offsets of the job that produced them); NULL =
  * packed back to back.  cri_job_input_offsets() returns the layout either way.  Host data is only read while the job is
  * created (headers) and by cri_job_run_host_items. */
 typedef struct cri_items { const uint8_t* const* ptrs; const uint64_t* lens; const uint64_t* offsets; uint32_t n; } cri_items;
