@@ -467,3 +467,32 @@ def test_hca_decode_with_long_transform_runs(cc, knobs, run):
         want = O.hca_decode_float(h, key)
         mine = fl[int(offs[i]):int(offs[i + 1])]
         assert mine.size == want.size and np.array_equal(mine.view(np.uint32), np.asarray(want, dtype=np.float32).reshape(-1).view(np.uint32)), (run, i)
+
+
+# ------------------------------------------------------------------------------------------------ where decoded WAVs are placed
+def test_decoded_wavs_start_their_samples_on_a_line(cc):
+    """cri_job_output_offsets of the decode jobs: every WAV is placed so that the samples behind its header (44 bytes, 112 with a
+    smpl chunk) start a 128-byte line -- the decoders store PCM in whole sample rows, which are then whole lines -- items do not overlap,
+    the bytes between them are zero after a run, and the items are the oracle's."""
+    from pycricodecs_amd.batch import Job
+    rng = np.random.default_rng(5)
+    wavs = [synth.wav(40 + k, int(rng.integers(100, 9000)), 1 + k % 2, 48000) for k in range(6)]
+    wavs.append(synth.wav_bytes(synth.pcm16(99, 6000, 2, 48000), 48000, loop=(1000, 5000)))
+    adx = [O.adx_encode(w) for w in wavs]
+    hca = [O.hca_encode(w, 1) for w in wavs]
+    for job, refs in ((Job.adx_decode(adx), [O.adx_decode(a) for a in adx]), (Job.hca_decode(hca), [O.hca_decode(h) for h in hca])):
+        outs, st = run_job(job)
+        import torch
+        bufs = job.alloc("cuda:0"); job.run(*bufs); torch.cuda.synchronize()
+        blob = bufs[1].cpu().numpy()
+        o = [int(v) for v in job.output_offsets]
+        assert o[-1] == job.output_bytes and o[-1] % 64 == 0
+        end = 0
+        for i, ref in enumerate(refs):
+            hdr = 0x70 if ref[0x24:0x28] == b"smpl" else 0x2C
+            assert (o[i] + hdr) % 128 == 0 and o[i] >= end, (i, o[i], hdr)
+            assert not blob[end:o[i]].any(), i
+            assert bytes(blob[o[i]:o[i] + len(ref)]) == ref == bytes(outs[i]), i
+            end = o[i] + len(ref)
+        assert not blob[end:].any()
+    assert any(r[0x24:0x28] == b"smpl" for r in refs)
