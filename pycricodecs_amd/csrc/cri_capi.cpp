@@ -208,6 +208,7 @@ struct cri_job {
     // The pipelined host path of jobs that cannot be cut inside (run_host_core): the same work planned again as a few jobs over
     // consecutive ranges of the items, made on the first host run that wants them and kept.
     bool partable = false, parts_tried = false;
+    std::mutex parts_mu;                         // (two threads may make their first large host run on one job at the same time)
     std::vector<uint64_t> part_keys;             // HCA decode: the caller's keys / subkeys, for the parts
     std::vector<uint16_t> part_subkeys;
     std::vector<cri_job*> host_parts;
@@ -1882,6 +1883,7 @@ bool hca_decode_sliceable(const cri_job* j) {
 // outputs are 64-byte aligned pieces back to back in both, which the builder checks, part by part.
 bool host_parts_ready(cri_job* j, const HostSrc& src) {
     if (!j->partable || (j->kind != CRI_JOB_ADX_DECODE && j->kind != CRI_JOB_HCA_DECODE) || j->n < 8) return false;
+    std::lock_guard<std::mutex> lk(j->parts_mu);
     if (j->parts_tried) return !j->host_parts.empty();
     j->parts_tried = true;
     uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) / HOST_SLICE_BYTES);
