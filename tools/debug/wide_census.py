@@ -29,3 +29,27 @@ for fam in sys.argv[1:] or ["sparse", "mixed", "tonal"]:
           "16-band blocks that hold one (by block index): %s" % (fam, 100 * per_frame.mean(), 100 * per_tile.mean(),
           per_frame_count[per_frame].mean() if per_frame.any() else 0, per_frame_ch.max(), np.round(blocks.mean(axis=0), 2).tolist()), flush=True)
     del bufs
+
+# second part: the parse's two symbol paths (table: every code of a 16-band block at most four bits in all 64 frames of the tile; else generic)
+for fam in sys.argv[1:] or ["tonal", "sparse", "mixed", "noise"]:
+    uniq = B.make_hca_streams(8, 10.0, 0, 1, fam)
+    n = 64
+    job = Job.hca_decode(B.tile(uniq, n), keys=[B.KEY] * n)
+    bufs = job.alloc("cuda:0")
+    job.run(*bufs); torch.cuda.synchronize()
+    arr = (_capi.HcaGroupInfo * 64)()
+    job._L.cri_job_hca_groups(job._h, arr, 64)
+    g = arr[0]
+    C_, frames = g.channels, g.frames
+    tiles = (frames + 63) // 64
+    desc = bufs[2][g.code_desc_offset:g.code_desc_offset + tiles * C_ * 8 * 64 * 16].cpu().numpy().reshape(tiles, C_, 8, 64, 16)
+    bits = desc & 0x0F
+    coded_blk = (bits > 0).any(axis=(3, 4))                        # [tile][ch][block]: blocks with any coded band
+    long_sym = (bits > 4).any(axis=3)                              # [tile][ch][block][band]: a long code in some frame of the tile
+    generic_blk = long_sym.any(axis=3)
+    nb = coded_blk.sum()
+    gen = (generic_blk & coded_blk).sum()
+    short_in_generic = (~long_sym[generic_blk & coded_blk]).mean() if gen else 0.0
+    print("%-7s coded blocks %d: generic path %4.1f %%; symbols of generic blocks that are short in all 64 frames: %4.1f %%; generic share by block index %s"
+          % (fam, nb, 100.0 * gen / nb, 100.0 * short_in_generic, np.round((generic_blk & coded_blk).sum(axis=(0, 1)) / np.maximum(coded_blk.sum(axis=(0, 1)), 1), 2).tolist()), flush=True)
+    del bufs
