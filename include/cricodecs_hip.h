@@ -78,6 +78,9 @@ void cri_free(void* p);
 /* Message for a return code: the reference's own strings for the ADX / PCM / HCA domains
  * (adx.cpp:11-30, pcm.cpp:22-33, hca.cpp:3255-3264). */
 const char* cri_strerror(int code);
+/* Identity of the sources the loaded library was built from: 24 hex digits, a sha256 prefix over csrc/, this header and the compiler
+ * flags (pycricodecs_amd/build.py, source_id()).  A binding that ships a prebuilt library can hold it to its source tree. */
+const char* cri_build_id(void);
 
 /* 1 when a gfx950 device is usable, 0 otherwise (thread-safe). */
 int cri_device_available(void);
@@ -97,8 +100,8 @@ int cri_get_device(void);         /* the calling thread's current device, -1 wit
  * or synchronises, so it can be captured in a hipGraph (tests/test_gpu_round4.py::test_job_run_captured_in_a_hip_graph
  * replays one capture per job kind).
  * Lifetime: a run's kernels read the job's metadata.  cri_job_destroy waits for the last run that was ENQUEUED through
- * cri_job_run (an event behind its last kernel) before that memory is reused -- a job may be destroyed while its work is in
- * flight.  A run captured into a graph leaves no such event: the job must outlive every launch of a graph that holds it.
+ * cri_job_run on every stream the job was run on (an event per stream behind its last kernel) before that memory is reused -- a
+ * job may be destroyed while its work is in flight.  A run captured into a graph leaves no such event: the job must outlive every launch of a graph that holds it.
  *
  * Items are described AFS2-style: one blob + offsets[n+1]; item i = blob[offsets[i], offsets[i+1]).
  * The device input handed to cri_job_run must be a byte-identical copy of that blob.

@@ -25,7 +25,7 @@ SYMBOLS = [
     "cri_job_create_hca_decode_items", "cri_job_create_adx_decode_items", "cri_job_create_adx_encode_items",
     "cri_job_create_hca_encode_items", "cri_job_create_hca_crypt_items", "cri_job_input_offsets", "cri_device_count", "cri_set_device", "cri_get_device", "cri_job_device", "cri_job_run_floats", "cri_job_float_count", "cri_job_float_offsets",
     "cri_usm_audio_mask", "cri_usm_index", "cri_job_create_usm_audio_demux", "cri_job_create_sfa_pack", "cri_job_item_tags", "cri_job_item_sizes",
-    "cri_job_hca_groups", "cri_job_run_host_items", "cri_pinned_alloc", "cri_pinned_free", "cri_release_cache",
+    "cri_job_hca_groups", "cri_job_run_host_items", "cri_pinned_alloc", "cri_pinned_free", "cri_release_cache", "cri_build_id",
 ]
 
 
@@ -92,10 +92,30 @@ class testing_knobs:
         return False
 
 
+def _fresh(path):
+    """A prebuilt library is only loaded if it was built from THIS tree's sources (build.source_id() against the id compiled into the
+    file): prebuilt binaries travel with the tree, file times do not mean anything there.  A stale or missing one is rebuilt on the
+    spot (hipcc cross-compiles anywhere); CRICODECS_NO_REBUILD=1 turns that into an error instead."""
+    from . import build as B
+    if not os.path.isdir(B.CSRC):                              # an installed copy without sources: nothing to hold it to
+        return
+    want = B.source_id()
+    if os.path.exists(path) and B.embedded_id(path) == want:
+        return
+    if os.environ.get("CRICODECS_NO_REBUILD") == "1":
+        raise OSError("%s is not built from this tree (library %s, sources %s): run `python -m pycricodecs_amd.build`" % (path, B.embedded_id(path), want))
+    import sys
+    print("pycricodecs_amd: %s is stale or missing (library %s, sources %s): rebuilding" % (os.path.basename(path), B.embedded_id(path), want), file=sys.stderr, flush=True)
+    B.build(verbose=False)
+
+
 def _bind(path):
+    _fresh(path)
     if not os.path.exists(path):
         raise OSError("%s not built: run `python -m pycricodecs_amd.build` (hipcc, gfx950)" % path)
     L = C.CDLL(path)
+    L.cri_build_id.argtypes = []
+    L.cri_build_id.restype = C.c_char_p
     u8p, u64p, i32p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)
     vp = C.c_void_p
     L.cri_adx_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(u8p), szp]
@@ -172,6 +192,11 @@ class CriCodecsError(Exception):
     def __init__(self, code):
         self.code = code
         super().__init__("%s (code %d)" % (strerror(code), code))
+
+
+def build_id():
+    """The id of the sources the loaded library was built from (cri_build_id)."""
+    return lib().cri_build_id().decode()
 
 
 def strerror(code):

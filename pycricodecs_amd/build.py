@@ -4,8 +4,15 @@
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is load-bearing: the reference's float work is single
 rounded multiplies/adds (x86-64 SSE2 build, no FMA), and bit-exact HCA output depends on not fusing them.
+
+Build identity.  Prebuilt libraries travel to the GPU box with the tree, so "is this .so the tree's source?" must be answerable
+without trusting file times: `source_id()` is a sha256 over every file of csrc/ (+ the public header and the
+compiler flags), it is compiled into both libraries (`cri_build_id()`, csrc/cri_capi.cpp), and a library is stale exactly when the
+id embedded in its file differs from the tree's.  tests/test_build_id.py holds both libraries to it on the CPU and on the GPU box.
 """
+import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -16,16 +23,77 @@ LIB = os.path.join(LIBDIR, "libcricodecs_hip.so")
 TESTING_LIB = os.path.join(LIBDIR, "libcricodecs_hip_testing.so")   # parity-test build: the same objects, cri_capi.cpp and the test kernels with -DCRI_TESTING
 TESTING_SOURCES = ["cri_capi.cpp", "cri_testing.hip"]
 SOURCES = ["cri_host.cpp", "cri_hca_dec.hip", "cri_hca_enc.hip", "cri_adx.hip", "cri_misc.hip", "cri_capi.cpp"]
-HEADERS = ["cri_host.h", "cri_kernels.h", "cri_types.h", "cri_tables.h", "cri_imdct_tables.h", "cri_device.h", "cri_dct_lane.h", "../../include/cricodecs_hip.h"]
+PUBLIC_HEADER = os.path.join(HERE, "..", "include", "cricodecs_hip.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+ID_MARK = b"CRI_BUILD_ID="
+
+
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _extra():
+    return os.environ.get("CRI_HIPCC_EXTRA", "").split()
+
+
+def _headers():
+    """Every header a translation unit of csrc/ can see (all of csrc/*.h + the public header)."""
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [PUBLIC_HEADER]
+
+
+def _digest(paths, salt):
+    h = hashlib.sha256()
+    h.update(salt.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def source_id():
+    """Identity of what the libraries are built from: sources, headers, flags (incl. CRI_HIPCC_EXTRA).  24 hex digits."""
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    files.append(os.path.join(CSRC, "pyext", "CriCodecs_ext.cpp"))
+    return _digest(files + _headers(), " ".join(FLAGS + _extra()))[:24]
+
+
+def embedded_id(path):
+    """The id compiled into a built library, read from the file (nothing is loaded); None if there is none."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    m = re.search(re.escape(ID_MARK) + rb"([0-9a-f]{24})", blob)
+    return m.group(1).decode() if m else None
 
 
 def _stale():
-    if not os.path.exists(LIB) or not os.path.exists(TESTING_LIB):
-        return True
-    t = min(os.path.getmtime(LIB), os.path.getmtime(TESTING_LIB))
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS + ["cri_testing.hip"])
+    want = source_id()
+    return embedded_id(LIB) != want or embedded_id(TESTING_LIB) != want
+
+
+def _compile(src, obj, defines, verbose):
+    """Compiles src -> obj unless obj was made from exactly these inputs (a hash of source + headers + command beside the object)."""
+    hipcc = _hipcc()
+    cmd = [hipcc] + FLAGS + defines + _extra() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    key = _digest([os.path.join(CSRC, src)] + _headers(), " ".join(cmd))
+    stamp = obj + ".key"
+    try:
+        with open(stamp) as f:
+            if f.read().strip() == key and os.path.exists(obj):
+                return obj
+    except OSError:
+        pass
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(key)
+    return obj
 
 
 def build(force=False, verbose=True):
@@ -36,15 +104,17 @@ def build(force=False, verbose=True):
             build_extension(verbose)
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if force:
+        for f in os.listdir(LIBDIR):
+            if f.endswith(".key"):
+                os.remove(os.path.join(LIBDIR, f))
+    hipcc = _hipcc()
+    bid = source_id()
+    iddef = ['-DCRI_BUILD_ID_STRING="%s%s"' % (ID_MARK.decode(), bid)]
     objs = []
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc] + FLAGS + os.environ.get("CRI_HIPCC_EXTRA", "").split() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
+        objs.append(_compile(src, obj, iddef if src == "cri_capi.cpp" else [], verbose))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -53,16 +123,13 @@ def build(force=False, verbose=True):
     tobjs = [o for o in objs if not o.endswith("cri_capi.o")]
     for src in TESTING_SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + "_testing.o")
-        cmd = [hipcc] + FLAGS + ["-DCRI_TESTING"] + os.environ.get("CRI_HIPCC_EXTRA", "").split() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-        tobjs.append(obj)
+        tobjs.append(_compile(src, obj, ["-DCRI_TESTING"] + (iddef if src == "cri_capi.cpp" else []), verbose))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + tobjs + ["-o", TESTING_LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     build_extension(verbose)
+    assert embedded_id(LIB) == bid and embedded_id(TESTING_LIB) == bid, "the build id did not make it into the libraries"
     return LIB
 
 
@@ -79,4 +146,7 @@ def build_extension(verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--id" in sys.argv:
+        print("tree", source_id(), "lib", embedded_id(LIB), "testing", embedded_id(TESTING_LIB))
+    else:
+        build(force="--force" in sys.argv)

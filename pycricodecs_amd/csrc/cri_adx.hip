@@ -958,7 +958,10 @@ __device__ __forceinline__ bool seg_row_ends(const SegLane& X, uint32_t row) {
 // every segment behind a RUN of silent ones its exact start state in one round, from the last segment with sound before the run.
 #define SEG_NO_STOP 0xFFFFFFFFu
 #define SEG_SILENT 0xFFFFFFFEu          // record word 3: no end-of-stream row, every block of the segment is zeros
-__device__ __forceinline__ uint32_t seg_stop_of(uint32_t w3) { return w3 >= SEG_SILENT ? SEG_NO_STOP : w3; }
+#define SEG_SILENT_AT 0xC0000000u       // ... the same, and the low 30 bits say where the silent run began: 1 + the chain's last segment with sound
+                                        // before this one, 0 if there is none (k_adx_seg_runs; stop rows are below 2^27)
+__device__ __forceinline__ bool seg_is_silent(uint32_t w3) { return w3 >= SEG_SILENT_AT && w3 != SEG_NO_STOP; }
+__device__ __forceinline__ uint32_t seg_stop_of(uint32_t w3) { return w3 >= SEG_SILENT_AT ? SEG_NO_STOP : w3; }
 __device__ __forceinline__ int32_t seg_idle_step(int32_t c0, int32_t c1, int32_t h1, int32_t h2) {
     return clamp_sym((__mul24(c0, h1) >> 12) + (__mul24(c1, h2) >> 12), 0x7FFF);      // seg_block with code 0
 }
@@ -1106,12 +1109,19 @@ __global__ __launch_bounds__(64) void k_adx_seg_fix(AdxArgs a, uint32_t round, u
     if (X.k == 0) { rec[dst] = my_end; return; }
     const uint32_t C = X.S.channels;
     uint32_t prev_end = a.seg_state[4 * (uint64_t)(g - C) + src];
-    if (a.seg_state[4 * (uint64_t)(g - C) + 3] == SEG_SILENT) {
+    const uint32_t prev_w3 = a.seg_state[4 * (uint64_t)(g - C) + 3];
+    if (seg_is_silent(prev_w3)) {
         // behind a run of silent segments: the start state follows from the last segment with sound before the run (or the header's
-        // history), however long the run -- no decode, and no waiting for the run's segments to be repaired one round after the other
-        uint32_t j = X.k - 1;
-        while (j > 0 && a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + 3] == SEG_SILENT) j--;
-        const bool from_start = a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + 3] == SEG_SILENT;      // (j == 0 and silent too)
+        // history), however long the run -- no decode, and no waiting for the run's segments to be repaired one round after the other.
+        // Long chains carry the run's beginning in the record (k_adx_seg_runs: one load); short ones are walked back here -- a walk per lane
+        // and round over a chain of n silent segments would be n^2 dependent loads (an hour of silence is 250 000 segments).
+        uint32_t j; bool from_start;
+        if (prev_w3 != SEG_SILENT) { const uint32_t at = prev_w3 & 0x3FFFFFFFu; from_start = at == 0; j = from_start ? 0 : at - 1; }
+        else {
+            j = X.k - 1;
+            while (j > 0 && seg_is_silent(a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + 3])) j--;
+            from_start = seg_is_silent(a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + 3]);      // (j == 0 and silent too)
+        }
         uint32_t state; uint32_t from_row;
         if (from_start) { const uint32_t chain = X.S.first_chain + X.ch; state = seg_pack(a.history[2 * chain], a.history[2 * chain + 1]); from_row = 0; }
         else { state = a.seg_state[4 * ((uint64_t)g - (uint64_t)(X.k - j) * C) + src]; from_row = (j + 1) * X.S.seg_rows; }
@@ -1123,10 +1133,36 @@ __global__ __launch_bounds__(64) void k_adx_seg_fix(AdxArgs a, uint32_t round, u
     int32_t h1, h2;
     seg_unpack(prev_end, h1, h2);
     const uint32_t stop_row = seg_stop_of(rec[3]), r_end = stop_row < X.r1 ? stop_row : X.r1;
-    const bool merged = seg_repair(X, r_end, h1, h2, rec[3] == SEG_SILENT);
+    const bool merged = seg_repair(X, r_end, h1, h2, seg_is_silent(rec[3]));
     const uint32_t e = merged ? my_end : seg_pack(h1, h2);
     rec[0] = prev_end; rec[dst] = e;
     if (last && e != my_end) atomicOr(&a.seg_flags[X.S.first_chain + X.ch], 1u);     // the next segment started from a stale state
+}
+
+// Where the silent runs of long chains begin: a wave per chain takes 64 of its segments at a time and writes, into the record of every
+// silent one, 1 + the last segment with sound before it (a ballot and a count of leading zeros per step, the carry in a scalar).
+#define SEG_RUNS_MIN 48u                // chains of fewer segments are walked back by k_adx_seg_fix itself
+__global__ __launch_bounds__(64) void k_adx_seg_runs(AdxArgs a) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t chain = blockIdx.x; chain < a.chains; chain += gridDim.x) {
+        uint32_t lo = 0, hi = a.n_streams;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.streams[mid].first_chain <= chain) lo = mid; else hi = mid; }
+        const AdxStream S = a.streams[lo];
+        if (S.seg_count < SEG_RUNS_MIN) continue;
+        const uint32_t ch = chain - S.first_chain, C = S.channels;
+        uint32_t carry = 0;
+        for (uint32_t k0 = 0; k0 < S.seg_count; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const bool on = k < S.seg_count;
+            uint32_t* rec = a.seg_state + 4 * ((uint64_t)S.first_seg + (uint64_t)(on ? k : 0) * C + ch);
+            const bool silent = on && seg_is_silent(rec[3]);
+            const uint64_t sound = __builtin_amdgcn_ballot_w64(on && !silent);
+            const uint64_t below = sound & (~0ull >> (63 - lane));                  // segments with sound at or before this lane's
+            const uint32_t last = below ? k0 + 64 - (uint32_t)__builtin_clzll(below) : carry;
+            if (silent) rec[3] = SEG_SILENT_AT | last;
+            if (sound) carry = k0 + 64 - (uint32_t)__builtin_clzll(sound);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a, uint32_t fin) {
@@ -1160,7 +1196,7 @@ __global__ __launch_bounds__(64) void k_adx_seg_serial(AdxArgs a, uint32_t fin) 
         uint32_t end = rec[fin];                                     // (fin: where the last repair round left the ends)
         if (rec[0] != cur) {                                         // the segment's samples were decoded from rec[0]
             seg_unpack(cur, h1, h2);
-            if (!seg_repair(X, r_end, h1, h2, rec[3] == SEG_SILENT)) end = seg_pack(h1, h2);
+            if (!seg_repair(X, r_end, h1, h2, seg_is_silent(rec[3]))) end = seg_pack(h1, h2);
         }
         if (stop_row != SEG_NO_STOP) stopped = true;
         cur = end;
@@ -1557,6 +1593,7 @@ void launch_adx_decode_seg(const AdxArgs& a, hipStream_t s) {
     if (!a.seg_lanes) return;
     constexpr uint32_t ROUNDS = 6;      // (a round with nothing to repair costs a launch; a chain that is still moving after the last one costs its whole file on the wave-per-file kernel -- 1.6 ms for a 2 s clip, however large the job)
     hipLaunchKernelGGL(k_adx_seg_decode, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a);
+    if (a.seg_max_count >= SEG_RUNS_MIN) hipLaunchKernelGGL(k_adx_seg_runs, dim3(a.chains < 4096 ? a.chains : 4096), dim3(64), 0, s, a);
     for (uint32_t r = 0; r < ROUNDS; r++) hipLaunchKernelGGL(k_adx_seg_fix, dim3((a.seg_lanes + 63) / 64), dim3(64), 0, s, a, r, r + 1 == ROUNDS ? 1u : 0u);
     // Flagged chains.  Histories do not always merge: through digital silence the decoder's state just sits where the last sound left
     // it (the recurrence has fixed points away from zero: -100, -100 maps to -100), so a file with silent stretches keeps every

@@ -4,6 +4,7 @@
 // cipher / ATH tables, header images) is uploaded once, and cri_job_run only enqueues kernels on the caller's
 // stream.  There is no CPU implementation of the per-frame / per-block work in this library.
 #include <hip/hip_runtime.h>
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,6 +107,7 @@ struct Knobs {
     uint64_t host_pull_wgs = 0;                  // the pipelined host path's upload kernel: workgroups (0: the planner's choice)
     uint64_t hca_run = 0;                        // HCA decode: frames of a transform run (0: the planner's choice of 8 / 16 / 32)
     uint64_t adx_seglen = 0;                     // ... least segment length (decode: in warm-ups, default 3; lane encode: per cent of the warm-up, default 50)
+    int bad_launch = 0;                          // every run also launches a kernel with an impossible configuration (what a run reports then is under test)
 };
 // SIMDs of the calling thread's device (CUs x 4): the ADX lane kernels run one row after the other in a lane and are bound by instruction
 // issue per SIMD, so what a dispatch costs is (waves per SIMD, rounded UP) x (rows of its longest lane) -- 1.4 waves per SIMD cost what 2 do
@@ -115,18 +117,36 @@ static uint32_t device_simds() {
     return (uint32_t)cus * 4;
 }
 static int adx_mapping_of(const char* e) {
-    if (!e) return ADX_MAP_AUTO;
-    const char* names[] = {"", "chain", "file", "seg", "lane", "wave"};
-    for (int k = 1; k < 6; k++) if (!strcmp(e, names[k])) return k;
+    if (!e || !*e) return ADX_MAP_AUTO;
+    const char* names[] = {"auto", "chain", "file", "seg", "lane", "wave"};
+    for (int k = 0; k < 6; k++) if (!strcmp(e, names[k])) return k;
+    fprintf(stderr, "cricodecs_hip: CRICODECS_ADX_MAPPING=%s is not one of auto|chain|file|seg|lane|wave: ignored\n", e);
     return ADX_MAP_AUTO;
+}
+// a byte count from the environment: decimal digits only (an optional k / m / g suffix); anything else leaves the default in place
+static void env_bytes(const char* name, uint64_t& field) {
+    const char* e = getenv(name);
+    if (!e) return;
+    char* end = nullptr;
+    errno = 0;
+    const unsigned long long v = strtoull(e, &end, 10);
+    uint64_t mul = 1;
+    if (end && (*end == 'k' || *end == 'K')) { mul = 1ull << 10; end++; }
+    else if (end && (*end == 'm' || *end == 'M')) { mul = 1ull << 20; end++; }
+    else if (end && (*end == 'g' || *end == 'G')) { mul = 1ull << 30; end++; }
+    if (end == e || *end != 0 || errno != 0 || e[0] == '-' || e[0] == '+' || v > (~0ull >> 1) / mul) {
+        fprintf(stderr, "cricodecs_hip: %s=%s is not a byte count: ignored\n", name, e);
+        return;
+    }
+    field = v * mul;
 }
 static Knobs& knobs_mut() {
     static Knobs k;
     static std::once_flag once;
     std::call_once(once, [] {
         k.adx_mapping = adx_mapping_of(getenv("CRICODECS_ADX_MAPPING"));
-        if (const char* e = getenv("CRICODECS_HOST_SLICE_MIN")) k.host_slice_min = strtoull(e, nullptr, 10);
-        if (const char* e = getenv("CRICODECS_HOST_STAGE_PIECE")) k.host_stage_piece = strtoull(e, nullptr, 10);
+        env_bytes("CRICODECS_HOST_SLICE_MIN", k.host_slice_min);
+        env_bytes("CRICODECS_HOST_STAGE_PIECE", k.host_stage_piece);
     });
     return k;
 }
@@ -213,16 +233,29 @@ struct cri_job {
     std::vector<uint16_t> part_subkeys;
     std::vector<cri_job*> host_parts;
     std::vector<uint32_t> host_part_first;       // [parts + 1] first item of each part
-    hipEvent_t last_run = nullptr;
+    // One event per stream the job has been run on (two threads may run one job on their own streams; the host path runs its
+    // parts on private streams): the destructor waits for all of them.  Past 16 streams the oldest entry is waited for and reused.
+    std::mutex run_mu;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> run_events;
     void note_run(hipStream_t s) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
-        if (!last_run && hipEventCreateWithFlags(&last_run, hipEventDisableTiming) != hipSuccess) { last_run = nullptr; return; }
-        (void)hipEventRecord(last_run, s);
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return; }   // (only the query's own error is dropped)
+        if (cs != hipStreamCaptureStatusNone) return;
+        std::lock_guard<std::mutex> lk(run_mu);
+        hipEvent_t ev = nullptr;
+        for (auto& e : run_events) if (e.first == s) { ev = e.second; break; }
+        if (!ev) {
+            if (run_events.size() >= 16) {
+                ev = run_events.front().second; run_events.erase(run_events.begin());
+                (void)hipEventSynchronize(ev);
+            } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+            run_events.emplace_back(s, ev);
+        }
+        (void)hipEventRecord(ev, s);
     }
     ~cri_job() {
         for (cri_job* part : host_parts) delete part;
-        if (last_run) { (void)hipEventSynchronize(last_run); (void)hipEventDestroy(last_run); }
+        for (auto& e : run_events) { (void)hipEventSynchronize(e.second); (void)hipEventDestroy(e.second); }
         for (auto& v : class_events) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     }
 
@@ -274,6 +307,19 @@ struct DeviceGuard {
 }  // namespace
 
 extern "C" void cri_free(void* p) { free(p); }
+
+// Identity of the sources this library was built from (pycricodecs_amd/build.py: source_id()).  The string literal carries a marker in
+// front so that the build script can also find the id in the FILE of a prebuilt library.
+#ifndef CRI_BUILD_ID_STRING
+#define CRI_BUILD_ID_STRING "CRI_BUILD_ID=unstamped"
+#endif
+extern "C" const char* cri_build_id(void) {
+    static const char id[] = CRI_BUILD_ID_STRING;
+    return id + 13;
+}
+#ifdef CRI_TESTING
+extern "C" int cri_is_testing_build(void) { return 1; }
+#endif
 
 extern "C" const char* cri_strerror(int code) {
     static const char* adx[] = {                      // adx.cpp:11-30
@@ -783,6 +829,7 @@ static int create_adx_decode(const ItemSrc& it, cri_job** out, const uint8_t* ta
             S.first_seg = lanes; S.first_chain = chains; S.hist_offset = chains;
             seg_first.push_back(lanes);
             lanes += S.seg_count * S.channels; chains += S.channels;
+            if (S.seg_count > j->adx.seg_max_count) j->adx.seg_max_count = S.seg_count;
             for (uint32_t c = 0; c < S.channels; c++) { history.push_back(pend_hist[hist_at[k] + 2 * c]); history.push_back(pend_hist[hist_at[k] + 2 * c + 1]); }
             streams.push_back(S);
         }
@@ -1663,8 +1710,12 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
         }
         default: return CRI_ERR_UNSUPPORTED;
     }
+#ifdef CRI_TESTING
+    if (knobs().bad_launch) launch_fill_i32_bad((int32_t*)d_out, s);
+#endif
+    const hipError_t launched = hipGetLastError();   // the launches' own verdict, read before anything else can clear it
     j->note_run(s);
-    return hipGetLastError() == hipSuccess ? 0 : CRI_ERR_HIP;
+    return launched == hipSuccess ? 0 : CRI_ERR_HIP;
 }
 
 extern "C" int cri_job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, int32_t* d_status, void* hip_stream) {
@@ -1885,7 +1936,9 @@ bool host_parts_ready(cri_job* j, const HostSrc& src) {
     if (!j->partable || (j->kind != CRI_JOB_ADX_DECODE && j->kind != CRI_JOB_HCA_DECODE) || j->n < 8) return false;
     std::lock_guard<std::mutex> lk(j->parts_mu);
     if (j->parts_tried) return !j->host_parts.empty();
-    j->parts_tried = true;
+    // (latched below: on success, or when the layouts do not match -- a failure of the device (no memory for a part's metadata
+    //  right now) leaves the question open for the next host run)
+    bool transient = false;
     uint32_t K = (uint32_t)((j->in_bytes + j->out_bytes) / HOST_SLICE_BYTES);
     K = K < 4 ? 4 : (K > 64 ? 64 : K);
     if (K > j->n / 2) K = j->n / 2;
@@ -1905,15 +1958,16 @@ bool host_parts_ready(cri_job* j, const HostSrc& src) {
         cri_job* part = nullptr;
         const int prc = j->kind == CRI_JOB_ADX_DECODE ? create_adx_decode(ps, &part)
                       : create_hca_decode(ps, j->part_keys.empty() ? nullptr : j->part_keys.data() + i0, j->part_subkeys.empty() ? nullptr : j->part_subkeys.data() + i0, nullptr, &part);
-        if (prc || !part) { good = false; break; }
+        if (prc || !part) { good = false; transient = prc == CRI_ERR_HIP; break; }
         j->host_parts.push_back(part);
         // (an item starts where its samples are line-aligned, wav_item_start: the part's layout is the parent's moved by whole lines)
         const uint64_t base = j->out_offsets[i0] - part->out_offsets[0];
         good = base % 128 == 0 && j->out_offsets[i0] >= part->out_offsets[0];
         for (uint32_t i = i0; i < i1 && good; i++) good = part->out_offsets[i - i0] + base == j->out_offsets[i] && part->host_status[i - i0] == j->host_status[i];
     }
-    if (!good) { for (cri_job* part : j->host_parts) delete part; j->host_parts.clear(); return false; }
+    if (!good) { for (cri_job* part : j->host_parts) delete part; j->host_parts.clear(); j->parts_tried = !transient; return false; }
     j->host_part_first = first;
+    j->parts_tried = true;
     return true;
 }
 
@@ -2256,6 +2310,7 @@ extern "C" int cri_test_set(const char* key, long long value) {
     else if (!strcmp(key, "adx_seglen")) k.adx_seglen = (uint64_t)value;
     else if (!strcmp(key, "hca_run")) k.hca_run = (uint64_t)value;
     else if (!strcmp(key, "host_pull_wgs")) k.host_pull_wgs = (uint64_t)value;
+    else if (!strcmp(key, "bad_launch")) k.bad_launch = (int)value;
     else return CRI_ERR_INVALID_ARG;
     return 0;
 }

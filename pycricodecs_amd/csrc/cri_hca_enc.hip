@@ -36,6 +36,9 @@ namespace cri {
 __device__ unsigned long long g_enc_prof[1024][16];       // spread over 1024 slots so the atomics do not serialise on one address
 #define ENC_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
 #define ENC_PROF_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_enc_prof[(g * C + c) & 1023][k_], prof_acc[k_]); } while (0)
+#elif defined(CRI_ENC_ASM_MARKS)                           // (phase boundaries as comments in the ISA: tools/debug/enc_isa_phases.py counts between them)
+#define ENC_MARK(k) asm volatile("; ENC_PHASE_END " #k)
+#define ENC_PROF_FLUSH() do {} while (0)
 #else
 #define ENC_MARK(k) do {} while (0)
 #define ENC_PROF_FLUSH() do {} while (0)

@@ -77,6 +77,7 @@ struct AdxArgs {
     // segmented chains: first (segment, channel) lane of every stream (n_streams + 1 entries), the lanes' records
     // {speculative start state, end state, end state after repair, stop row} and one flag word per (stream, channel) chain
     const uint32_t* seg_first; uint32_t n_streams, seg_lanes; uint32_t* seg_state; uint32_t* seg_flags;
+    uint32_t seg_max_count;        // decode: the most segments any chain has (long chains get k_adx_seg_runs)
     uint32_t* seg_ckpt;            // encode: the history after every round of four rows, per channel (the output holds codes, not histories)
 };
 void launch_adx_decode(const AdxArgs& a, hipStream_t s);
@@ -110,6 +111,7 @@ void launch_pcm_convert(const ConvertArgs& a, hipStream_t s);
 void launch_scatter_images(const uint8_t* img, const uint64_t* img_off, const uint64_t* dst_off, uint32_t n, uint8_t* out, hipStream_t s);
 // copies item bodies verbatim (crypt: headers are patched on the host image, frames by the kernel)
 void launch_fill_i32(int32_t* p, int32_t v, uint32_t n, hipStream_t s);
+void launch_fill_i32_bad(int32_t* p, hipStream_t s);
 void launch_pull_host(uint8_t* dst, const uint8_t* src_host, uint64_t bytes, hipStream_t s, uint32_t max_wg = 8);
 
 // USM audio (@SFA) chunk streams, usm.py: byte segments copied between a container and contiguous streams, with the audio

@@ -18,6 +18,9 @@ void launch_fill_i32(int32_t* p, int32_t v, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
 }
 
+// test-only (called from the -DCRI_TESTING planner): a launch the runtime must refuse (more LDS than a compute unit has)
+void launch_fill_i32_bad(int32_t* p, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 1u << 20, s, p, 0, 0u); }
+
 // Host memory -> HBM by the compute units: a few workgroups pull page-locked host memory across the link with 16-byte loads
 // (source-aligned; the head and tail bytes singly).  Used by the pipelined host path for the uploads, so that the downloads have
 // the DMA engines to themselves (cri_capi.cpp, run_host_core).

@@ -1,0 +1,118 @@
+"""GPU parity and robustness, round-5 additions (through the C ABI, against the pinned oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+from pycricodecs_amd import synth
+
+pytestmark = pytest.mark.gpu
+KEY = G.KEY
+
+
+@pytest.fixture(scope="module")
+def cc():
+    from pycricodecs_amd import CriCodecs, _capi
+    assert _capi.lib().cri_device_available() == 1, "no HIP device: the GPU tests must run on the HIP path"
+    return CriCodecs
+
+
+def run_job(job, stream=None):
+    import torch
+    bufs = job.alloc("cuda:0")
+    job.run(*bufs, stream=stream)
+    torch.cuda.synchronize()
+    blob = bytes(bufs[1].cpu().numpy())
+    status = bufs[3].cpu().numpy()[:job.n]
+    return job.split(blob), status
+
+
+# ------------------------------------------------------------------------------------------------ b: a launch that fails is reported
+@pytest.mark.parametrize("captured", [False, True])
+def test_a_failed_launch_is_reported_also_while_capturing(cc, knobs, captured):
+    """cri_job_run's verdict is the launches' own: a kernel the runtime refuses (test knob `bad_launch`: more LDS than a compute unit
+    has) makes the run return CRI_ERR_HIP -- also while the stream is being captured into a hipGraph, where the bookkeeping behind
+    the launches used to clear the error before it was read."""
+    import torch
+    from pycricodecs_amd import _capi
+    from pycricodecs_amd.batch import Job
+    wavs = [synth.wav(5100 + k, 32 * 200, 2, 48000) for k in range(3)]
+    job = Job.adx_encode(wavs)
+    bufs = job.alloc("cuda:0")
+    job.run(*bufs)
+    torch.cuda.synchronize()
+    knobs(bad_launch=1)
+    s = torch.cuda.Stream()
+    if captured:
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(_capi.CriCodecsError) as e:
+            with torch.cuda.graph(g, stream=s):
+                job.run(*bufs)
+        del g
+    else:
+        with pytest.raises(_capi.CriCodecsError) as e:
+            job.run(*bufs, stream=s)
+    assert e.value.code == -301
+    torch.cuda.synchronize()
+    knobs(bad_launch=0)
+    outs, st = run_job(job)                                        # and the job is still good
+    assert not st.any()
+    for o, w in zip(outs, wavs):
+        assert bytes(o) == O.adx_encode(w)
+
+
+# ------------------------------------------------------------------------------------------------ a3: long silent chains
+@pytest.mark.parametrize("warm", [100, 1])
+def test_adx_segmented_decode_of_long_silent_chains(cc, knobs, warm):
+    """A long file that is mostly digital silence: hundreds of silent segments in a row.  k_adx_seg_runs writes where each silent run
+    began into the segments' records (a wave per chain, 64 segments a step), so a lane behind the run finds the last segment with
+    sound in one load instead of walking the run back -- n^2 dependent loads per repair round before.  Segments forced
+    short so that the chains have far more than 64 segments; silent heads, tails and a file of nothing but silence; bytes = oracle."""
+    from pycricodecs_amd.batch import Job
+    knobs(adx_mapping="seg", adx_warm_pct=warm, adx_seglen=1)
+    files = []
+    for k, (secs, ch, hp) in enumerate([(40, 2, 500), (30, 1, 500), (20, 2, 4000), (25, 2, 500)]):
+        n = 48000 * secs
+        x = np.zeros((n, ch), np.int32)
+        if k != 3:
+            burst = synth.pcm16(7000 + k, 9000, ch, 48000).astype(np.int32).reshape(-1, ch)
+            for at in ((n // 7, n // 2, n - 20000) if k != 1 else (0, n // 3)):
+                x[at:at + len(burst)] = burst[:max(0, min(len(burst), n - at))]
+        files.append(O.adx_encode(synth.wav_bytes(x.astype(np.int16), 48000), 4, 18, 3, hp, 0, 4))
+    job = Job.adx_decode(files)
+    assert job.dominant_kernel == "k_adx_seg_decode"
+    outs, st = run_job(job)
+    assert not st.any() and not job.host_status.any()
+    for i, (o, f) in enumerate(zip(outs, files)):
+        assert bytes(o) == O.adx_decode(f), i
+
+
+# ------------------------------------------------------------------------------------------------ b: one job, several streams, destroyed in flight
+def test_job_run_on_several_streams_then_destroyed(cc):
+    """cri_job_destroy waits for the last run on EVERY stream the job was enqueued on (one event per stream, made under a lock): a
+    job run on three streams and dropped at once leaves three correct outputs, and the next job -- which takes over the recycled
+    metadata allocation -- is right as well."""
+    import torch
+    from pycricodecs_amd.batch import Job
+    items = [O.hca_crypt(O.hca_encode(synth.wav(5200 + k, 1024 * 40 + 77 * k, 2, 48000), 1), 1, 56, KEY) for k in range(12)]
+    refs = [O.hca_decode(h, KEY) for h in items]
+    job = Job.hca_decode(items, keys=[KEY] * len(items))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sets = [job.alloc("cuda:0") for _ in streams]
+    for s, bufs in zip(streams, sets):
+        job.run(*bufs, stream=s)
+    offs = [int(job.output_offsets[i]) for i in range(job.n)]
+    del job                                                        # destroyed with work in flight on three streams
+    other = Job.adx_encode([synth.wav(5300 + k, 32 * 500, 2, 48000) for k in range(4)])
+    outs2, st2 = run_job(other)
+    torch.cuda.synchronize()
+    for bufs in sets:
+        assert int(bufs[3].abs().sum().item()) == 0
+        blob = bytes(bufs[1].cpu().numpy())
+        for o, r in zip(offs, refs):
+            assert blob[o:o + len(r)] == r
+    assert not st2.any()
+    for k, o in enumerate(outs2):
+        assert bytes(o) == O.adx_encode(synth.wav(5300 + k, 32 * 500, 2, 48000))
