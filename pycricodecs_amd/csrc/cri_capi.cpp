@@ -167,10 +167,10 @@ struct cri_job {
     // device metadata (one allocation: MetaPool)
     MetaPool meta;
     DevBuf d_formats, d_streams, d_cipher, d_ath, d_img, d_img_off, d_img_dst, d_chain_stream, d_history, d_stale,
-        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert, d_segs, d_crcmul, d_seg_chain, d_enctab;
+        d_frame_sizes, d_first_frame, d_adx_streams, d_adx_order, d_crc_off, d_convert, d_segs, d_crcmul, d_seg_chain, d_enctab, d_enc_hint;
     cri_job() {
         for (DevBuf* b : {&d_formats, &d_streams, &d_cipher, &d_ath, &d_img, &d_img_off, &d_img_dst, &d_chain_stream, &d_history, &d_stale,
-                          &d_frame_sizes, &d_first_frame, &d_adx_streams, &d_adx_order, &d_crc_off, &d_convert, &d_segs, &d_crcmul, &d_seg_chain, &d_enctab}) b->pool = &meta;
+                          &d_frame_sizes, &d_first_frame, &d_adx_streams, &d_adx_order, &d_crc_off, &d_convert, &d_segs, &d_crcmul, &d_seg_chain, &d_enctab, &d_enc_hint}) b->pool = &meta;
     }
     std::vector<ConvertItem> convert;            // WAV items whose samples are converted to PCM16 in scratch before encoding
     uint64_t convert_total = 0;
@@ -202,6 +202,7 @@ struct cri_job {
     struct EncLaunch { uint32_t format, stream_begin, stream_end, frames, channels; };
     std::vector<HcaEncArgs> hca_enc;
     std::vector<uint32_t> hca_enc_crc_off;       // per launch: offset into d_crcmul
+    std::vector<uint32_t> hca_enc_hint_off;      // per launch: offset into d_enc_hint (the stream of every 16th frame)
     uint32_t n_cipher = 0;
     // optional per-kernel-class event timing
     bool events_on = false;
@@ -1581,17 +1582,25 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
     j->out_offsets[n] = out_pos; j->out_bytes = out_pos;
     std::stable_sort(streams.begin(), streams.end(), [](const HcaStream& a, const HcaStream& b) { return a.format < b.format; });
     std::vector<uint16_t> crcmul;
+    std::vector<uint32_t> enc_hint;
     for (size_t b = 0; b < streams.size();) {
         size_t e = b; uint32_t frames = 0;
         const HcaFormat& F = formats[streams[b].format];
         while (e < streams.size() && streams[e].format == streams[b].format) { streams[e].first_frame = frames; frames += streams[e].frames; e++; }
         HcaEncArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
-        a.channels = F.channels; a.frame_size = F.frame_size; a.crc_chunk = (F.frame_size - 2 + 63) / 64;
+        a.channels = F.channels; a.frame_size = F.frame_size; a.crc_chunk = 4 * ((F.frame_size - 2 + 255) / 256);   // whole words per lane
         a.joint = F.stereo_bands > 0 ? 1u : 0u;
+        // frame -> stream without a binary search over the whole table (fourteen dependent loads at the head of every workgroup of a
+        // 10 000-file job): the stream of every 16th frame of the launch; a workgroup walks on from there (a step or two)
+        j->hca_enc_hint_off.push_back((uint32_t)enc_hint.size());
+        for (uint32_t g = 0, sx = (uint32_t)b; g < frames; g += 16) {
+            while (sx + 1 < e && streams[sx + 1].first_frame <= g) sx++;
+            enc_hint.push_back(sx);
+        }
         j->hca_enc_crc_off.push_back((uint32_t)crcmul.size());
         for (uint32_t l = 0; l < 64; l++) {
-            uint32_t v = crc_xpow_bytes(a.crc_chunk * (63 - l));
+            uint32_t v = crc_xpow_bytes(a.crc_chunk * (63 - l) + 2);   // (+ 2 bytes: the checksum is the remainder of message * x^16)
             for (uint32_t bit = 0; bit < 16; bit++) { crcmul.push_back((uint16_t)v); v = ((v << 1) ^ ((v & 0x8000) ? 0x8005u : 0u)) & 0xFFFF; }
         }
         if (hca_encode_lds_bytes(F.channels, F.frame_size) > 160 * 1024) {
@@ -1604,12 +1613,13 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
     if (formats.empty()) { HcaFormat F; memset(&F, 0, sizeof F); formats.push_back(F); }
     if (streams.empty()) { HcaStream S; memset(&S, 0, sizeof S); streams.push_back(S); }
     if (crcmul.empty()) crcmul.assign(1024, 0);
+    if (enc_hint.empty()) enc_hint.push_back(0);
     static std::vector<uint8_t> enctab;                       // the same for every job: built once
     static std::once_flag enctab_once; static int enctab_rc = 0;
     std::call_once(enctab_once, [] { enctab_rc = hca_enc_build_tables(enctab); });
     int rc = enctab_rc;
     if (rc) { delete j; return rc; }
-    if ((rc = j->d_enctab.upload(enctab)) || (rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
+    if ((rc = j->d_enctab.upload(enctab)) || (rc = j->d_formats.upload(formats)) || (rc = j->d_streams.upload(streams)) || (rc = j->d_crcmul.upload(crcmul)) || (rc = j->d_enc_hint.upload(enc_hint)) || (rc = j->upload_images()) || (rc = j->upload_convert())) { delete j; return rc; }
     if ((rc = j->meta.commit())) { delete j; return rc; }
     *out = j;
     return 0;
@@ -1688,6 +1698,7 @@ static int job_run(cri_job* j, const void* d_in, void* d_out, void* d_scratch, i
                 a.in = (const uint8_t*)d_in; a.out = (uint8_t*)d_out; a.status = d_status; a.scratch = (const uint8_t*)d_scratch;
                 a.formats = (const HcaFormat*)j->d_formats.p; a.streams = (const HcaStream*)j->d_streams.p;
                 a.crc_mul = (const uint16_t*)j->d_crcmul.p + j->hca_enc_crc_off[k];
+                a.stream_hint = (const uint32_t*)j->d_enc_hint.p + j->hca_enc_hint_off[k];
                 a.tables = (const uint8_t*)j->d_enctab.p;
                 j->mark(0, true, s); launch_hca_encode(a, s); j->mark(0, false, s);
             }

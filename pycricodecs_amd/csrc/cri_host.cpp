@@ -579,7 +579,7 @@ static int enc_len_of(int r, float x) {
 }
 int hca_enc_build_tables(std::vector<uint8_t>& blob) {
     blob.assign(HCA_ET_BYTES, 0);
-    float* win = (float*)(blob.data() + HCA_ET_WIN);
+    float* win4 = (float*)(blob.data() + HCA_ET_WIN4);
     float* tw = (float*)(blob.data() + HCA_ET_TW);
     float* deq = (float*)(blob.data() + HCA_ET_DEQ);
     float* escale = (float*)(blob.data() + HCA_ET_ESCALE);
@@ -591,15 +591,28 @@ int hca_enc_build_tables(std::vector<uint8_t>& blob) {
     uint8_t* clen = blob.data() + HCA_ET_CLEN;
     uint8_t* code = blob.data() + HCA_ET_CODE;
     uint8_t* ishuf = blob.data() + HCA_ET_ISHUF;
-    for (int i = 0; i < 128; i++) { win[i] = HCA_WINDOW[i] * (1.0f / 32768.0f);   // exact: PcmToFloat's scale folded in (hca.cpp:2470-2479)
-         ishuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
+    for (int i = 0; i < 128; i++) { ishuf[HCA_ENC_SHUFFLE[i]] = (uint8_t)i; clen[i] = HCA_ENC_CODE_LEN[i >> 4][i & 15]; code[i] = HCA_ENC_CODE[i >> 4][i & 15]; }
+    for (int i = 128; i < 256; i++) { clen[i] = (uint8_t)((i >> 4) - 4); code[i] = 0; }      // sign-magnitude codes: the length of a zero (a non-zero value takes one bit more)
+    // the MDCT's window + fold (hca.cpp:2532-2547) as k_hca_encode's lanes use it: point j = l8 + 8 r of a subframe takes the folded
+    // inputs k = 2 j (even) and 127 - 2 j (odd); input k < 64 is  -w[63 - k] x[192 + k] + w[64 + k] x[191 - k],  k >= 64 is
+    // w[k - 64] x[k - 64] + w[191 - k] x[191 - k]  (x = the subframe's 256 samples, previous half first).  The window is held times
+    // 2^-15: PcmToFloat's scale (hca.cpp:2470-2479), exact -- a power of two commutes with the rounding of the product
+    for (int r = 0; r < 8; r++)
+        for (int l8 = 0; l8 < 8; l8++)
+            for (int odd = 0; odd < 2; odd++) {
+                const int k = odd ? 127 - 2 * l8 - 16 * r : 2 * l8 + 16 * r;
+                const bool low = k < 64;
+                const float wa = HCA_WINDOW[low ? 63 - k : k - 64] * (1.0f / 32768.0f), wb = HCA_WINDOW[low ? 64 + k : 191 - k] * (1.0f / 32768.0f);
+                win4[4 * (8 * r + l8) + odd] = low ? -wa : wa;
+                win4[4 * (8 * r + l8) + 2 + odd] = wb;
+            }
     {
         int k = 0;
         const int rows[7] = {7, 5, 4, 3, 2, 1, 0}, count[7] = {64, 32, 16, 8, 4, 2, 1};
         for (int j = 0; j < 7; j++) for (int i = 0; i < count[j]; i++, k++) { tw[2 * k] = HCA_ENC_COS[rows[j]][i]; tw[2 * k + 1] = HCA_ENC_SIN[rows[j]][i]; }
     }
     for (int i = 0; i < 72; i++) deq[i] = i < 63 ? HCA_DEQ_SCALE[i] : f32_from_bits(0x7FC00000u);   // NaN padding never compares <=
-    for (int i = 0; i < 64; i++) escale[i] = HCA_ENC_SCALE[i];
+    for (int i = 0; i < 64; i++) escale[i] = i ? HCA_ENC_SCALE[i] : 0.0f;     // (entry 0 is never used as a factor: scalefactor 0 means zeros, hca.cpp:2641-2644)
     for (int j = 0; j < 32; j++) {                         // entries 0..62 that are <= 2^(j - 25) (hca.cpp:2611-2623 by exponent)
         const float thr = f32_from_bits((uint32_t)(j + 102) << 23);
         int n = 0;
@@ -661,26 +674,26 @@ int hca_enc_build_tables(std::vector<uint8_t>& blob) {
         if (below_p != below_m) return CRI_ERR_INVALID_ARG;
         rank[r] = below_p + 1;
     }
-    // classes by binade: exponent field 114 + i (everything below 2^-13 is under every threshold: row 0), at most two thresholds each
-    for (int i = 0; i < 13; i++)
-        for (int sign = 0; sign < 2; sign++) {
+    // classes by half-binade: a row per (sign, exponent field, top mantissa bit) = the float's top ten bits -- everything below 2^-13
+    // is under every threshold, no half-binade above holds more than one (checked: a table of another shape makes the job fail)
+    for (int sign = 0; sign < 2; sign++)
+        for (uint32_t h = 0; h < 256; h++) {
             const uint32_t* t = sign ? tminus : tplus;
-            uint32_t in_row[16]; uint32_t n = 0, base = 0;
+            uint32_t in_row = 0x7F800000u, n = 0, base = 0;
             for (int r = 1; r < 16; r++) {
-                const uint32_t e = t[r] >> 23;
-                if (e <= 114 || e > 126) return CRI_ERR_INVALID_ARG;      // row 0 also stands for everything smaller: it must be empty
-                if (e < 114u + (uint32_t)i) base++;
-                else if (e == 114u + (uint32_t)i) in_row[n++] = t[r];
+                const uint32_t th = t[r] >> 22;
+                if (th <= 2 * 114 + 1 || th > 2 * 126 + 1) return CRI_ERR_INVALID_ARG;    // the rows up to there stand for everything smaller: they must be empty
+                if (th < h) base++;
+                else if (th == h) { in_row = t[r]; n++; }
             }
-            if (n > 2) return CRI_ERR_INVALID_ARG;
-            if (n == 2 && in_row[0] > in_row[1]) { const uint32_t x = in_row[0]; in_row[0] = in_row[1]; in_row[1] = x; }
-            uint32_t* row = cls + 4 * (2 * i + sign);
-            row[0] = n > 0 ? in_row[0] : 0x7F800000u; row[1] = n > 1 ? in_row[1] : 0x7F800000u; row[2] = base; row[3] = 0;
+            if (n > 1) return CRI_ERR_INVALID_ARG;
+            uint32_t* row = cls + 2 * (512 * sign + h);
+            row[0] = in_row; row[1] = base;
         }
     for (int i = 0; i < 60; i++) {
         const int r = i < 59 ? HCA_ENC_CURVE_TO_RES[i] : 0;
         cp[2 * i + 0] = r ? (16 - rank[r]) * 0x01010101u : 0u;
-        cp[2 * i + 1] = 8 * shortest[r] | anomaly[r] << 8 | (uint32_t)r << 16;
+        cp[2 * i + 1] = 8 * shortest[r] | (uint32_t)r << 20 | anomaly[r] << 28;
     }
     return 0;
 }

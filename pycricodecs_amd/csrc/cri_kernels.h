@@ -53,11 +53,13 @@ struct HcaEncArgs {
     const uint8_t* scratch;        // converted PCM16 (HcaStream::pad0 != 0 -> src_offset is relative to scratch)
     const HcaFormat* formats;
     const HcaStream* streams;      // sorted by format; src_offset = first PCM byte, dst_offset = first frame byte
-    const uint16_t* crc_mul;       // [64][16]: (x^bit * x^(8 * crc_chunk * (63 - lane))) mod P: a lane's chunk remainder times its place in the frame
+    const uint16_t* crc_mul;       // [64][16]: (x^bit * x^(16 + 8 * crc_chunk * (63 - lane))) mod P: a lane's chunk remainder times its place in the frame
+    const uint32_t* stream_hint;   // stream (index into `streams`) of every 16th frame of the launch
     uint32_t format, stream_begin, stream_end, frames, channels, frame_size;
-    uint32_t crc_chunk;            // bytes of the (front-padded) frame each lane checksums
+    uint32_t crc_chunk;            // bytes of the (front-padded) frame each lane checksums: whole words
     uint32_t lds_per_frame;        // LDS bytes of one frame's working set (set by launch_hca_encode)
     uint32_t frames_per_group;     // frames per workgroup (set by launch_hca_encode)
+    uint32_t groups;               // frame groups of the launch: the (persistent) workgroups walk them (set by launch_hca_encode)
     uint32_t joint;                // 1: the format has intensity-stereo bands (a pair's waves wait for each other there: one frame per workgroup)
 };
 size_t hca_encode_lds_bytes(uint32_t channels, uint32_t frame_size);

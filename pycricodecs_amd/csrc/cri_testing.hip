@@ -14,7 +14,7 @@ namespace cri {
 // quantise, look the length up; |x| >= dead zone from resolution 8 on), on "bands" of eight spectra with consecutive bit patterns:
 // thread t takes magnitudes first + 8 * stride * t .. + 7 (and the same negated), at every resolution 1 .. 15.
 __global__ __launch_bounds__(256) void k_test_enc_band_cost(const uint8_t* tables, uint32_t first, uint32_t stride, uint32_t bands, unsigned long long* counts, uint32_t* first_bad) {
-    const uint4* cls = (const uint4*)(tables + HCA_ET_CLS);
+    const uint8_t* cls = tables + HCA_ET_CLS;
     const uint2* cp = (const uint2*)(tables + HCA_ET_CP);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= bands) return;

@@ -70,19 +70,23 @@ static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels
 #define HCA_QC_TILE(C) (8u * (C) * 4u * HCA_QC_QUARTER)              /* bytes of a tile: 2 KB per frame and channel */
 
 // Encoder tables as k_hca_encode keeps them in LDS: one blob, built on the host (hca_enc_build_tables), byte offsets below
-#define HCA_ET_WIN 0          // float[128]   MDCT window (hca.cpp:2529-2553) times 2^-15
-#define HCA_ET_TW 512         // float2[128]  {cos, sin} twiddles, only the entries the lane mapping reads: row 7 [0,64), row 5 [64,96), 4 [96,112), 3 [112,120), 2 [120,124), 1 [124,126), 0 [126]
-#define HCA_ET_DEQ 1536       // float[72]    scale-factor table padded with NaN
-#define HCA_ET_ESCALE 1824    // float[64]
-#define HCA_ET_CP 2080        // uint2[60]    per curve position {(16 - rank) in every byte, 8 * shortest | anomaly << 8 | resolution << 16}; [59] = a band that costs nothing
-#define HCA_ET_CLS 2560       // uint4[13][2] per binade of |x| (exponent field 114 .. 126; below: row 0) and sign: {A, B, classes below, 0}: class = base + (|x| >= A) + (|x| >= B)
-#define HCA_ET_INV 2976       // float[16]    quantiser inverse step per resolution
-#define HCA_ET_IBOUNDS 3040   // float[16]
-#define HCA_ET_SFBASE 3104    // uint8[32]
-#define HCA_ET_CLEN 3136      // uint8[128]
-#define HCA_ET_CODE 3264      // uint8[128]
-#define HCA_ET_ISHUF 3392     // uint8[128]
-#define HCA_ET_BYTES 3520
+#define HCA_ET_TW 0           // float2[128]  {cos, sin} twiddles, only the entries the lane mapping reads: row 7 [0,64), row 5 [64,96), 4 [96,112), 3 [112,120), 2 [120,124), 1 [124,126), 0 [126]
+#define HCA_ET_DEQ 1024       // float[72]    scale-factor table padded with NaN
+#define HCA_ET_ESCALE 1312    // float[64]
+#define HCA_ET_CP 1568        // uint2[60]    per curve position {(16 - rank) in every byte, 8 * shortest | resolution << 20 | anomaly << 28}; [59] = a band that costs nothing.  (The second word is
+                              //              summed as it is over bands, lanes and channels by the rate loop: the bits are the low 20 bits of that sum -- at most 8 x 128 x 96)
+#define HCA_ET_INV 2048       // float[16]    quantiser inverse step per resolution
+#define HCA_ET_IBOUNDS 2112   // float[16]
+#define HCA_ET_SFBASE 2176    // uint8[32]
+#define HCA_ET_ISHUF 2208     // uint8[128]
+#define HCA_ET_CLEN 2336      // uint8[256]   code length by resolution * 16 + quantiser index; rows 8 .. 15 (sign-magnitude codes): resolution - 4, the length of a zero
+#define HCA_ET_CODE 2592      // uint8[256]   code; rows 8 .. 15: 0
+#define HCA_ET_WIN4 2848      // float4[8][8] the MDCT window: [register r][lane & 7] = the four factors of the point's two folded inputs (hca.cpp:2529-2553), times 2^-15, with
+                              //              the fold's signs: {even a, odd a, even b, odd b}
+#define HCA_ET_LDS_BYTES 4896 // ... up to here the blob is copied into LDS; what follows is read from memory (every lane its own row: the L1 holds the 0.5 KB that are ever hit)
+#define HCA_ET_CLS 4896       // uint2[768]   row (x >> 22: sign, exponent field, top mantissa bit -- a half-binade), |x| < 1: {A, classes below}: class = base + (|x| >= A).  Rows
+                              //              256 .. 511 (exponents no |x| < 1 has) are never read
+#define HCA_ET_BYTES 11040
 #define HCA_ENC_CLAMP_BITS 0x3F7FFFFEu   // ScaleSpectra's clamp 0.9999999f (hca.cpp:2639-2654): the one value the quantiser can push past its table
 
 

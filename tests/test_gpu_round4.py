@@ -55,9 +55,9 @@ def test_hca_encoder_band_cost_rule_on_the_device(cc):
     clamp) of both signs, in bands of eight consecutive bit patterns -- 1.07 G floats x 2 signs, nothing sampled."""
     from pycricodecs_amd import _capi
     with _capi.testing_knobs() as L:
-        tab = (C.c_uint8 * 4096)()
+        tab = (C.c_uint8 * 16384)()
         L.cri_test_enc_tables.argtypes = [C.c_void_p, C.c_size_t]
-        assert L.cri_test_enc_tables(tab, 4096) > 0
+        assert L.cri_test_enc_tables(tab, 16384) > 0
         L.cri_test_enc_band_cost.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint32)]
         cases, bad, first = C.c_ulonglong(), C.c_ulonglong(), (C.c_uint32 * 4)()
         clamp = 0x3F7FFFFE

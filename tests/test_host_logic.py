@@ -156,46 +156,68 @@ def test_header_walk_mutation_fuzz_vs_oracle(shim):
 
 def test_encoder_threshold_tables_equal_the_quantiser_rule(shim):
     """k_hca_encode's rate loop never quantises (hca.cpp:2763-2790): a spectrum is classed once -- how many of the fifteen
-    resolutions' length thresholds of its sign it reaches, from a table row per binade and sign -- and costs
+    resolutions' length thresholds of its sign it reaches, from a table row per half-binade and sign -- and costs
     shortest[r] + (class + (16 - rank[r]) >= 16) at resolution r, minus the clamp-value anomaly.  The tables come from
     hca_enc_build_tables; here the rule is held against the reference's own expression -- (int)(x * inv + (inv + 1)) -
     (int)(inv + 0.5 - 8) into QuantizeSpectrumBits, |x| >= dead zone for resolutions 8..15 -- on every float within 4096 ulps of
     a threshold, the clamp value and its neighbours, the smallest magnitudes, and two million random values per resolution."""
-    ET_CP, ET_CLS, ET_INV, ET_CLEN, ET_BYTES = 2080, 2560, 2976, 3136, 3520
+    ET_CP, ET_CLS, ET_INV, ET_CLEN, ET_CODE, ET_WIN4, ET_BYTES = 1568, 4896, 2048, 2336, 2592, 2848, 11040          # cri_types.h, HCA_ET_*
     CLAMP = 0x3F7FFFFE
-    buf = (C.c_uint8 * 4096)()
+    buf = (C.c_uint8 * 16384)()
     shim.shim_hca_enc_tables.argtypes = [C.c_void_p, C.c_size_t]
-    assert shim.shim_hca_enc_tables(buf, 4096) == ET_BYTES
+    assert shim.shim_hca_enc_tables(buf, 16384) == ET_BYTES
     blob = bytes(buf)[:ET_BYTES]
     cp = np.frombuffer(blob, dtype=np.uint32, count=120, offset=ET_CP).reshape(60, 2)
-    cls = np.frombuffer(blob, dtype=np.uint32, count=104, offset=ET_CLS).reshape(13, 2, 4)
+    rows = np.frombuffer(blob, dtype=np.uint32, count=768 * 2, offset=ET_CLS).reshape(768, 2)
+    cls = np.stack([rows[0:256], rows[512:768]], axis=1)           # [half-binade = top bits of |x|][sign]; rows 256 .. 511 are never read
+    assert all((cls[h, s] == (0x7F800000, 0)).all() for h in range(2 * 114 + 2) for s in range(2))      # below 2^-12: under every threshold
+    assert (cls[254:, :, 1] == 15).all()
     inv_tab = np.frombuffer(blob, dtype=np.float32, count=16, offset=ET_INV)
-    clen = np.frombuffer(blob, dtype=np.uint8, count=128, offset=ET_CLEN).reshape(8, 16)
+    clen_all = np.frombuffer(blob, dtype=np.uint8, count=256, offset=ET_CLEN).reshape(16, 16)
+    code_all = np.frombuffer(blob, dtype=np.uint8, count=256, offset=ET_CODE).reshape(16, 16)
+    clen = clen_all[:8]
+    for r in range(8, 16):                                         # sign-magnitude resolutions: the length of a zero, no code
+        assert (clen_all[r] == r - 4).all() and (code_all[r] == 0).all()
+    # the window rows: point j = l8 + 8 r takes folded inputs k = 2 j and 127 - 2 j (hca.cpp:2532-2547), window times 2^-15
+    win4 = np.frombuffer(blob, dtype=np.float32, count=256, offset=ET_WIN4).reshape(8, 8, 4)
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "cri_tables.h")).read()       # (generated from the reference: tools/gen_tables.py)
+    w = [float.fromhex(t) for t in re.findall(r"[-0-9a-fx.]+p[-+]?\d+(?=f)", text[text.index("HCA_WINDOW[128]"):].split("};")[0])]
+    assert len(w) == 128
+    for r in range(8):
+        for l8 in range(8):
+            for odd in range(2):
+                k = 127 - 2 * l8 - 16 * r if odd else 2 * l8 + 16 * r
+                low = k < 64
+                wa = np.float32(w[63 - k if low else k - 64]) * np.float32(1.0 / 32768.0)
+                wb = np.float32(w[64 + k if low else 191 - k]) * np.float32(1.0 / 32768.0)
+                assert win4[r, l8, odd] == (-wa if low else wa) and win4[r, l8, 2 + odd] == wb
     curve = [15, 14, 14, 14, 14, 14, 14, 13, 13, 13, 13, 13, 13, 12, 12, 12, 12, 12, 12, 11, 11, 11, 11, 11, 11, 10, 10, 10, 10, 10, 10, 10,
              9, 9, 9, 9, 9, 9, 8, 8, 8, 8, 8, 8, 7, 6, 6, 5, 4, 4, 4, 3, 3, 3, 2, 2, 2, 2, 1]
     dead = {8: 0x3D042108, 9: 0x3C820821, 10: 0x3C010204, 11: 0x3B808081, 12: 0x3B004020, 13: 0x3A802008, 14: 0x3A001002, 15: 0x39800801}
-    thresholds = sorted(set(int(t) for t in cls[:, :, 0:2].reshape(-1) if t != 0x7F800000))
+    thresholds = sorted(set(int(t) for t in cls[:, :, 0].reshape(-1) if t != 0x7F800000))
     assert len(thresholds) == 22                                   # fifteen per sign; the eight dead zones serve both signs
 
     def classes(x):                                                # what the kernel does per spectrum
         u = x.view(np.uint32)
-        e = np.maximum(((u >> 23) & 0xFF).astype(np.int64) - 114, 0)
-        assert e.max() <= 12
-        row = cls[e, (u >> 31).astype(np.int64)]
+        h = ((u >> 22) & 0x1FF).astype(np.int64)
+        assert h.max() <= 253
+        row = cls[h, (u >> 31).astype(np.int64)]
         ax = np.abs(x)
-        return row[:, 2].astype(np.int64) + (ax >= row[:, 0].copy().view(np.float32)) + (ax >= row[:, 1].copy().view(np.float32))
+        return row[:, 1].astype(np.int64) + (ax >= row[:, 0].copy().view(np.float32))
 
     rng = np.random.default_rng(5)
     seen = set()
     for pos in range(59):
         r = curve[pos]
-        assert cp[pos, 1] >> 16 == r
+        assert (cp[pos, 1] >> 20) & 15 == r
         if r in seen:
             continue
         seen.add(r)
         k = int(cp[pos, 0] & 0xFF)
         assert cp[pos, 0] == k * 0x01010101 and 1 <= k <= 15
-        shortest, anomaly = int(cp[pos, 1] & 0xFF) // 8, int(cp[pos, 1] >> 8) & 1
+        shortest, anomaly = int(cp[pos, 1] & 0xFF) // 8, int(cp[pos, 1] >> 28) & 1
         mags = [np.arange(max(0, t - 4096), min(CLAMP, t + 4096) + 1, dtype=np.uint32) for t in thresholds]
         mags += [np.arange(CLAMP - 64, CLAMP + 1, dtype=np.uint32), np.arange(0, 64, dtype=np.uint32),
                  rng.integers(0, CLAMP + 1, 2_000_000, dtype=np.uint32)]
