@@ -103,11 +103,11 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 #define ENC_X_HBITS 0        // int[8]      header bits per channel
 #define ENC_X_STEP 32        // int[2][8]   a search step's bits per channel (two slots, used alternately)
 #define ENC_X_TOTA 96        // int[8]      the channels' bits at the final noise level
-#define ENC_X_ROWTOT 128     // uint[64]    bits of the 8 x C rows of spectra, in stream order (subframe, channel)
-#define ENC_X_INTEN 384      // uint8[8][8] intensity indices (written by the pair's primary, packed by the secondary)
-#define ENC_X_BYTES 448
+#define ENC_X_INTEN 128      // uint8[8][8] intensity indices (written by the pair's primary, packed by the secondary)
+#define ENC_X_ROWTOT 192     // uint[8 * C] bits of the 8 x C rows of spectra, in stream order (subframe, channel)
+#define ENC_X_BYTES(C) (192 + 32 * (C))
 #define ENC_CH_SPEC 0        // one piece, three lives: float[1216] the frame's samples of this channel (128 of history first; padded, see ENC_STG_PAD) until the MDCT has read them;
-#define ENC_CH_STG 0         // float2[8][72] the MDCT's change of places; float[8][128] the channel's spectra (MDCT output); afterwards int[130]: the
+#define ENC_CH_STG 0         // float2[8][72] the MDCT's change of places; float[8][132] the channel's spectra (MDCT output, ENC_SP_ROW); afterwards int[130]: the
                              // boundary search's prefix
 // (the region's last 256 bytes hold samples only -- the transposes and the spectra end at 4608 -- so what is written after the MDCT lives there)
 #define ENC_CH_HAVG 4608     // float[8]
@@ -119,6 +119,9 @@ __device__ __forceinline__ void put_bits(uint32_t* words, uint32_t p, uint32_t v
 // subframes to a group of 32 lanes, all four on the same banks if the blocks lay 128 words apart.  Block k is shifted by (k >> 1) * 16 +
 // (k & 1): any four consecutive blocks then start on banks {0, 1, 16, 17} (mod 32), and a group's 32 words fall on 32 banks.
 #define ENC_STG_PAD(k) ((((k) >> 1) << 4) | ((k) & 1))
+// The spectra, a row of 128 per subframe: rows lie 132 words apart -- a band of all eight subframes (what the MDCT's last stage stores, what
+// the sequential sums of intensity stereo and HFR read) is then eight banks, not one
+#define ENC_SP_ROW 132
 
 struct EncFmt {
     uint32_t frame_size, total, base, stereo, groups, bpg, hfr_band_count, types;
@@ -165,7 +168,7 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, int sf0, int 
 #ifdef ENC_MIN_WAVES_PER_SIMD
 #define ENC_WAVES_PER_SIMD(CT) ENC_MIN_WAVES_PER_SIMD
 #else
-#define ENC_WAVES_PER_SIMD(CT) ((CT) >= 5 ? 6 : 5)
+#define ENC_WAVES_PER_SIMD(CT) ((CT) == 1 ? 5 : 6)
 #endif
 #define ENC_WAVES_PER_SIMD_OF(c) ((uint32_t)ENC_WAVES_PER_SIMD((int)(c)))
 #ifndef ENC_MAX_WAVES
@@ -174,8 +177,9 @@ __device__ __forceinline__ void enc_header_length(const EncFmt& F, int sf0, int 
 
 // CT = channels of the format (1 .. 8); workgroup = FPG frames x CT waves
 template <int CT>
-// (waves per SIMD by channel count: 96 registers -- a few spilled -- for five waves up to four channels, 80 for six from five channels on,
-//  where workgroups of 5 .. 8 waves otherwise leave wave slots empty; the channel regions' LDS (4.8 KB each) leaves room for either)
+// (waves per SIMD: 80 registers for six -- three dwords spilled in the stereo instance -- wherever the LDS lets six workgroups' worth of
+//  waves onto a compute unit (two channels and more: 26 KB per four waves; stereo 155 -> 165 M frames/s against five waves at 90 registers);
+//  mono's four frames per workgroup are 28 KB: five)
 __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT) * CT), ENC_WAVES_PER_SIMD(CT)) void k_hca_encode(HcaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr uint32_t C = CT;
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
     uint8_t* fr = smem_all + HCA_ET_LDS_BYTES + 16 + fw * a.lds_per_frame;
     int* X_hbits = (int*)(fr + ENC_X_HBITS); int* X_step = (int*)(fr + ENC_X_STEP); int* X_totA = (int*)(fr + ENC_X_TOTA);
     uint32_t* X_rowtot = (uint32_t*)(fr + ENC_X_ROWTOT); uint8_t* X_inten = fr + ENC_X_INTEN;
-    uint32_t* words = (uint32_t*)(fr + ENC_X_BYTES);
-    uint8_t* ch0 = fr + ENC_X_BYTES + ((nwords * 4 + 15) & ~15u);
+    uint32_t* words = (uint32_t*)(fr + ENC_X_BYTES(C));
+    uint8_t* ch0 = fr + ENC_X_BYTES(C) + ((nwords * 4 + 15) & ~15u);
     uint8_t* chb = ch0 + c * ENC_CH_BYTES;
     float* sp = (float*)(chb + ENC_CH_SPEC);
     float* stg = (float*)(chb + ENC_CH_STG);
@@ -248,9 +252,9 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             auto stage = [&](uint32_t k, uint32_t s, uint32_t blk, float v) { ((float*)(ch0 + k * ENC_CH_BYTES + ENC_CH_STG))[s + ENC_STG_PAD(blk)] = v; };   // blk = s >> 7
             if (!st.enc_loop && rlo == -128 && rhi == 1024) {      // the whole window lies inside the stream: 576 * C dwords, 9 per thread
                 uint32_t dw[9];
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 9; j++) dw[j] = ld_u32_unaligned(fbase + 4 * (tidf + 64 * C * j));
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 9; j++) {
                     const uint32_t e0 = 2 * (tidf + 64 * C * j);
                     // (a thread's samples of round j lie in block j: its dwords start at sample frame (tidf + 64 C j) * 2 / C, and tidf * 2 / C < 128)
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             const float* swa = stg + sfm * 128 + ENC_STG_PAD(sfm);
             const float* swb = stg + sfm * 128 + ENC_STG_PAD(sfm + 1);
             f2 z[8];
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < 8; r++) {
                 // folded inputs k = 2j (even) and 127 - 2j (odd) of point j: hca.cpp:2532-2547 -- for k < 64 (even inputs of r < 4, odd ones
                 // of r >= 4)  -w[63 - k] x[192 + k] + w[64 + k] x[191 - k],  else  w[k - 64] x[k - 64] + w[191 - k] x[191 - k];  the four
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             }
     #define ENC_BFLY(LO, HI, TW) { const f2 d_ = z[LO] - z[HI]; z[LO] = z[LO] + z[HI]; z[HI] = enc_rot(d_, TW); }
             {   // bit 5: (z[r], z[r + 4]), twiddle [5][l8 + 8 r]
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; r++) ENC_BFLY(r, r + 4, T.tw[64 + l8 + 8 * r])
             }
             {   // bit 4: (z[r], z[r + 2]), twiddle [4][l8 + 8 (r & 1)]
@@ -332,14 +336,14 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             // staging rows: every sample has been read by now, and the spectra are stored after the last load below.
             f2* tb = (f2*)chb + sfm * 72;
             wave_lds_sync();
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < 8; r++) tb[l8 + 9 * r] = z[r];
             wave_lds_sync();
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < 8; r++) z[r] = tb[9 * l8 + r];
             wave_lds_sync();
             {   // bit 2: (z[r], z[r + 4]), twiddle [2][r]
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; r++) ENC_BFLY(r, r + 4, T.tw[120 + r])
             }
             {   // bit 1: (z[r], z[r + 2]), twiddle [1][r & 1]
@@ -354,8 +358,8 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             // point j = 8 l8 + r holds spectrum lines ishuf[2j], ishuf[2j + 1] (the inverse of the final shuffle), scaled by 1/8
             const uint4 op = *(const uint4*)(T.ishuf + 16 * l8);
             const uint32_t opw[4] = {op.x, op.y, op.z, op.w};
-            float* out = sp + sfm * 128;
-    #pragma unroll
+            float* out = sp + sfm * ENC_SP_ROW;
+#pragma unroll
             for (int r = 0; r < 8; r++) {
                 const f2 o = z[r] * f2{0.125f, 0.125f};
                 const uint32_t w = opw[r >> 1] >> (16 * (r & 1));
@@ -375,14 +379,14 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 float* sums = havg;                                // [24] (the HFR averages use this piece later)
                 if (lane < 24) {
                     const uint32_t sfl = lane & 7, kind = lane >> 3;
-                    const float* l = lsp + sfl * 128; const float* r = rsp + sfl * 128;
+                    const float* l = lsp + sfl * ENC_SP_ROW; const float* r = rsp + sfl * ENC_SP_ROW;
                     float acc = 0;
                     uint32_t b = F.base;
                     for (; b + 8 <= F.total; b += 8) {
                         float t[8];
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < 8; k++) { const float lv = l[b + k], rv = r[b + k]; t[k] = fabsf(kind == 0 ? lv : (kind == 1 ? rv : lv + rv)); }
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < 8; k++) acc += t[k];
                     }
                     for (; b < F.total; b++) { const float lv = l[b], rv = r[b]; acc += fabsf(kind == 0 ? lv : (kind == 1 ? rv : lv + rv)); }
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                     else if ((double)ratio > sqrt(2.0) / 2) ratio = (float)(sqrt(2.0) / 2);
                     // the first entry of the descending table below the stored value (hca.cpp:2591-2593) = one more than the entries 1 .. 12 at or above it
                     int q = 1;
-    #pragma unroll
+#pragma unroll
                     for (int k = 1; k < 13; k++) q += T.ibounds[k] >= stored ? 1 : 0;
                     if (!(er > 0 || el > 0)) { q = 0; ratio = 1; }
                     X_inten[(c + 1) * 8 + lane] = (uint8_t)q;
@@ -410,14 +414,14 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 // (l + r) * ratio into the primary, zeros into the secondary: a lane takes a band of all eight subframes, everything
                 // fetched before anything is stored
                 float rt[8];
-    #pragma unroll
+#pragma unroll
                 for (int sf = 0; sf < 8; sf++) rt[sf] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(myratio), sf));
                 for (uint32_t b = F.base + lane; b < F.total; b += 64) {
                     float sv[8];
-    #pragma unroll
-                    for (int sf = 0; sf < 8; sf++) sv[sf] = lsp[sf * 128 + b] + rsp[sf * 128 + b];
-    #pragma unroll
-                    for (int sf = 0; sf < 8; sf++) { lsp[sf * 128 + b] = sv[sf] * rt[sf]; rsp[sf * 128 + b] = 0; }
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) sv[sf] = lsp[sf * ENC_SP_ROW + b] + rsp[sf * ENC_SP_ROW + b];
+#pragma unroll
+                    for (int sf = 0; sf < 8; sf++) { lsp[sf * ENC_SP_ROW + b] = sv[sf] * rt[sf]; rsp[sf * ENC_SP_ROW + b] = 0; }
                 }
             }
             __syncthreads();
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 for (int i = 0; i < bpg; i++) {
                     const int band = hfr_start + grp * bpg + i;
                     if (band >= 128) break;
-                    for (int sf = 0; sf < 8; sf++) sum += fabsf(sp[sf * 128 + band]);
+                    for (int sf = 0; sf < 8; sf++) sum += fabsf(sp[sf * ENC_SP_ROW + band]);
                     count += 8;
                 }
                 havg[grp] = sum / (float)count;
@@ -451,9 +455,9 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         int sfr[2]; uint32_t ntop[2];
         {
             float m0 = 0, m1 = 0;
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) {
-                xr[sf] = *(const f2*)(sp + sf * 128 + b0);
+                xr[sf] = *(const f2*)(sp + sf * ENC_SP_ROW + b0);
                 m0 = fmaxf(m0, fabsf(xr[sf].x)); m1 = fmaxf(m1, fabsf(xr[sf].y));      // (the largest magnitude, hca.cpp:2627-2631: no NaNs here)
             }
             uint32_t s0 = (uint32_t)enc_find_scalefactor(T, m0), s1 = (uint32_t)enc_find_scalefactor(T, m1);
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             // ScaleSpectra, hca.cpp:2639-2654: a band without a scalefactor (and every band past the coded range) is zeros -- the table's
             // entry 0 is 0.0 for that (cri_host.cpp; a zero of either sign: nothing below tells them apart)
             const f2 e01 = f2{T.escale[s0], T.escale[s1]};
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) {
                 const f2 v = xr[sf] * e01;
                 xr[sf] = f2{__builtin_amdgcn_fmed3f(v.x, -0.9999999f, 0.9999999f), __builtin_amdgcn_fmed3f(v.y, -0.9999999f, 0.9999999f)};   // hca.cpp:2646-2649 (the products are never NaN)
@@ -472,16 +476,16 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             // values that sit on the clamp (the quantiser's one irregular input, cri_host.cpp): counted per band, in the rare frame that has any
             ntop[0] = ntop[1] = 0;
             if (__builtin_amdgcn_ballot_w64(m0 * e0 >= 0.9999999f || m1 * e1 >= 0.9999999f) != 0) {
-    #pragma unroll
+#pragma unroll
                 for (int sf = 0; sf < 8; sf++) {
                     ntop[0] += enc_on_clamp(xr[sf].x); ntop[1] += enc_on_clamp(xr[sf].y);
                 }
             }
             // class of every spectrum: how many of the fifteen resolutions' thresholds (of its sign) it reaches
             cl[0][0] = cl[0][1] = cl[1][0] = cl[1][1] = 0;
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) {
-    #pragma unroll
+#pragma unroll
                 for (int b = 0; b < 2; b++) {
                     const uint32_t k = enc_class(T.cls, b ? xr[sf].y : xr[sf].x);
                     cl[b][sf >> 2] |= k << (8 * (sf & 3));
@@ -494,8 +498,8 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 
         // ---- CalculateHfrScale, hca.cpp:2676-2706: sequential sums over the scaled spectra of the bands below the HFR range
         if (hfr) {
-    #pragma unroll
-            for (int sf = 0; sf < 8; sf++) *(f2*)(sp + sf * 128 + b0) = xr[sf];
+#pragma unroll
+            for (int sf = 0; sf < 8; sf++) *(f2*)(sp + sf * ENC_SP_ROW + b0) = xr[sf];
             wave_lds_sync();
             const int bpg = (int)F.bpg;
             const int hb = (int)(F.hfr_band_count < F.total - F.hfr_band_count ? F.hfr_band_count : F.total - F.hfr_band_count);
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 for (int i = 0; i < bpg; i++) {
                     const int band = grp * bpg + i;
                     if (band >= hb) break;
-                    for (int sf = 0; sf < 8; sf++) sum += fabsf(sp[sf * 128 + (hfr_start - band - 1)]);
+                    for (int sf = 0; sf < 8; sf++) sum += fabsf(sp[sf * ENC_SP_ROW + (hfr_start - band - 1)]);
                     count += 8;
                 }
                 const float avg = sum / (float)count;
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         // A band sits at curve position noise - kb; the table row of that position holds its resolution's thresholds and shortest code.
         int kb[2]; bool live[2];
         auto band_setup = [&]() {
-    #pragma unroll
+#pragma unroll
             for (int b = 0; b < 2; b++) { kb[b] = 5 * sfr[b] / 2 - 2; live[b] = (b ? b1 : b0) < coded && sfr[b] != 0; }
         };
         auto row_of = [&](int noise, int b) -> uint2 {
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                     if (c == 0 && lane < 8) X_step[((round + 1) & 1) * 8 + lane] = 0;      // the next round's sums (last read before the round before this one ended)
                     __syncthreads();
                     hbtot = 16 + 16 + 16;
-    #pragma unroll
+#pragma unroll
                     for (uint32_t k = 0; k < C; k++) hbtot += X_hbits[k];
                 } else hbtot = 16 + 16 + 16 + hbits_c;
                 int low = 0, high = done ? 0 : 255;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 // than the two further adds here) -- and read the total back behind the step's barrier
                 auto steps = [&](auto tops_c) {
                     int* slot = X_step + (round & 1) * 8;
-    #pragma unroll
+#pragma unroll
                     for (int step = 0; step < 8; step++) {     // 256 levels: always 8 steps
                         const int mid = (low + high) / 2;
                         int bits;
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 if (lane == 0) X_totA[c] = totA;
                 __syncthreads();
                 v0 = v1 = hbtot;
-    #pragma unroll
+#pragma unroll
                 for (uint32_t k = 0; k < C; k++) {
                     const uint2 p = *(const uint2*)((const uint32_t*)(ch0 + k * ENC_CH_BYTES + ENC_CH_SPEC) + b0);
                     const int t = X_totA[k];
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         // ---- CalculateFrameResolutions (hca.cpp:2868-2876), PackFrame (hca.cpp:2938-2963): sync word, 9+7 bit header, then per
         //      channel scalefactors + intensity / HFR scales
         int rb[2];
-    #pragma unroll
+#pragma unroll
         for (int b = 0; b < 2; b++) {
             const int i = (int)(b ? b1 : b0);
             const uint2 t = row_of(i < eval_boundary ? noise_level - 1 : noise_level, b);
@@ -725,15 +729,15 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
             // resolution - 4 bits for a zero, one more otherwise, (|q| << 1 | sign).  One formula serves both: the table's rows 8 .. 15 hold the
             // length of a zero and no code, `wide` adds the bit of a non-zero value and `wmask` lets the sign-magnitude code through.
             int downb[2]; float invb[2], upb[2]; uint32_t wmask[2], r16[2]; bool wide[2];
-    #pragma unroll
+#pragma unroll
             for (int b = 0; b < 2; b++) {
                 invb[b] = T.inv[rb[b]]; upb[b] = invb[b] + 1; downb[b] = (int)((double)invb[b] + 0.5);
                 wide[b] = rb[b] >= 8; wmask[b] = wide[b] ? (2u << (rb[b] - 4)) - 1 : 0u; r16[b] = (uint32_t)rb[b] * 16;
             }
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) {
                 uint32_t code[2], len[2];
-    #pragma unroll
+#pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int q = (int)((h ? xr[sf].y : xr[sf].x) * invb[h] + upb[h]) - downb[h];
                     const uint32_t ti = (((uint32_t)q + 8) & 15) | r16[h];
@@ -750,22 +754,22 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
         uint32_t rowbase[8];
         if (XCH) {
             if (lane == 63) {
-    #pragma unroll
+#pragma unroll
                 for (int sf = 0; sf < 8; sf++) X_rowtot[sf * C + c] = incl[sf] & 0xFFFF;
             }
             __syncthreads();
             const uint32_t mine = lane < 8 * C ? X_rowtot[lane] : 0u;          // stream order: subframe-major
             const uint32_t ex = wave_incl_scan_dpp(mine) - mine;
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) rowbase[sf] = (uint32_t)__builtin_amdgcn_readlane((int)ex, sf * (int)C + (int)c);
         } else {
             uint32_t acc = 0;
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) { rowbase[sf] = acc; acc += (uint32_t)__builtin_amdgcn_readlane((int)incl[sf], 63) & 0xFFFF; }
         }
         if (status == 0) {
             const uint32_t start = (uint32_t)hbtot - 16;       // sync + header + every channel's scalefactor part
-    #pragma unroll
+#pragma unroll
             for (int sf = 0; sf < 8; sf++) {
                 const uint32_t tl = incl[sf] >> 16;
                 // BitWriter drops writes that do not fit (IO.cpp:131-134); the rate loop guarantees they do
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 {
                     const uint32_t wr[8] = {cw0.x, cw0.y, cw0.z, cw0.w, cw1.x, cw1.y, cw1.z, cw1.w};
                     uint32_t acc = 0;
-        #pragma unroll
+    #pragma unroll
                     for (uint32_t bit = 0; bit < 16; bit++) acc ^= (0u - ((crc >> bit) & 1u)) & (wr[bit >> 1] >> (16 * (bit & 1)));
                     acc &= 0xFFFFu;
                     acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xF, 0xF, true);      // the scan's pattern, with xor
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 // LDS of one frame: exchange words, frame image, a region per channel
 size_t hca_encode_lds_per_frame(uint32_t C, uint32_t frame_size) {
     const size_t nwords = (frame_size + 3) / 4 + 2;
-    return ENC_X_BYTES + ((nwords * 4 + 15) & ~(size_t)15) + (size_t)C * ENC_CH_BYTES;
+    return ENC_X_BYTES(C) + ((nwords * 4 + 15) & ~(size_t)15) + (size_t)C * ENC_CH_BYTES;
 }
 // frames per workgroup
 uint32_t hca_encode_frames_per_group(uint32_t C, uint32_t frame_size, bool joint = false) {

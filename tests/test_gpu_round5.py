@@ -54,7 +54,7 @@ def test_a_failed_launch_is_reported_also_while_capturing(cc, knobs, captured):
     else:
         with pytest.raises(_capi.CriCodecsError) as e:
             job.run(*bufs, stream=s)
-    assert e.value.code == -301
+    assert e.value.code == -303                                   # CRI_ERR_HIP
     torch.cuda.synchronize()
     knobs(bad_launch=0)
     outs, st = run_job(job)                                        # and the job is still good
