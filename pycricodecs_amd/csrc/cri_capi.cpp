@@ -1590,7 +1590,6 @@ static int create_hca_encode(const ItemSrc& it, uint32_t force_no_looping, uint3
         HcaEncArgs a; memset(&a, 0, sizeof a);
         a.format = streams[b].format; a.stream_begin = (uint32_t)b; a.stream_end = (uint32_t)e; a.frames = frames;
         a.channels = F.channels; a.frame_size = F.frame_size; a.crc_chunk = 4 * ((F.frame_size - 2 + 255) / 256);   // whole words per lane
-        a.joint = F.stereo_bands > 0 ? 1u : 0u;
         // frame -> stream without a binary search over the whole table (fourteen dependent loads at the head of every workgroup of a
         // 10 000-file job): the stream of every 16th frame of the launch; a workgroup walks on from there (a step or two)
         j->hca_enc_hint_off.push_back((uint32_t)enc_hint.size());

@@ -380,16 +380,20 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                 if (lane < 24) {
                     const uint32_t sfl = lane & 7, kind = lane >> 3;
                     const float* l = lsp + sfl * ENC_SP_ROW; const float* r = rsp + sfl * ENC_SP_ROW;
+                    // |l|, |r| or |l + r| as |l * ml + r * mr| with factors 1 / 0: the products are exact and x + 0 is x, so the three kinds
+                    // are one instruction sequence (written with selects, the compiler made a branch and a wait per band and kind out of it:
+                    // this phase took a third of a Low-quality frame's time)
+                    const float ml = kind == 1 ? 0.0f : 1.0f, mr = kind == 0 ? 0.0f : 1.0f;
                     float acc = 0;
                     uint32_t b = F.base;
                     for (; b + 8 <= F.total; b += 8) {
                         float t[8];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) { const float lv = l[b + k], rv = r[b + k]; t[k] = fabsf(kind == 0 ? lv : (kind == 1 ? rv : lv + rv)); }
+                        for (int k = 0; k < 8; k++) t[k] = fabsf(l[b + k] * ml + r[b + k] * mr);
 #pragma unroll
                         for (int k = 0; k < 8; k++) acc += t[k];
                     }
-                    for (; b < F.total; b++) { const float lv = l[b], rv = r[b]; acc += fabsf(kind == 0 ? lv : (kind == 1 ? rv : lv + rv)); }
+                    for (; b < F.total; b++) acc += fabsf(l[b] * ml + r[b] * mr);
                     sums[lane] = acc;
                 }
                 wave_lds_sync();
@@ -838,10 +842,10 @@ size_t hca_encode_lds_per_frame(uint32_t C, uint32_t frame_size) {
     return ENC_X_BYTES(C) + ((nwords * 4 + 15) & ~(size_t)15) + (size_t)C * ENC_CH_BYTES;
 }
 // frames per workgroup
-uint32_t hca_encode_frames_per_group(uint32_t C, uint32_t frame_size, bool joint = false) {
-    // (formats with intensity stereo: the pair's secondary waits at two barriers while the primary sums -- with a second frame in the
-    //  workgroup four waves wait for the slowest of four; one frame per workgroup measured +4 % there, -3 % on plain formats)
-    uint32_t fpg = (C >= ENC_MAX_WAVES || (joint && C > 1)) ? 1 : ENC_MAX_WAVES / C;
+uint32_t hca_encode_frames_per_group(uint32_t C, uint32_t frame_size) {
+    // (formats with intensity stereo ran one frame per workgroup while the tables were copied per workgroup and five waves shared a SIMD; with
+    //  persistent workgroups at six waves per SIMD two frames per workgroup are what the LDS lets in: Middle 135 -> 151, Low 122 -> 133 M frames/s)
+    uint32_t fpg = C >= ENC_MAX_WAVES ? 1 : ENC_MAX_WAVES / C;
     while (fpg > 1 && HCA_ET_LDS_BYTES + 16 + fpg * hca_encode_lds_per_frame(C, frame_size) > 160 * 1024) fpg--;
     return fpg;
 }
@@ -853,7 +857,7 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
     if (!a.frames || a.channels < 1 || a.channels > 8) return;
     HcaEncArgs b = a;
     b.lds_per_frame = (uint32_t)hca_encode_lds_per_frame(a.channels, a.frame_size);
-    b.frames_per_group = hca_encode_frames_per_group(a.channels, a.frame_size, a.joint != 0);
+    b.frames_per_group = hca_encode_frames_per_group(a.channels, a.frame_size);
     const size_t lds = HCA_ET_LDS_BYTES + 16 + b.frames_per_group * hca_encode_lds_per_frame(a.channels, a.frame_size);
     if (lds > 160 * 1024) return;
     b.groups = (a.frames + b.frames_per_group - 1) / b.frames_per_group;

@@ -60,7 +60,6 @@ struct HcaEncArgs {
     uint32_t lds_per_frame;        // LDS bytes of one frame's working set (set by launch_hca_encode)
     uint32_t frames_per_group;     // frames per workgroup (set by launch_hca_encode)
     uint32_t groups;               // frame groups of the launch: the (persistent) workgroups walk them (set by launch_hca_encode)
-    uint32_t joint;                // 1: the format has intensity-stereo bands (a pair's waves wait for each other there: one frame per workgroup)
 };
 size_t hca_encode_lds_bytes(uint32_t channels, uint32_t frame_size);
 void launch_hca_encode(const HcaEncArgs& a, hipStream_t s);
