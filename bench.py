@@ -322,7 +322,7 @@ def verify_items(d_out, offsets, which, refs, what):
     first batch of mismatches."""
     import torch
     dev = d_out.device
-    d_refs = [torch.frombuffer(bytearray(r), dtype=torch.uint8).to(dev) for r in refs]
+    d_refs = [None if r is None else torch.frombuffer(bytearray(r), dtype=torch.uint8).to(dev) for r in refs]      # (None: a unique input no item is a copy of)
     bad = torch.zeros((), dtype=torch.int64, device=dev)
     total = 0
     for i, u in enumerate(which):
@@ -362,7 +362,7 @@ def roofline_of(alg_bytes, alg_bytes_path, kernel_ms, dt, traffic=None, extra=No
     achieved = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
     e2e = alg_bytes_path / dt / 1e9
     r = {"bound": "valu" if extra and "valu" in extra else "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+         "frac": round(achieved / HBM_PEAK_GBPS, 5), "frac_end_to_end": round(e2e / HBM_PEAK_GBPS, 5), "traffic": None,
          "end_to_end": {"achieved": round(e2e, 2), "frac": round(e2e / HBM_PEAK_GBPS, 5),
                         "what": "algorithmic bytes of the whole path / wall time of a step (all kernels of the path, launch gaps included)"},
          "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -448,6 +448,48 @@ def make_hca_streams(unique, seconds, rank, quality, family):
     return [O.hca_crypt(O.hca_encode(family_wav(1000 * rank + u, seconds, family), quality), 1, 56, KEY) for u in range(unique)]
 
 
+def make_hca_streams_many(D, unique, seconds, quality, family, check=64):
+    """`unique` DISTINCT encrypted streams for the headline at its written size ("10 000 synthetic encrypted stereo streams") without
+    10 000 runs of the signal generator and of the CPU encoder: 64 base signals of the family; stream u is base u % 64 rotated by
+    997 * (u // 64) samples at gain 1 - (u // 64) / 500 -- distinct PCM, the family's spectrum -- and the WAVs are encoded and enciphered
+    ON THE DEVICE, a thousand at a time, by the library's own encoder, whose bytes are held to the oracle here on `check` of them spread
+    over the batch (and on every item of every encode test and bench line)."""
+    import numpy as np
+    import torch
+    import oracle_lib as O
+    from pycricodecs_amd import synth
+    from pycricodecs_amd.batch import Job
+    n = int(48000 * seconds) // 32 * 32
+    bases = [family_pcm(1000 * D.rank + b, n, 2, 48000, family).astype(np.int32) for b in range(min(64, unique))]
+
+    def wav_of(u):
+        k = u // len(bases)
+        x = np.roll(bases[u % len(bases)], 997 * k, axis=0)
+        return synth.wav_bytes((x * (500 - k % 400) // 500).astype(np.int16), 48000)
+    out = []
+    picks = set(range(0, unique, max(1, unique // check)))
+    for lo in range(0, unique, 1000):
+        wavs = oracle_many(wav_of, range(lo, min(unique, lo + 1000)), 32)
+        ej = Job.hca_encode(wavs, quality=quality)
+        eb = ej.alloc(D.dev)
+        ej.run(*eb)
+        torch.cuda.synchronize()
+        assert int((eb[3] != 0).sum().item()) == 0
+        plain = ej.split(bytes(eb[1].cpu().numpy()))
+        for u in range(lo, lo + len(wavs)):
+            if u in picks:
+                assert bytes(plain[u - lo]) == O.hca_encode(wavs[u - lo], quality), "device encode of stream %d differs from the oracle's" % u
+        cj = Job.hca_crypt([bytes(p) for p in plain], True, 56, keys=[KEY] * len(plain))
+        cb = cj.alloc(D.dev)
+        cj.run(*cb)
+        torch.cuda.synchronize()
+        out += [bytes(x) for x in cj.split(bytes(cb[1].cpu().numpy()))]
+        del eb, cb, ej, cj
+        torch.cuda.empty_cache()
+    assert len(set(hash(x) for x in out)) == unique
+    return out
+
+
 def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True, uniq=None):
     """Decode of `streams` copies of `unique` streams (or of the prepared encrypted streams `uniq`).  Returns a result dict
     (rank-local verification, rank-reduced timing)."""
@@ -455,7 +497,7 @@ def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, 
     import oracle_lib as O
     from pycricodecs_amd.batch import Job
     if uniq is None:
-        uniq = make_hca_streams(unique, seconds, D.rank, quality, family)
+        uniq = make_hca_streams(unique, seconds, D.rank, quality, family) if unique <= 256 else make_hca_streams_many(D, unique, seconds, quality, family)
     items = tile(uniq, streams)
     job = Job.hca_decode(items, keys=[KEY] * len(items))
     assert not job.host_status.any(), "synthetic inputs rejected at the header stage"
@@ -468,8 +510,9 @@ def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, 
            "census": job.record_census(bufs[2]), "sample": uniq[0],
            "bytes": {"in": job.input_bytes, "out": job.output_bytes, "scratch": job.scratch_bytes}}
     if verify:
-        refs = [O.hca_decode(h, KEY) for h in uniq]
+        refs = oracle_many(lambda h: O.hca_decode(h, KEY), uniq)
         res["verified"] = verify_items(bufs[1], job.output_offsets, [i % len(uniq) for i in range(streams)], refs, "HCA decode")
+        del refs
     del bufs
     torch.cuda.empty_cache()
     return res
@@ -539,33 +582,87 @@ def adx_roundtrip_run(D, streams, unique, seconds, family, steps, warmup, verify
     return res
 
 
-def awb_clip_plan(n_total, rank, world, seed=77, family="tonal"):
-    """The mixed bank's clips and who decodes which: 48 unique clips (24 log-uniform durations 0.05-2 s x {HCA High encrypted with the
-    bank's subkey, ADX bs18/bd4}), the global list of n_total draws from them (the same on every rank), and this rank's share of that
-    list -- longest-processing-time balanced by frame count (pycricodecs_amd.shard).  Returns (uniq, order_all, mine, subkey)."""
+def hca_clip(h, nsamples):
+    """An HCA file cut to its first `nsamples` samples as an encoder would have written the shorter clip: the frames that cover them
+    (frames are independent: the frame bytes are the long file's, cipher included), the `fmt` chunk's frame count and appended-sample
+    count rewritten (hca.cpp:693-707: samples = frames * 1024 - inserted - appended), the header checksum renewed."""
+    import oracle_lib as O
+    hs, fs = int.from_bytes(h[6:8], "big"), int.from_bytes(h[0x1C:0x1E], "big")
+    delay = int.from_bytes(h[20:22], "big")
+    nf = min(int.from_bytes(h[16:20], "big"), -(-(nsamples + delay) // 1024))
+    nsamples = min(nsamples, nf * 1024 - delay)
+    head = bytearray(h[:hs])
+    head[16:20] = nf.to_bytes(4, "big")
+    head[22:24] = (nf * 1024 - delay - nsamples).to_bytes(2, "big")
+    head[hs - 2:hs] = O.crc16(bytes(head[:hs - 2])).to_bytes(2, "big")
+    return bytes(head) + h[hs:hs + nf * fs]
+
+
+def adx_clip(a, nsamples):
+    """An ADX file cut to its first `nsamples` samples: the block rows that cover them (the encoder's state runs forward only, so the
+    shorter clip's blocks are the long file's), the header's sample count rewritten (adx.cpp:300-340), the end-of-stream footer kept."""
+    off, bs, ch = int.from_bytes(a[2:4], "big") + 4, a[5], a[7]
+    spb = (bs - 2) * 8 // a[6]
+    total = int.from_bytes(a[12:16], "big")
+    rows_total = -(-total // spb)
+    nsamples = min(nsamples, total)
+    rows = -(-nsamples // spb)
+    head = bytearray(a[:off])
+    head[12:16] = nsamples.to_bytes(4, "big")
+    return bytes(head) + a[off:off + rows * bs * ch] + a[off + rows_total * bs * ch:]
+
+
+AWB_BASES = 24
+
+
+def awb_clip_plan(n_total, rank, world, seed=77, family="tonal", n_durations=4096):
+    """The mixed bank's clips and who decodes which (BASELINE configs[4]: "duration log-uniform ... per clip").  `n_durations` distinct
+    clip lengths, log-uniform in 0.05-2 s and distinct to the sample (at most n_total), each as an HCA clip (High, encrypted with the
+    bank's subkey) and as an ADX clip (bs18/bd4; its length rounded up to whole blocks of 32 samples): 2 x n_durations unique clips.  A clip is the head of one of 24 base signals of 2.1 s --
+    the oracle encodes the 24 once per codec, hca_clip / adx_clip cut them to length the way an encoder would have written the shorter
+    file (frame / block counts and sample counts in the headers, the HCA header checksum).  The global list is n_total draws from the
+    unique clips (the same on every rank); this rank's share of it is longest-processing-time balanced by frame count
+    (pycricodecs_amd.shard).  Returns (uniq, order_all, mine, subkey)."""
     import numpy as np
     import oracle_lib as O
     from pycricodecs_amd import shard, synth
     subkey = 0x2468
     rng = np.random.default_rng(seed)
-    durs = np.exp(rng.uniform(np.log(0.05), np.log(2.0), 24))
+    n_durations = max(1, min(n_durations, n_total))
+    lens = set()
+    while len(lens) < n_durations:                             # distinct sample counts
+        lens.update(int(x) for x in np.exp(rng.uniform(np.log(0.05), np.log(2.0), n_durations - len(lens))) * 48000)
+    lens = sorted(lens)
+    rng.shuffle(lens)
+    base_n = int(48000 * 2.1) // 32 * 32
+    bases = []
+    for u in range(AWB_BASES):
+        w = synth.wav_bytes(family_pcm(7000 + u, base_n, 2, 48000, family), 48000)
+        bases.append((O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, subkey), O.adx_encode(w)))
     uniq = []
-    for u, d in enumerate(durs):
-        w = synth.wav_bytes(family_pcm(7000 + u, max(32, int(48000 * d) // 32 * 32), 2, 48000, family), 48000)
-        uniq.append(("hca", O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, subkey)))
-        uniq.append(("adx", O.adx_encode(w)))
+    for u, n in enumerate(lens):
+        h, a = bases[u % AWB_BASES]
+        uniq.append(("hca", hca_clip(h, n)))
+        uniq.append(("adx", adx_clip(a, -(-n // 32) * 32)))      # whole blocks: the reference's own ADX decoder writes past its buffer for any other count (adx.cpp:392-415)
     order_all = rng.integers(0, len(uniq), n_total)
     wts = [shard.hca_weight(u[1]) if u[0] == "hca" else shard.adx_weight(u[1]) // 2 for u in uniq]
     mine = shard.my_items([wts[i] for i in order_all], rank, world) if world > 1 else list(range(n_total))
     return uniq, order_all, mine, subkey
 
 
-def build_awb_bank(n_total, rank, world, seed=77, family="tonal"):
+def oracle_many(fn, items, threads=None):
+    """fn over items on the host's cores (the oracle is a C library: its calls release the interpreter lock)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(threads or min(64, os.cpu_count() or 8)) as ex:
+        return list(ex.map(fn, items))
+
+
+def build_awb_bank(n_total, rank, world, seed=77, family="tonal", n_durations=4096):
     """AFS2 bank of this rank's share of `n_total` short clips (BASELINE configs[4] shape, awb_clip_plan).  Returns (bank, uniq, order,
     subkey): order[i] = the unique clip behind the bank's item i."""
     import struct
     import numpy as np
-    uniq, order_all, mine, subkey = awb_clip_plan(n_total, rank, world, seed, family)
+    uniq, order_all, mine, subkey = awb_clip_plan(n_total, rank, world, seed, family, n_durations)
     align = 0x20
     order = [int(order_all[i]) for i in mine]
     n = len(order)
@@ -580,7 +677,7 @@ def build_awb_bank(n_total, rank, world, seed=77, family="tonal"):
     return head.ljust(hs, b"\0") + b"".join(parts), uniq, order, subkey
 
 
-def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=False, family="tonal"):
+def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=False, family="tonal", n_durations=4096):
     """Decode of a mixed AFS2 bank through the AWB front door: one HCA job + one ADX job over the bank as it sits in HBM.
     With world > 1 every rank decodes its LPT share of clips x world clips and (gather=True) the decoded PCM of all
     ranks is collected on rank 0 inside the timed region -- the only collective-like step of the whole path."""
@@ -589,7 +686,7 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     from pycricodecs_amd import shard
     from pycricodecs_amd.batch import Job
     world = D.world
-    bank, uniq, order, subkey = build_awb_bank(clips if strong else clips * world, D.rank, world, family=family)      # strong: `clips` is the whole job
+    bank, uniq, order, subkey = build_awb_bank(clips if strong else clips * world, D.rank, world, family=family, n_durations=n_durations)      # strong: `clips` is the whole job
     n = len(order)
     hj, aj = Job.awb_decode(bank, KEY)
     d_in, ho, hscr, hst = hj.alloc(D.dev)
@@ -612,8 +709,9 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     dt, kms = run_timed(D, step, max(steps, 1), max(warmup, 1), [hj, aj])
     hca_units, adx_units, n_all = D.reduce([float(hj.units), float(aj.units), float(n)], "sum")
     assert int((hst < 0).sum().item()) == 0 and int((ast < 0).sum().item()) == 0
-    res = {"workload": "AFS2 bank(s) of %d clips%s (0.05-2 s log-uniform, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV%s"
-                       % (int(n_all), " over %d GPUs, LPT-sharded" % world if world > 1 else "", ", PCM gathered on rank 0 (RCCL send/recv)" if gather and world > 1 else ""),
+    res = {"workload": "AFS2 bank(s) of %d clips%s (0.05-2 s log-uniform, %d distinct lengths, 48 kHz stereo, 50 %% ADX bs18/bd4 + 50 %% HCA High encrypted with subkey), decode to WAV%s"
+                       % (int(n_all), " over %d GPUs, LPT-sharded" % world if world > 1 else "", len(uniq) // 2, ", PCM gathered on rank 0 (RCCL send/recv)" if gather and world > 1 else ""),
+           "distinct_clips": len(set(order)), "distinct_lengths": len(uniq) // 2,
            "bank_bytes_rank0": len(bank), "pcm_bytes_rank0": int(hj.output_bytes + aj.output_bytes), "ms_per_step": round(dt * 1e3, 3),
            "hca_frames": int(hca_units), "adx_frames": int(adx_units), "frames_per_s": round((hca_units + adx_units) / dt, 1),
            "clips_per_s": round(n_all / dt, 1), "unit": "frames/s (HCA frames + ADX block rows)", "material": family}
@@ -625,7 +723,8 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     first_of = lambda kind: next((uniq[i][1] for i in order if uniq[i][0] == kind), None)
     res["_cpu_parts"] = {"hca": first_of("hca"), "adx": first_of("adx"), "hca_frames": int(hj.units), "adx_rows": int(aj.units), "subkey": subkey}
     if verify:
-        refs = [O.hca_decode(b, KEY, subkey) if k == "hca" else O.adx_decode(b) for k, b in uniq]
+        used = set(order)
+        refs = oracle_many(lambda t: None if t[0] not in used else (O.hca_decode(t[1][1], KEY, subkey) if t[1][0] == "hca" else O.adx_decode(t[1][1])), list(enumerate(uniq)))
         hi = [i for i in range(n) if uniq[order[i]][0] == "hca"]
         ai = [i for i in range(n) if uniq[order[i]][0] == "adx"]
         v1 = verify_items(ho, [hj.output_offsets[i] for i in hi], [order[i] for i in hi], refs, "AWB HCA items")
@@ -720,11 +819,15 @@ def secondary_measurements(args, D):
                         "chunks_per_s": round(job.units / dt, 1), "ms_per_step": round(dt * 1e3, 3), "verified_items": v["items"]}
     del bufs
     torch.cuda.empty_cache()
-    r = awb_mixed_run(D, args.awb_clips, 3, 1)
+    r = awb_mixed_run(D, args.awb_clips, 3, 1, n_durations=args.awb_durations)
     r.pop("_roofline_parts"); r.pop("_cpu_parts")
     out["awb_mixed_decode"] = r
     out["single_call_ms"] = single_call_latency(args.seconds)
-    out["baseline_configs"] = baseline_config_lines(args, D)
+    lines = baseline_config_lines(args, D)
+    # one compact object of everything above, next to the BASELINE configurations at the END of the line (the driver keeps the tail of stdout)
+    out["summary_M_per_s"] = {k: round((v.get("frames_per_s") or v.get("chunks_per_s") or 0) / 1e6, 2) for k, v in out.items() if isinstance(v, dict) and ("frames_per_s" in v or "chunks_per_s" in v)}
+    out["summary_M_per_s"]["single_call_ms [ours, reference]"] = out["single_call_ms"]
+    out["baseline_configs"] = lines
     return out
 
 
@@ -746,12 +849,22 @@ def baseline_config_lines(args, D):
         alg_dom = r.get("alg_bytes_by_kernel", {}).get(dom, r["alg_bytes"])
         traffic = committed_traffic(int(r["units"]) // (2 if traffic_key.startswith("adx") else 1), dom, traffic_key) if traffic_key else None
         extra = {"bytes_per_unit": unit_bytes}
-        if traffic_key == "hca_encode":
-            extra.update(committed_valu(int(r["units"]), kms, "hca_encode") or {})
+        if traffic_key in ("hca_encode", "hca_decode"):
+            extra.update(committed_valu(int(r["units"]), kms, traffic_key) or {})
         out = {"workload": workload, "value": round(r["units"] / r["dt"], 1), "unit": "frames/s", "ms_per_step": round(r["dt"] * 1e3, 3), "dtype": dtype,
                "frames_per_step": int(r["units"]), "roofline": roofline_of(alg_dom, r["alg_bytes"], kms, r["dt"], traffic, extra),
                "verified": r.get("verified"), "cpu_baseline": cpu}
         return out
+    # configs[2] again, as written: 10 000 DISTINCT streams (the headline tiles 64; make_hca_streams_many says how these are made)
+    if args.streams >= 10000 and not args.no_distinct:
+        r = hca_decode_run(D, args.streams, args.streams, args.seconds, 1, "tonal", 3, 1)
+        lines["configs[2] hca_decode, %d distinct streams" % args.streams] = line(
+            r, "BASELINE configs[2] with every stream distinct: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s, no two alike (64 base signals, each rotated and scaled per stream, encoded and enciphered on the device)" % (args.streams, args.seconds),
+            "f32", "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"], None, "hca_decode")
+        lines["configs[2] hca_decode, %d distinct streams" % args.streams]["record_forms"] = census_text(r["census"])
+        r.pop("job", None)
+        del r
+        torch.cuda.empty_cache()
     # configs[1]
     r = adx_roundtrip_run(D, 1000, 16, 10.0, "tonal", 3, 1)
     lines["configs[1] adx_roundtrip"] = line(r, "BASELINE configs[1]: ADX encode + decode round trip (bs18/bd4/mode3/v4), 1000 48 kHz stereo WAVs x 10 s; a frame = one block row, counted for the encode and for the decode",
@@ -766,7 +879,7 @@ def baseline_config_lines(args, D):
     torch.cuda.empty_cache()
     # configs[4]
     for fam in ("tonal", "sfx"):
-        r = awb_mixed_run(D, args.config_awb_clips, 3, 1, family=fam)
+        r = awb_mixed_run(D, args.config_awb_clips, 3, 1, family=fam, n_durations=args.awb_durations)
         rp, cp = r.pop("_roofline_parts"), r.pop("_cpu_parts")
         kms = rp["kernel_ms"]
         dom = max(kms, key=kms.get)
@@ -895,10 +1008,12 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-distinct", action="store_true", help="skip the all-streams-distinct form of the headline inside the default run")
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
     ap.add_argument("--host-streams", type=int, default=10000, help="streams of the host-memory secondary (host output buffers: 1.92 MB each)")
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
+    ap.add_argument("--awb-durations", type=int, default=4096, help="distinct clip lengths of the mixed AWB bank (log-uniform 0.05-2 s; each as an HCA and as an ADX clip)")
     ap.add_argument("--config-awb-clips", type=int, default=100000, help="clips of the configs[4] line inside the default run (one GPU)")
     ap.add_argument("--config-cpu-seconds", type=float, default=4.0, help="seconds of reference CPU work per baseline of the configs lines (single thread; again on all cores)")
     args = ap.parse_args()
@@ -922,7 +1037,7 @@ def main():
     t_setup = time.time()
 
     if wl == "awb_mixed":                                      # BASELINE configs[4]; its own metric line
-        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify, strong=strong, family=args.data if args.data in ("tonal", "sfx") else "tonal")
+        r = awb_mixed_run(D, args.awb_clips, args.steps, args.warmup, gather=not args.no_gather, verify=verify, strong=strong, family=args.data if args.data in ("tonal", "sfx") else "tonal", n_durations=args.awb_durations)
         rp, cp = r.pop("_roofline_parts"), r.pop("_cpu_parts")
         if D.rank == 0:
             kms = rp["kernel_ms"]
@@ -932,7 +1047,7 @@ def main():
             if not args.no_cpu:
                 common["cpu_baseline"] = cpu_baseline_awb(cp)
             print(json.dumps(dict(common, metric="audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", value=r["frames_per_s"], unit="frames/s",
-                                  ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (24 unique durations x 2 codecs, tiled; tonal family)",
+                                  ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (%d distinct clip lengths x 2 codecs, heads of 24 base signals; %s family)" % (r["distinct_lengths"], r["material"]),
                                   config=r)), flush=True)
         D.close()
         return

@@ -333,3 +333,19 @@ def test_hca_delay_and_padding_trims(ch):
     for k, (n, delay, pad) in enumerate([(9000, 128, 0), (9000, 1, 0), (12000, 127, 77), (2048 * 5, 1029, 1500), (700, 0, 3), (1024 * 9, 2, 1)]):
         h = hca_forge.forge_trim(O.hca_encode(synth.wav(2100 + 10 * ch + k, n, ch, 48000), 1), delay, pad)
         both(lambda: O.hca_decode(h), lambda: R.hca_decode(h))
+
+
+def test_clipped_bank_items_decode_alike():
+    """bench.py's ragged AWB bank (BASELINE configs[4]) holds heads of long files cut to length by rewriting the headers (bench.hca_clip /
+    adx_clip: frame / block and sample counts, the HCA header checksum).  The real reference takes every such clip and decodes it to the
+    bytes the oracle does -- lengths inside a frame / a block, one-frame clips, the full length."""
+    import bench as B
+    w = synth.wav(31, 48000 * 2, 2, 48000)
+    h, a = O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, 0x2468), O.adx_encode(w)
+    for n in (2400, 2401, 5000, 1024 * 7 - 128, 1024 * 7 - 127, 33, 48000, 95999, 96000):
+        na = -(-n // 32) * 32                                 # (ADX clips are whole blocks: the reference's decoder writes past its buffer otherwise, adx.cpp:392-415)
+        hc, ac = B.hca_clip(h, n), B.adx_clip(a, na)
+        pcm = both(lambda: O.hca_decode(hc, KEY, 0x2468), lambda: R.hca_decode(hc, KEY, 0x2468))
+        assert pcm is not None and (len(pcm) - 44) // 4 == n
+        pcm = both(lambda: O.adx_decode(ac), lambda: R.adx_decode(ac))
+        assert pcm is not None and (len(pcm) - 44) // 4 == na
