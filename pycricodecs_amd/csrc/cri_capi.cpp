@@ -1306,31 +1306,28 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
         // what counts -- a warm-up of 640 rows (the merge time) before segments of 320 gives three times the lanes, each with 960 rows
         // instead of 1024 + up to 600 of repair, at 2.4 times the instructions (4.45 -> 3.4 ms; 4000 files of 10 s would go 8.7 -> 9.2).
         bool short_segments = true;
-        {
-            uint64_t lanes_long = 0;
-            for (const AdxStream& S : streams) {
-                const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
-                if (g <= 0 || !S.frames) { lanes_long += S.channels; continue; }
-                const uint64_t rows = std::max<uint64_t>((S.frames + p_target - 1) / p_target, std::max<uint64_t>(4, 1024ull * 39 * pct / 100 / (uint64_t)g));
-                lanes_long += (uint64_t)S.channels * ((S.frames + rows - 1) / rows);
-            }
-            if (lanes_long >= 98304) short_segments = false;
+        uint64_t lanes_long = 0, rows_long = 0;
+        for (const AdxStream& S : streams) {
+            const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
+            if (g <= 0 || !S.frames) { lanes_long += S.channels; rows_long = std::max<uint64_t>(rows_long, S.frames); continue; }
+            const uint64_t rows = std::min<uint64_t>(S.frames, std::max<uint64_t>((S.frames + p_target - 1) / p_target, std::max<uint64_t>(4, 1024ull * 39 * pct / 100 / (uint64_t)g)));
+            lanes_long += (uint64_t)S.channels * ((S.frames + rows - 1) / rows);
+            rows_long = std::max<uint64_t>(rows_long, rows + (rows < S.frames ? 600 : 0));      // (a cut file without warm-up: the repair rounds re-encode up to the merge time)
         }
-        auto lane_warm = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (640ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4) : (uint64_t)0; };
+        auto warm_short = [&](int64_t g) { return std::max<uint64_t>(4, (640ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4); };
         // The least segment length.  With a warm-up the kernel's time is (waves per SIMD, rounded up) x (warm-up + segment): the planner
         // tries segment lengths from half a warm-up to the whole file and keeps the cheapest -- 1000 files of 10 s: 480 rows (1000 waves on
         // 1024 SIMDs, 2.2 ms) instead of 320 (1469 waves: every SIMD with two of them sets the pace, 3.4 ms); 12 500 files of 1 s: no cut at
         // all (391 waves of 1500 rows, 2.8 ms against 4.4).  (adx_seglen, tests only, fixes it instead.)
-        uint64_t best_pct = seg_pct;
-        if (short_segments && !knobs().adx_seglen) {
-            const uint32_t nsimd = device_simds();
-            uint64_t best_cost = ~0ull;
+        uint64_t best_pct = seg_pct, best_cost = ~0ull;
+        const uint32_t nsimd = device_simds();
+        if (!knobs().adx_seglen) {
             for (uint64_t cand = 50; cand <= 6400; cand = cand * 9 / 8 + 1) {
                 uint64_t lanes_c = 0, longest = 0;
                 for (const AdxStream& S : streams) {
                     const int64_t g = S.mode == 2 ? 64 : 4096 - (int64_t)S.coef0 - (int64_t)S.coef1;
                     if (g <= 0 || !S.frames) { lanes_c += S.channels; longest = std::max<uint64_t>(longest, S.frames); continue; }
-                    const uint64_t warm = lane_warm(g), lmin = std::max<uint64_t>(4, (warm * cand / 100 + 3) / 4 * 4);
+                    const uint64_t warm = warm_short(g), lmin = std::max<uint64_t>(4, (warm * cand / 100 + 3) / 4 * 4);
                     uint64_t rows = (std::max<uint64_t>((S.frames + p_target - 1) / p_target, lmin) + 3) / 4 * 4;
                     if (rows > S.frames) rows = S.frames;
                     lanes_c += (uint64_t)S.channels * ((S.frames + rows - 1) / rows);
@@ -1342,6 +1339,15 @@ static int create_adx_encode(const ItemSrc& it, const cri_adx_encode_params* p, 
                 if (cost < best_cost) { best_cost = cost; best_pct = cand; }
             }
         }
+        // The long-segment regime is taken when the job has lanes enough for it AND the same cost model does not price the best short plan
+        // (often: no cut at all) below it.  Round 4 switched on the lane count alone, and 25 000-32 000 files of 1 s -- two waves per SIMD
+        // of 1024-row segments plus repairs, where 782-1000 uncut waves of 1500 rows fit one to a SIMD -- took 4.8-5.0 ms instead of 2.9
+        // (the "cliff" between 24 000 and 26 000 files that DESIGN r4 put down to the memory system: it was this threshold).
+        if (lanes_long >= 98304) {
+            const uint64_t waves_long = (lanes_long + 63) / 64, cost_long = ((waves_long + nsimd - 1) / nsimd) * rows_long;
+            short_segments = !knobs().adx_seglen && best_cost <= cost_long;
+        }
+        auto lane_warm = [&](int64_t g) { return short_segments ? warm_short(g) : (uint64_t)0; };
         auto lane_lmin = [&](int64_t g) { return short_segments ? std::max<uint64_t>(4, (lane_warm(g) * best_pct / 100 + 3) / 4 * 4)
                                                                  : std::max<uint64_t>(4, (1024ull * 39 * pct / 100 / (uint64_t)g + 3) / 4 * 4); };
         uint32_t lanes = 0, chains = 0; uint64_t rounds = 0;
