@@ -7,13 +7,16 @@ import ctypes as C
 import os
 
 try:  # load torch's bundled HIP runtime first so both sides share one libamdhip64 (same soname)
+    if os.environ.get("CRICODECS_NO_TORCH") == "1":      # (the AddressSanitizer run: its allocator hooks need the system's HIP runtime)
+        raise ImportError
     import torch  # noqa: F401
 except Exception:  # pragma: no cover
     torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libcricodecs_hip.so")
-TESTING_LIB_PATH = os.path.join(HERE, "lib", "libcricodecs_hip_testing.so")   # the same sources + the parity tests' knobs (cri_test_set); never shipped
+LIB_DIR = os.environ.get("CRICODECS_LIB_DIR") or os.path.join(HERE, "lib")      # (the AddressSanitizer build lives in a directory of its own: tools/asan_gpu.sh)
+LIB_PATH = os.path.join(LIB_DIR, "libcricodecs_hip.so")
+TESTING_LIB_PATH = os.path.join(LIB_DIR, "libcricodecs_hip_testing.so")   # the same sources + the parity tests' knobs (cri_test_set); never shipped
 
 SYMBOLS = [
     "cri_adx_decode", "cri_adx_encode", "cri_hca_decode", "cri_hca_encode", "cri_hca_crypt", "cri_free", "cri_strerror",

@@ -18,13 +18,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("CRICODECS_LIB_DIR") or os.path.join(HERE, "lib")      # (another directory for a build of another kind: tools/asan_gpu.sh)
 LIB = os.path.join(LIBDIR, "libcricodecs_hip.so")
 TESTING_LIB = os.path.join(LIBDIR, "libcricodecs_hip_testing.so")   # parity-test build: the same objects, cri_capi.cpp and the test kernels with -DCRI_TESTING
 TESTING_SOURCES = ["cri_capi.cpp", "cri_testing.hip"]
 SOURCES = ["cri_host.cpp", "cri_hca_dec.hip", "cri_hca_enc.hip", "cri_adx.hip", "cri_misc.hip", "cri_capi.cpp"]
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "cricodecs_hip.h")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+ARCH = os.environ.get("CRI_OFFLOAD_ARCH", "gfx950")          # (gfx950:xnack+ for the AddressSanitizer build, tools/asan_gpu.sh)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 ID_MARK = b"CRI_BUILD_ID="
 
@@ -35,6 +36,15 @@ def _hipcc():
 
 def _extra():
     return os.environ.get("CRI_HIPCC_EXTRA", "").split()
+
+
+def _link_extra():
+    """Sanitizer flags of CRI_HIPCC_EXTRA go to the link as well (the device runtime of AddressSanitizer is linked there)."""
+    return [f for f in _extra() if f.startswith("-fsanitize") or f == "-shared-libsan"]
+
+
+def _no_undefined():
+    return [] if _link_extra() else ["-Wl,--no-undefined"]           # (a sanitized library resolves its runtime at load time)
 
 
 def _headers():
@@ -115,7 +125,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
         objs.append(_compile(src, obj, iddef if src == "cri_capi.cpp" else [], verbose))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + _link_extra() + objs + ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib"] + _no_undefined()
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -124,7 +134,7 @@ def build(force=False, verbose=True):
     for src in TESTING_SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + "_testing.o")
         tobjs.append(_compile(src, obj, ["-DCRI_TESTING"] + (iddef if src == "cri_capi.cpp" else []), verbose))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + tobjs + ["-o", TESTING_LIB, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + _link_extra() + tobjs + ["-o", TESTING_LIB, "-Wl,-rpath,/opt/rocm/lib"] + _no_undefined()
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

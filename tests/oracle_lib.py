@@ -10,9 +10,10 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        san = os.environ.get("CRI_TEST_SANITIZED") == "1"       # tests/test_sanitizers.py: the same restatement under ASan + UBSan
+        path = os.path.join(ROOT, "oracle", "liboracle_san.so" if san else "liboracle.so")
         if not os.path.exists(path):
-            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True)
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), os.path.basename(path)], check=True)
         L = C.CDLL(path)
         u8p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)
         L.ora_adx_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(u8p), szp]

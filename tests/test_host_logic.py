@@ -21,10 +21,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def shim():
     src = os.path.join(ROOT, "tests", "shim", "host_shim.cpp")
     host = os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_host.cpp")
-    out = os.path.join(ROOT, "tests", "shim", "libhost_shim.so")
-    deps = [src, host, os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_host.h")]
+    san = os.environ.get("CRI_TEST_SANITIZED") == "1"           # tests/test_sanitizers.py: the product's host logic under ASan + UBSan
+    out = os.path.join(ROOT, "tests", "shim", "libhost_shim_san.so" if san else "libhost_shim.so")
+    deps = [src, host, os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_host.h"), os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_types.h"), os.path.join(ROOT, "pycricodecs_amd", "csrc", "cri_tables.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", src, host, "-o", out], check=True)
+        flags = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if san else []
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall"] + flags + [src, host, "-o", out], check=True)
     L = C.CDLL(out)
     L.shim_wav_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
     L.shim_hca_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
