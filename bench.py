@@ -392,8 +392,8 @@ def committed_traffic(units, dom, workload="hca_decode"):
         return None
     ks, total = wl["kernels"], wl["total_hbm_bytes_per_unit"]
     out = {"traffic": int(round(total * units)),
-           "traffic_source": "profiles/%s, %s: %.1f B per %s over the path's kernels (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, calibrated per access width, dispatches summed per step; 1000-item batch) x %d units; algorithmic %s B"
-                             % (os.path.basename(tfiles[-1]), workload, total, wl.get("unit", "unit"), units, wl.get("algorithmic_bytes_per_unit", "?"))}
+           "traffic_source": "profiles/%s, %s: %.1f B per %s over the path's kernels (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, calibrated per access width, dispatches summed per step; counter passes over %s units per step) x %d units; algorithmic %s B"
+                             % (os.path.basename(tfiles[-1]), workload, total, wl.get("unit", "unit"), wl.get("units_per_step", "1000-item batches:"), units, wl.get("algorithmic_bytes_per_unit", "?"))}
     key = dom if dom in ks else next((k for k in ks if k.startswith(dom) or dom.startswith(k)), None)
     if key and ks[key].get("hbm_bytes_per_unit"):
         out["traffic_dominant_kernel"] = int(round(ks[key]["hbm_bytes_per_unit"] * units))
@@ -419,27 +419,28 @@ def committed_traffic_awb(hca_frames, adx_rows):
 
 def committed_valu(units, kernel_ms, workload="hca_decode"):
     """What bounds the HCA kernels is VALU issue, not HBM: from the committed SQ counter passes of this path
-    (profiles/r*_pmc_1000streams.json) the wave64 VALU instructions per frame and `busy` = the share of a kernel's cycles its SIMDs
+    (profiles/r*_pmc.json: full-size batches from round 5 on) the wave64 VALU instructions per frame and `busy` = the share of a kernel's cycles its SIMDs
     spend issuing them (4 cycles each on one of 1024 SIMDs, against GRBM_GUI_ACTIVE: clock-independent).  floor_ms = the time this
     run's kernels would take if VALU issue were all they did (busy x measured time)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1000streams.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_1000streams.json")))
     if not files:
         return None
     with open(files[-1]) as fh:
         pj = json.load(fh)
-    per, busy, floor = {}, {}, 0.0
+    per, busy, floor, batch = {}, {}, 0.0, None
     for name, k in (pj.get("workloads", {}).get(workload) or (pj.get("kernels", {}) if workload == "hca_decode" else {})).items():
         cls = "k_hca_parse" if "parse" in name else ("k_hca_transform" if "transform" in name else ("k_hca_encode" if "k_hca_encode" in name else None))
         if not cls or "VALU_per_frame" not in k:
             continue
         per[cls] = k["VALU_per_frame"]
+        batch = k.get("frames_per_step", batch)
         if "valu_busy" in k:
             busy[cls] = k["valu_busy"]
             floor += k["valu_busy"] * kernel_ms.get(cls, 0.0)
     if not per:
         return None
     return {"valu": {"insts_per_frame": per, "busy": busy, "floor_ms": round(floor, 3) if busy else None,
-                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE, counters-only passes, 1000-stream batch)" % os.path.basename(files[-1])}}
+                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE, counters-only passes, %s)" % (os.path.basename(files[-1]), "%d frames per step" % batch if batch else "1000-stream batch")}}
 
 
 # ------------------------------------------------------------------------------------------------ workloads

@@ -603,7 +603,11 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     //      operation a block waits for (feed_land) is then a whole block old.
     //      Formats the in-lane transform handles (a.narrow) store the lines as int8 -- half the record bytes, and this kernel is
     //      partly bound by the CU's store path -- when no band of the tile's 64 frames can exceed 8 bits (the usual case by far).
+#ifdef EXP_FORCE_NARROW                                    // (timing experiment only -- wrong samples: what a record form with int8 lines for EVERY tile could gain at most)
+    const bool narrow = a.narrow != 0;
+#else
     const bool narrow = a.narrow != 0 && !__any(wide_bits != 0);
+#endif
     //      (channels without coded bands -- a secondary channel of a format with base_band_count 0 -- have no blocks)
     uint32_t first_c = 0;
     while (first_c + 1 < C && F.coded(first_c) == 0) first_c++;
