@@ -76,7 +76,7 @@ def main(tag):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name.replace("bench.json", "bench_default.json"))))
-    for name in ("hca_encode_phases.txt", "hca_encode_phases_8ch.txt", "commit.txt"):
+    for name in ("hca_encode_phases.txt", "hca_encode_phases_low.txt", "hca_encode_phases_8ch.txt", "commit.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))

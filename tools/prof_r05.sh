@@ -24,6 +24,7 @@ timeout 900 python bench.py --workload hca_encode --steps 3 --warmup 1 > $OUT/be
 timeout 600 python bench.py --workload adx_roundtrip > $OUT/bench_adx_roundtrip.json 2> $OUT/bench_adx_roundtrip.err
 timeout 600 python bench.py --workload awb_mixed > $OUT/bench_awb_mixed.json 2> $OUT/bench_awb_mixed.err
 fi
+if [ -z "$SKIP_PROFILES" ]; then
 declare -A CMDS
 CMDS[hca_decode]="python bench.py --no-cpu --no-secondary --no-verify --steps 5 --warmup 2"
 CMDS[hca_encode]="python bench.py --workload hca_encode --no-cpu --no-verify --steps 3 --warmup 1"
@@ -79,12 +80,16 @@ json.dump(res,open(out+'/counters_raw.json','w'),indent=1,sort_keys=True)
 print(json.dumps({w:{k:v.get('dispatches') for k,v in ks.items()} for w,ks in res.items()},indent=1)[:3000])
 PY
 rm -rf $RAW
+fi   # SKIP_PROFILES
 # the encoder's phase split
 if [ -z "$SKIP_PHASES" ]; then
-CRI_HIPCC_EXTRA=-DCRI_ENC_PROFILE python -m pycricodecs_amd.build --force > /dev/null 2>&1
+export CRI_HIPCC_EXTRA=-DCRI_ENC_PROFILE            # (for the runs too: the binding only loads a library built with the flags it is told)
+python -m pycricodecs_amd.build > /dev/null 2>&1
 python tools/debug/enc_phases.py 2 > $OUT/hca_encode_phases.txt 2>&1
+python tools/debug/enc_phases.py 2 3 > $OUT/hca_encode_phases_low.txt 2>&1
 python tools/debug/enc_phases.py 8 > $OUT/hca_encode_phases_8ch.txt 2>&1
-python -m pycricodecs_amd.build --force > /dev/null 2>&1
+unset CRI_HIPCC_EXTRA
+python -m pycricodecs_amd.build > /dev/null 2>&1
 tail -15 $OUT/hca_encode_phases.txt
 fi
 for w in hca_decode hca_encode adx_roundtrip awb_mixed; do echo "== $w"; head -8 $OUT/${w}_kernel_stats.csv; done
