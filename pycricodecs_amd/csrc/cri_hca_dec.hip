@@ -1555,7 +1555,11 @@ constexpr LcgPow make_lcg_pow() {
     return t;
 }
 __device__ const LcgPow HCA_LCG_POW = make_lcg_pow();
+#ifdef EXP_DCT_T
+#define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048 + 2304)
+#else
 #define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
+#endif
 #define HCA_PLAIN_JOINT_LDS_BYTES (HCA_PLAIN_LDS_BYTES + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
 struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
@@ -2007,6 +2011,10 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
                 if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
             }
             __builtin_amdgcn_sched_barrier(0);             // (keep the load here: the compiler would sink it behind most of the DCT)
+#ifdef EXP_DCT_T
+            if (!JOINT && !WIDE) dct4_inplace_T(x, L, (float*)(smem + 2048 + 1024 + 256 + 64 + 80 + 2048 + 2048), lane);
+            else
+#endif
             dct4_inplace(x, L);
             if (WIDE) __syncthreads();                     // (every wave has taken the previous pass's PCM out of the shared piece)
             if (s < 0) {
