@@ -3,6 +3,8 @@
 # every global / LDS access of the kernels is checked against the shadow of the allocations, hipMalloc'ed buffers get red zones).
 #   The build (8 minutes of hipcc) is made in the build container and travels with the tree:
 #     CRICODECS_LIB_DIR=$PWD/pycricodecs_amd/lib_asan CRI_OFFLOAD_ARCH=gfx950:xnack+ CRI_HIPCC_EXTRA="-fsanitize=address -shared-libsan -g" python -m pycricodecs_amd.build
+#     hipcc -fsanitize=address -shared-libsan -g -O1 -x c++ tools/asan_fuzz.cpp -o pycricodecs_amd/lib_asan/asan_fuzz \
+#           -Lpycricodecs_amd/lib_asan -lcricodecs_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 #   This ROCm has no sanitizer build of the HIP runtime (/opt/rocm/lib/asan): a device-side report reaches the host as hostcall service
 #   4, for which the plain runtime has no handler -- the process dies with "Hostcall: no handler found for service ID 4".  That IS the
 #   detection (the positive control below shows it for a 12-byte over-read and over-write of a hipMalloc'ed buffer); a clean run is a run
