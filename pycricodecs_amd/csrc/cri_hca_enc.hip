@@ -823,7 +823,16 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
                     acc ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x143, 0xC, 0xF, false);
                     crc = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63);
                 }
-                if (lane == 0) put_bits(words, (F.frame_size - 2) * 8, crc & 0xFFFF, 16);
+                // The checksum REPLACES the frame's last two bytes (hca.cpp:2961-2962).  They are not always zero here: the bit writer's buffer
+                // reaches to the frame's last byte (hca.cpp:2941) and the rate loop's count can come out short of what the pack writes
+                // (hca.cpp:2771-2786 against 2920-2938), so a full frame's last code may end inside them -- cleared, then or-ed.
+                if (lane == 0) {
+                    const uint32_t p = (F.frame_size - 2) * 8;
+                    const uint64_t m = (uint64_t)0xFFFFu << ((64u - (p & 31) - 16u) & 63);
+                    words[p >> 5] &= ~(uint32_t)(m >> 32);
+                    words[(p >> 5) + 1] &= ~(uint32_t)m;
+                    put_bits(words, p, crc & 0xFFFF, 16);
+                }
             }
             wave_lds_sync();
             // the frame image is big-endian words; whole dwords go out byte-swapped (unaligned dword stores), then the last bytes

@@ -120,3 +120,19 @@ def test_job_run_on_several_streams_then_destroyed(cc):
     assert not st2.any()
     for k, o in enumerate(outs2):
         assert bytes(o) == O.adx_encode(synth.wav(5300 + k, 32 * 500, 2, 48000))
+
+
+# ------------------------------------------------------------------------------------------------ a35: a payload that runs into the checksum field
+def test_hca_encode_when_the_payload_runs_into_the_checksum_field(cc):
+    """The rate loop's bit count can come out a bit short of what the pack writes (hca.cpp:2771-2786 against 2920-2938), and the bit writer's
+    buffer reaches to the frame's last byte (hca.cpp:2941): a full frame's last code then ends inside the two checksum bytes, which the
+    reference OVERWRITES with the checksum (hca.cpp:2961-2962).  The library or-ed its checksum onto the stray bit (found by
+    tools/parity_soak.py, one frame in 200 000 files: eight channels, 8 kHz, lowest quality; the fixture is four frames cut out around it).
+    Bytes = oracle, through the single-file call and the batch job."""
+    from pycricodecs_amd.batch import Job
+    w = G.load("enc_payload_reaches_checksum_8ch_q4.wav")
+    ref = O.hca_encode(w, 4)
+    assert bytes(cc.HcaEncode(w, False, 4)) == ref
+    outs, st = run_job(Job.hca_encode([w, w, synth.wav(1, 5000, 8, 8000), w], quality=4))
+    assert not st.any()
+    assert [bytes(o) for o in outs] == [ref, ref, O.hca_encode(synth.wav(1, 5000, 8, 8000), 4), ref]

@@ -12,7 +12,7 @@ points, seven signal kinds incl. full-scale noise, digital silence and values on
 
 and a few of the items through the five drop-in single-file calls as well.  The oracle's side runs on the box's host cores (threads).
 Prints one line per round and a summary; exit code 1 on any mismatch.
-    python tools/parity_soak.py [seconds [seed]]"""
+    python tools/parity_soak.py [seconds [seed [a bank of 1000-4000 items every n-th round (default 10, 0 = never)]]]"""
 import sys, time
 from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -23,6 +23,7 @@ from pycricodecs_amd.batch import Job
 
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+BIG_EVERY = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 rng = np.random.default_rng(SEED)
 pool = ThreadPoolExecutor(32)
 RATES = [8000, 11025, 22050, 32000, 44100, 48000]
@@ -63,10 +64,13 @@ def rand_pcm(n, ch):
     return np.clip(np.rint(x), -32768, 32767).astype("<i2"), kind
 
 
-def rand_wav(max_ch, whole_blocks=0.0):
+def rand_wav(max_ch, whole_blocks=0.0, big=False):
     ch = int(rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 7, 8])) if max_ch > 2 else int(rng.integers(1, max_ch + 1))
     r = rng.random()
-    n = int(rng.integers(1, 2100)) if r < 0.25 else (int(rng.integers(2100, 60000)) if r < 0.85 else int(rng.integers(60000, 8 * 48000 // max(1, ch // 2))))
+    if big:          # a bank of thousands: mostly short clips, a few long files (segmented chains, long transform runs)
+        n = int(rng.integers(1, 4000)) if r < 0.7 else (int(rng.integers(4000, 48000)) if r < 0.97 else int(rng.integers(48000, 30 * 48000 // max(1, ch // 2))))
+    else:
+        n = int(rng.integers(1, 2100)) if r < 0.25 else (int(rng.integers(2100, 60000)) if r < 0.85 else int(rng.integers(60000, 8 * 48000 // max(1, ch // 2))))
     if rng.random() < whole_blocks:
         n = (n + 31) // 32 * 32
     sr = int(rng.choice(RATES))
@@ -108,10 +112,15 @@ def corrupt_hca(h):
     return bytes(a)
 
 
-def same_or_both_refuse(kind, outs, st, refs, info):
+def same_or_both_refuse(kind, outs, st, refs, info, inputs=None):
     for i, (o, s, r) in enumerate(zip(outs, st, refs)):
         ok = (s != 0) if r is None else (s == 0 and o == r)
         note(kind, ok, (info[i], "status %d" % s, None if r is None else len(r), len(o)), r is None)
+        if not ok and inputs is not None:                            # keep the case: input, what the library made, what the oracle made
+            import os
+            os.makedirs("gpurun_out/soak", exist_ok=True)
+            stem = "gpurun_out/soak/mismatch_%d_%s" % (len(bad), kind.replace(" ", "_"))
+            open(stem + ".in", "wb").write(inputs[i]); open(stem + ".got", "wb").write(o); open(stem + ".ref", "wb").write(r or b"")
 
 
 t0 = time.time(); rounds = 0
@@ -119,21 +128,23 @@ assert _capi.lib().cri_device_available() == 1, "no HIP device"
 print("build %s, seed %d, %.0f s" % (_capi.build_id(), SEED, BUDGET), flush=True)
 while time.time() - t0 < BUDGET:
     rounds += 1
-    n_items = int(rng.integers(8, 49))
+    jk = ["-", "-", "-"]
+    big = BIG_EVERY > 0 and rounds % BIG_EVERY == 0             # every so often a bank of thousands (the planner's other regimes)
+    n_items = int(rng.integers(1000, 4001)) if big else int(rng.integers(8, 49))
     # ---- HCA: encode -> crypt -> decode
-    bank = [rand_wav(8) for _ in range(n_items)]
+    bank = [rand_wav(8, 0.0, big) for _ in range(n_items)]
     wavs = [w for w, _ in bank]; info = [m for _, m in bank]
     q = int(rng.integers(0, 5))
     refs = list(pool.map(lambda w: oracle(O.hca_encode, w, q), wavs))
     outs, st = run_job(Job.hca_encode(wavs, quality=q))
-    same_or_both_refuse("hca_encode q%d" % q, outs, st, refs, info)
+    same_or_both_refuse("hca_encode q%d" % q, outs, st, refs, info, wavs)
     good = [(r, m) for r, m in zip(refs, info) if r is not None]
     if good:
         files = [r for r, _ in good]; finfo = [m for _, m in good]
         keys = [int(rng.integers(1, 1 << 62)) for _ in files]
         erefs = list(pool.map(lambda fk: oracle(O.hca_crypt, fk[0], 1, 56, fk[1]), zip(files, keys)))
         eouts, est = run_job(Job.hca_crypt(files, 1, 56, keys=keys))
-        same_or_both_refuse("hca_crypt", eouts, est, erefs, finfo)
+        same_or_both_refuse("hca_crypt", eouts, est, erefs, finfo, files)
         enc = [e if e is not None else f for e, f in zip(erefs, files)]
         dkeys = [k if e is not None else 0 for e, k in zip(erefs, keys)]
         for i in range(len(enc)):
@@ -143,10 +154,11 @@ while time.time() - t0 < BUDGET:
                 if e is not None:
                     enc[i] = e; dkeys[i] = keys[i]; finfo[i] = finfo[i] + ("corrupted",)
         drefs = list(pool.map(lambda fk: oracle(O.hca_decode, fk[0], fk[1]), zip(enc, dkeys)))
-        douts, dst = run_job(Job.hca_decode(enc, keys=dkeys))
-        same_or_both_refuse("hca_decode", douts, dst, drefs, finfo)
+        jd = Job.hca_decode(enc, keys=dkeys); jk[0] = jd.dominant_kernel
+        douts, dst = run_job(jd)
+        same_or_both_refuse("hca_decode", douts, dst, drefs, finfo, enc)
     # ---- ADX: encode -> decode
-    abank = [rand_wav(2, 0.6) for _ in range(n_items)]
+    abank = [rand_wav(2, 0.6, big) for _ in range(n_items)]
     # (whole blocks only where the reference's decoder is to be run: it writes past its buffer otherwise, adx.cpp:392-415)
     awavs = [w for w, _ in abank]; ainfo = [m for _, m in abank]
     bd, bs = [(4, 18), (4, 18), (4, 18), (8, 34), (2, 10), (6, 26), (12, 20), (15, 32)][int(rng.integers(0, 8))]
@@ -155,8 +167,9 @@ while time.time() - t0 < BUDGET:
     hp = int(rng.choice([0, 500, 2000]))
     arefs = list(pool.map(lambda w: oracle(O.adx_encode, w, bd, bs, mode, hp, filt, ver), awavs))
     try:
-        aouts, ast = run_job(Job.adx_encode(awavs, bd, bs, mode, hp, filt, ver))
-        same_or_both_refuse("adx_encode", aouts, ast, arefs, [m + (bd, bs, mode, ver, filt, hp) for m in ainfo])
+        ja = Job.adx_encode(awavs, bd, bs, mode, hp, filt, ver); jk[1] = ja.dominant_kernel
+        aouts, ast = run_job(ja)
+        same_or_both_refuse("adx_encode", aouts, ast, arefs, [m + (bd, bs, mode, ver, filt, hp) for m in ainfo], awavs)
     except (ValueError, _capi.CriCodecsError) as e:                # parameters the library refuses for the whole job: the oracle must refuse them too
         note("adx_encode params refused", all(r is None for r in arefs), ((bd, bs, mode, ver, filt, hp), str(e)))
         arefs = []
@@ -173,8 +186,9 @@ while time.time() - t0 < BUDGET:
                         a[int(i)] = int(rng.integers(0, 256))
             afiles.append(bytes(a))
         adrefs = list(pool.map(lambda f: oracle(O.adx_decode, f), afiles))
-        adouts, adst = run_job(Job.adx_decode(afiles))
-        same_or_both_refuse("adx_decode", adouts, adst, adrefs, [m + (bd, bs, mode, ver) for _, m in keep])
+        jad = Job.adx_decode(afiles); jk[2] = jad.dominant_kernel
+        adouts, adst = run_job(jad)
+        same_or_both_refuse("adx_decode", adouts, adst, adrefs, [m + (bd, bs, mode, ver) for _, m in keep], afiles)
     # ---- the drop-in single-file calls on a few of the round's items
     for i in rng.integers(0, n_items, 3):
         i = int(i)
@@ -190,8 +204,8 @@ while time.time() - t0 < BUDGET:
             note("AdxEncode (single)", single(cc.AdxEncode, awavs[i], bd, bs, mode, hp, filt, ver, False) == arefs[i], (ainfo[i], bd, bs, mode, ver))
             if arefs[i] is not None and ainfo[i][1] % 32 == 0:
                 note("AdxDecode (single)", single(cc.AdxDecode, arefs[i]) == oracle(O.adx_decode, arefs[i]), (ainfo[i], bd, bs, mode, ver))
-    print("round %d (%.0f s): %d items, quality %d, adx %d/%d mode %d v%d; comparisons so far %d, mismatches %d" %
-          (rounds, time.time() - t0, n_items, q, bd, bs, mode, ver, sum(c[0] for c in counts.values()), len(bad)), flush=True)
+    print("round %d (%.0f s): %d items%s, quality %d, adx %d/%d mode %d v%d; comparisons so far %d, mismatches %d" %
+          (rounds, time.time() - t0, n_items, " (%s / %s / %s)" % (jk[0], jk[1], jk[2]) if big else "", q, bd, bs, mode, ver, sum(c[0] for c in counts.values()), len(bad)), flush=True)
 
 print("---- %d rounds in %.0f s" % (rounds, time.time() - t0))
 for k in sorted(counts):
