@@ -182,7 +182,7 @@ while time.time() - t0 < BUDGET:
             if rng.random() < 0.33:
                 hs = int.from_bytes(a[2:4], "big") + 4
                 if len(a) > hs:
-                    for i in rng.integers(hs, len(a), max(1, (len(a) - hs) // 3)):
+                    for i in rng.integers(hs, len(a), max(1, (len(a) - hs) // 3) if rng.random() < 0.5 else int(rng.integers(1, 4))):      # (dense, or a byte or three)
                         a[int(i)] = int(rng.integers(0, 256))
             afiles.append(bytes(a))
         adrefs = list(pool.map(lambda f: oracle(O.adx_decode, f), afiles))
