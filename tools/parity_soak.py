@@ -1,10 +1,11 @@
 """GPU box: a time-bounded randomised parity soak of the whole path against the pinned oracle (the CPU restatement of adx.cpp / hca.cpp,
 oracle/), through the batch jobs of the C ABI -- the kernels the bench measures, with the mixes of formats, lengths and signals that the
 fixed parity tests only sample.  Every round draws a bank of WAVs (1-8 channels, six sample rates, lengths from one sample to 8 s, loop
-points, seven signal kinds incl. full-scale noise, digital silence and values on the quantisers' clamps) and takes it through
+points, seven signal kinds incl. full-scale noise, digital silence and values on the quantisers' clamps; one in twelve as u8 / s24 / s32 /
+f32 / f64 samples) and takes it through
 
     HCA encode (one random quality per round)      -> bytes == oracle's encoder, file by file
-    HCA crypt of those files (random keys, type 56) -> bytes == oracle
+    HCA crypt of those files (random keys / subkeys, type 56 or 1), and back -> bytes == oracle
     HCA decode of the enciphered files (with keys)  -> bytes == oracle's decoder; a tenth of the files with frames overwritten by random
                                                       bytes (half of those with the frame checksum renewed): same bytes or both refuse
     ADX encode (random bit depth / block size / mode / high-pass / version) -> bytes == oracle
@@ -74,6 +75,9 @@ def rand_wav(max_ch, whole_blocks=0.0, big=False):
     if rng.random() < whole_blocks:
         n = (n + 31) // 32 * 32
     sr = int(rng.choice(RATES))
+    if rng.random() < 0.08:                                      # other sample formats (the converters): the bench's signal as u8 / s24 / s32 / f32 / f64
+        t = str(rng.choice(["u8", "s24", "s32", "f32", "f64"]))
+        return synth.wav_typed(int(rng.integers(0, 1 << 30)), n, ch, sr, t), (ch, n, sr, t, None)
     pcm, kind = rand_pcm(n, ch)
     loop = None
     if rng.random() < 0.15 and n > 64:
@@ -141,20 +145,27 @@ while time.time() - t0 < BUDGET:
     good = [(r, m) for r, m in zip(refs, info) if r is not None]
     if good:
         files = [r for r, _ in good]; finfo = [m for _, m in good]
+        ctype = int(rng.choice([56, 56, 56, 1]))
         keys = [int(rng.integers(1, 1 << 62)) for _ in files]
-        erefs = list(pool.map(lambda fk: oracle(O.hca_crypt, fk[0], 1, 56, fk[1]), zip(files, keys)))
-        eouts, est = run_job(Job.hca_crypt(files, 1, 56, keys=keys))
-        same_or_both_refuse("hca_crypt", eouts, est, erefs, finfo, files)
+        subs = [int(rng.integers(0, 1 << 16)) if rng.random() < 0.3 else 0 for _ in files]
+        erefs = list(pool.map(lambda t: oracle(O.hca_crypt, t[0], 1, ctype, t[1], t[2]), zip(files, keys, subs)))
+        eouts, est = run_job(Job.hca_crypt(files, 1, ctype, keys=keys, subkeys=subs))
+        same_or_both_refuse("hca_crypt (encipher, type %d)" % ctype, eouts, est, erefs, finfo, files)
         enc = [e if e is not None else f for e, f in zip(erefs, files)]
         dkeys = [k if e is not None else 0 for e, k in zip(erefs, keys)]
+        dsubs = [k if e is not None else 0 for e, k in zip(erefs, subs)]
+        # and back (HcaCrypt's other direction)
+        prefs = list(pool.map(lambda t: oracle(O.hca_crypt, t[0], 0, ctype, t[1], t[2]), zip(enc, dkeys, dsubs)))
+        pouts, pst = run_job(Job.hca_crypt(enc, 0, ctype, keys=dkeys, subkeys=dsubs))
+        same_or_both_refuse("hca_crypt (decipher, type %d)" % ctype, pouts, pst, prefs, finfo, enc)
         for i in range(len(enc)):
             if rng.random() < 0.1:
                 plain = corrupt_hca(files[i])                     # corrupt the plain file, then encipher it with the oracle (so the checksums hold or not as drawn)
-                e = oracle(O.hca_crypt, plain, 1, 56, keys[i])
+                e = oracle(O.hca_crypt, plain, 1, ctype, keys[i], subs[i])
                 if e is not None:
-                    enc[i] = e; dkeys[i] = keys[i]; finfo[i] = finfo[i] + ("corrupted",)
-        drefs = list(pool.map(lambda fk: oracle(O.hca_decode, fk[0], fk[1]), zip(enc, dkeys)))
-        jd = Job.hca_decode(enc, keys=dkeys); jk[0] = jd.dominant_kernel
+                    enc[i] = e; dkeys[i] = keys[i]; dsubs[i] = subs[i]; finfo[i] = finfo[i] + ("corrupted",)
+        drefs = list(pool.map(lambda t: oracle(O.hca_decode, t[0], t[1], t[2]), zip(enc, dkeys, dsubs)))
+        jd = Job.hca_decode(enc, keys=dkeys, subkeys=dsubs); jk[0] = jd.dominant_kernel
         douts, dst = run_job(jd)
         same_or_both_refuse("hca_decode", douts, dst, drefs, finfo, enc)
     # ---- ADX: encode -> decode
