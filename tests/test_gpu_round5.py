@@ -136,3 +136,15 @@ def test_hca_encode_when_the_payload_runs_into_the_checksum_field(cc):
     outs, st = run_job(Job.hca_encode([w, w, synth.wav(1, 5000, 8, 8000), w], quality=4))
     assert not st.any()
     assert [bytes(o) for o in outs] == [ref, ref, O.hca_encode(synth.wav(1, 5000, 8, 8000), 4), ref]
+
+
+# ------------------------------------------------------------------------------------------------ c: the randomised soak, briefly
+def test_randomised_parity_soak_for_a_few_seconds(cc):
+    """tools/parity_soak.py (random banks through every batch job and single-file call, each output against the oracle; the long runs are
+    under profiles/) for ten seconds with a seed of its own, one bank of 1000-4000 items among the rounds: no mismatch."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "parity_soak.py"), "10", "20260929", "3"], cwd=root, capture_output=True, text=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-20:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    assert "TOTAL" in tail and " 0 mismatches" in tail.splitlines()[-1], tail
