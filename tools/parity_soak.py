@@ -11,6 +11,8 @@ f32 / f64 samples) and takes it through
     ADX encode (random bit depth / block size / mode / high-pass / version) -> bytes == oracle
     ADX decode of those files, a third with random block bytes -> bytes == oracle
 
+every third round the plain HCA files again, half of them re-headed as v3.0 (noise fill) or v1.x, some with random frame payloads: the
+decoder's floats before the clamp bit for bit, and the PCM of the same run;
 and a few of the items through the five drop-in single-file calls as well.  The oracle's side runs on the box's host cores (threads).
 Prints one line per round and a summary; exit code 1 on any mismatch.
     python tools/parity_soak.py [seconds [seed [a bank of 1000-4000 items every n-th round (default 10, 0 = never)]]]"""
@@ -168,6 +170,37 @@ while time.time() - t0 < BUDGET:
         jd = Job.hca_decode(enc, keys=dkeys, subkeys=dsubs); jk[0] = jd.dominant_kernel
         douts, dst = run_job(jd)
         same_or_both_refuse("hca_decode", douts, dst, drefs, finfo, enc)
+    # ---- every third round: the plain files again, half of them re-headed (v3.0 with min_resolution 0: noise fill; v1.x: the other ATH default), a
+    # few with every frame's payload random: the decoder's floats before the clamp, bit for bit, and the PCM of the same run
+    if good and rounds % 3 == 0:
+        import torch, hca_forge
+        fitems = []
+        for i, f in enumerate(files):
+            r = rng.random()
+            try:
+                g = hca_forge.forge_v3(f, 0) if r < 0.35 else (hca_forge.forge_v1(f) if r < 0.5 else (hca_forge.random_frames(f, int(rng.integers(0, 1 << 30)), float(rng.choice([1.0, 0.3, 0.05]))) if r < 0.6 and len(f) < 200000 else f))
+            except AssertionError:
+                g = f
+            fitems.append(g)
+        frefs = list(pool.map(lambda h: oracle(O.hca_decode_float, h), fitems))
+        wrefs = list(pool.map(lambda h: oracle(O.hca_decode, h, 0), fitems))
+        jf = Job.hca_decode(fitems)
+        bufs = jf.alloc("cuda:0")
+        d_f, offs = jf.run_floats(*bufs)
+        torch.cuda.synchronize()
+        fl = d_f.cpu().numpy(); fouts = jf.split(bytes(bufs[1].cpu().numpy()))
+        fst = bufs[3].cpu().numpy()[:jf.n]; fhs = np.asarray(jf.host_status[:jf.n]); fst = np.where(fhs != 0, fhs, fst)
+        for i in range(len(fitems)):
+            if frefs[i] is None or wrefs[i] is None:
+                ok = fst[i] != 0
+            else:
+                mine = fl[int(offs[i]):int(offs[i + 1])]
+                ok = fst[i] == 0 and mine.size == frefs[i].size and np.array_equal(mine.view(np.uint32), frefs[i].view(np.uint32)) and bytes(fouts[i]) == wrefs[i]
+            note("hca_decode floats + PCM (v2.0 / forged v3.0, v1.x, random frames)", ok, (finfo[i], "status %d" % fst[i]), frefs[i] is None)
+            if not ok:
+                import os
+                os.makedirs("gpurun_out/soak", exist_ok=True)
+                open("gpurun_out/soak/mismatch_%d_floats.in" % len(bad), "wb").write(fitems[i])
     # ---- ADX: encode -> decode
     abank = [rand_wav(2, 0.6, big) for _ in range(n_items)]
     # (whole blocks only where the reference's decoder is to be run: it writes past its buffer otherwise, adx.cpp:392-415)
@@ -220,6 +253,6 @@ while time.time() - t0 < BUDGET:
 
 print("---- %d rounds in %.0f s" % (rounds, time.time() - t0))
 for k in sorted(counts):
-    print("%-28s %7d comparisons (%d of them: both sides refuse the input), %d mismatches" % (k, counts[k][0], counts[k][2], counts[k][1]))
+    print("%-72s %7d comparisons (%d of them: both sides refuse the input), %d mismatches" % (k, counts[k][0], counts[k][2], counts[k][1]))
 print("TOTAL %d comparisons, %d mismatches" % (sum(c[0] for c in counts.values()), len(bad)))
 sys.exit(1 if bad else 0)
