@@ -356,6 +356,37 @@ def run_timed(D, step, steps, warmup, jobs):
     return dt, {k: v / steps for k, v in kms.items()}
 
 
+def sustained_run(job, bufs, seconds):
+    """The same job in a loop for `seconds` (after the timed steps): what the clocks settle at under this kernel family.  The shader
+    clock and the socket power are sampled once, halfway, from rocm-smi (None when it is not there).  The default steps of the bench
+    are a burst of ~0.15 s; a power-capped part runs its long jobs at the rate reported here."""
+    import subprocess
+    import torch
+    import re
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); n = 0; smi = None
+    while True:
+        for _ in range(8):
+            job.run(*bufs)
+        torch.cuda.synchronize(); n += 8
+        el = time.perf_counter() - t0
+        if smi is None and el > seconds / 2:
+            for _ in range(8):
+                job.run(*bufs)                                 # (sampled while the queue is full)
+            n += 8
+            try:
+                txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+                m, w = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt), re.search(r"Power \(W\): ([0-9.]+)", txt)
+                smi = {"sclk_mhz": int(m.group(1)) if m else None, "socket_power_w": float(w.group(1)) if w else None}
+            except Exception:
+                smi = {}
+            torch.cuda.synchronize()
+        if el >= seconds:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return dict({"seconds": round(time.perf_counter() - t0, 1), "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(job.units / dt, 1)}, **(smi or {}))
+
+
 def roofline_of(alg_bytes, alg_bytes_path, kernel_ms, dt, traffic=None, extra=None):
     """alg_bytes: algorithmic bytes the dominant kernel's launches cover; alg_bytes_path: of the whole step."""
     dom = max(kernel_ms, key=kernel_ms.get)
@@ -491,7 +522,7 @@ def make_hca_streams_many(D, unique, seconds, quality, family, check=64):
     return out
 
 
-def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True, uniq=None):
+def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True, uniq=None, sustain=0.0):
     """Decode of `streams` copies of `unique` streams (or of the prepared encrypted streams `uniq`).  Returns a result dict
     (rank-local verification, rank-reduced timing)."""
     import torch
@@ -510,6 +541,8 @@ def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, 
            "frame_size": int.from_bytes(uniq[0][0x1C:0x1E], "big"), "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
            "census": job.record_census(bufs[2]), "sample": uniq[0],
            "bytes": {"in": job.input_bytes, "out": job.output_bytes, "scratch": job.scratch_bytes}}
+    if sustain > 0:
+        res["sustained"] = sustained_run(job, bufs, sustain)
     if verify:
         refs = oracle_many(lambda h: O.hca_decode(h, KEY), uniq)
         res["verified"] = verify_items(bufs[1], job.output_offsets, [i % len(uniq) for i in range(streams)], refs, "HCA decode")
@@ -525,7 +558,7 @@ def census_text(c):
     return "%d of %d frames crossed scratch as int8 records, %d as int16" % (c["narrow"], c["frames"], c["frames"] - c["narrow"])
 
 
-def hca_encode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True):
+def hca_encode_run(D, streams, unique, seconds, quality, family, steps, warmup, verify=True, sustain=0.0):
     import torch
     import oracle_lib as O
     from pycricodecs_amd.batch import Job
@@ -540,6 +573,8 @@ def hca_encode_run(D, streams, unique, seconds, quality, family, steps, warmup, 
     res = {"job": job, "dt": dt, "kernel_ms": kms, "units": job.units, "alg_bytes": job.algorithmic_bytes, "sample": uniq[0],
            "frames_per_stream": int.from_bytes(head[16:20], "big"), "frame_size": int.from_bytes(head[0x1C:0x1E], "big"),
            "bytes": {"in": job.input_bytes, "out": job.output_bytes, "scratch": job.scratch_bytes}}
+    if sustain > 0:
+        res["sustained"] = sustained_run(job, bufs, sustain)
     if verify:
         refs = [O.hca_encode(w, quality) for w in uniq]
         res["verified"] = verify_items(bufs[1], job.output_offsets, [i % len(uniq) for i in range(streams)], refs, "HCA encode")
@@ -1009,6 +1044,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--sustain", type=float, default=4.0, help="seconds of the same job in a loop after the timed steps (single GPU, with the secondaries): config.sustained")
     ap.add_argument("--no-distinct", action="store_true", help="skip the all-streams-distinct form of the headline inside the default run")
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
@@ -1053,8 +1089,9 @@ def main():
         D.close()
         return
 
+    sustain = args.sustain if (D.world == 1 and not args.no_secondary) else 0.0
     if wl == "hca_decode":
-        r = hca_decode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify)
+        r = hca_decode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify, sustain=sustain)
         cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality %s, frame %d B, key 0xCF222F1FE0748978) per GPU"
                            % (streams, seconds, QNAME.get(args.quality, "?"), r["frame_size"]),
                "streams_per_gpu": streams, "frames_per_stream": r["frames_per_stream"], "unique_streams": unique, "parallelism": par,
@@ -1064,7 +1101,7 @@ def main():
         dtype, unit_bytes = "f32", "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"]
         cpu = ("hcadec", r["sample"], r["frames_per_stream"])
     elif wl == "hca_encode":
-        r = hca_encode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify)
+        r = hca_encode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify, sustain=sustain)
         cfg = {"workload": "BASELINE configs[3]: HCA encode (v2.0, quality %s), %d 48 kHz stereo WAVs x %.0f s per GPU" % (QNAME.get(args.quality, "?"), streams, seconds),
                "streams_per_gpu": streams, "frames_per_stream": r["frames_per_stream"], "unique_wavs": unique, "parallelism": par}
         if strong:
@@ -1078,6 +1115,8 @@ def main():
         dtype, unit_bytes = "int32", "blocksize + 2*samples_per_block = 18 + 64 = 82 B per block, encode and decode each"
         cpu = ("adxrt", r["sample"], 2 * r["frames_per_stream"])
     log("%s: setup + run + verify %.1fs; %s" % (wl, time.time() - t_setup, {k: "%.2f GB" % (v / 1e9) for k, v in r["bytes"].items()}))
+    if r.get("sustained"):
+        cfg["sustained"] = r["sustained"]
     if verify:
         cfg["verified"] = r["verified"]
         ok = D.reduce([float(r["verified"]["items"])], "sum")[0]
