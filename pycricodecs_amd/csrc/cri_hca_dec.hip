@@ -228,7 +228,7 @@ __device__ __forceinline__ void feed_issue_wave(BitFeed& f, uint32_t n, bool ask
 // In the spectra loop the lanes top up together every HCA_FEED_SYNC-th block (a landing step then serves most of the wave at
 // once); in between only when a lane would run dry.  A chunk asked for at the top of a block's iteration lands at its bottom.
 #ifndef HCA_FEED_SYNC
-#define HCA_FEED_SYNC 3     // (measured, parse of 4.69 M frames: 1: 9.68 ms, 2: 9.38, 3: 9.07, 4: 9.00, 5: 9.33)
+#define HCA_FEED_SYNC 4     // (measured, parse of 4.69 M frames: round 2: 1: 9.68 ms, 2: 9.38, 3: 9.07, 4: 9.00, 5: 9.33; round 5, alternating on one box: 2: 8.88, 3: 8.62, 4: 8.53, 5: 8.68; sparse material 3: 10.10, 4: 9.96)
 #endif
 __device__ __forceinline__ void feed_request(BitFeed& f, const BitBuf& b, bool eager, uint32_t thresh, uint4& c0, uint4& c1) {
     const uint32_t h = f.wr - b.rd, room = RING_WORDS - h;
