@@ -89,7 +89,10 @@ __device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; 
 // lane that burned more than 4 words in one block) and sits behind a wave-uniform branch, and so do the frame's last,
 // partial chunk and a chunk that would reach past the end of the input blob.
 #define RING_WORDS 16       // (+ 4 spare rows: the sink of a lane that lands nothing)
-size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + 256 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
+#ifndef EXP_PARSE_LDS_PAD
+#define EXP_PARSE_LDS_PAD 0    // (timing experiment: idle LDS per wave, e.g. 4096 = what a 32-word ring would take: three waves per SIMD)
+#endif
+size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)EXP_PARSE_LDS_PAD + (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + 256 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
 
 struct BitFeed {
     const uint8_t* next;     // next chunk of this lane's frame in the input blob
@@ -422,6 +425,9 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     {
         uint32_t si = a.stream_begin, f = 0;
         if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
+#ifdef EXP_FOLD_INPUT                                      // (timing / power experiment only -- wrong output: every tile reads the first stream's first 64 frames, i.e. its input out of L2)
+        if (valid) { si = a.stream_begin; f = lane; }
+#endif
         const uint64_t src_offset = a.streams[si].src_offset;
         const uint32_t cidx = a.streams[si].cipher;
         fd.next = a.in + src_offset + (uint64_t)f * F.frame_size;
