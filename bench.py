@@ -1044,7 +1044,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="awb_mixed with --gpus > 1: leave the decoded PCM on the ranks")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--sustain", type=float, default=4.0, help="seconds of the same job in a loop after the timed steps (single GPU, with the secondaries): config.sustained")
+    ap.add_argument("--sustain", type=float, default=4.0, help="seconds of the same job in a loop after the timed steps: config.sustained (single GPU; not with --no-secondary / --no-verify / --no-cpu, the profiling runs' flags)")
     ap.add_argument("--no-distinct", action="store_true", help="skip the all-streams-distinct form of the headline inside the default run")
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
@@ -1089,7 +1089,7 @@ def main():
         D.close()
         return
 
-    sustain = args.sustain if (D.world == 1 and not args.no_secondary) else 0.0
+    sustain = args.sustain if (D.world == 1 and not (args.no_secondary or args.no_verify or args.no_cpu)) else 0.0      # (profiling runs count dispatches: nothing extra in them)
     if wl == "hca_decode":
         r = hca_decode_run(D, streams, unique, seconds, args.quality, args.data, args.steps, args.warmup, verify, sustain=sustain)
         cfg = {"workload": "BASELINE configs[2]: HCA v2.0 decode, %d encrypted 48 kHz stereo streams x %.0f s (quality %s, frame %d B, key 0xCF222F1FE0748978) per GPU"
