@@ -1,3 +1,7 @@
+#!/bin/bash
+# ON THE GPU BOX: the parse's synchronised top-up interval (-DHCA_FEED_SYNC=n) A/B on one box, alternating, twice.  The variants are built
+# IN THE BUILD CONTAINER, each into a directory of its own:
+#   for n in 2 4 5; do CRICODECS_LIB_DIR=$PWD/pycricodecs_amd/lib_fs$n CRI_HIPCC_EXTRA="-DHCA_FEED_SYNC=$n" python -m pycricodecs_amd.build; done
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp CRICODECS_NO_REBUILD=1
 for rep in 1 2; do
  for n in base 2 4 5; do
