@@ -25,9 +25,13 @@ sparse (clean narrow-band material: bands of resolution 12..15, int16 records), 
 mixed (tonal and sparse alternating).  "data" in the line says which, and the record-form census of the run is in
 config.record_forms.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the launch stream inside
-the timed steps, plus the end-to-end figure (algorithmic bytes / step time); `cpu_baseline` is the real reference
-(oracle/_ref/criref, single thread) when that binary travelled with the repo, else the C restatement ("port").
+Prints ONE JSON line of at most 4 KB on stdout (rank 0; compact_line / emit): the contract's keys, `config`, `roofline`, `cpu_baseline`.
+`roofline.frac` = algorithmic bytes of the whole step / wall time of a step / HBM peak (the end-to-end figure); `dominant_kernel`
+inside it is the longest kernel with its OWN algorithmic bytes over its HIP-event time (events on the launch stream, inside the
+timed steps).  `cpu_baseline` is the real reference (oracle/_ref/criref, single thread) when that binary travelled with the repo,
+else the C restatement ("port").  Everything else of the default run -- the other BASELINE configurations at their written sizes,
+the secondaries at 1000 streams and at full size, host-memory lines, single-call latencies -- goes to bench_detail.json (repo
+root; also $BENCH_DETAIL_DIR) and to stderr.
 """
 import argparse
 import glob
@@ -388,18 +392,23 @@ def sustained_run(job, bufs, seconds):
 
 
 def roofline_of(alg_bytes, alg_bytes_path, kernel_ms, dt, traffic=None, extra=None):
-    """alg_bytes: algorithmic bytes the dominant kernel's launches cover; alg_bytes_path: of the whole step."""
+    """`achieved` / `frac`: algorithmic bytes of the WHOLE step (SURVEY 8(d)'s per-unit figure x units) / wall time of a step -- all kernels
+    of the path, launch gaps included -- against the HBM peak (round 6: until round 5 `frac` divided the whole path's bytes by ONE kernel's
+    time, which credited that kernel with bytes another one moves).  `dominant_kernel`: the longest kernel of the step with the algorithmic
+    bytes that are its OWN (alg_bytes: e.g. the HCA transform writes the PCM, 2 x 1024 x channels per frame; the parse reads the frame) over
+    its HIP-event time.  alg_bytes_path: of the whole step."""
     dom = max(kernel_ms, key=kernel_ms.get)
-    achieved = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    own = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
     e2e = alg_bytes_path / dt / 1e9
-    r = {"bound": "valu" if extra and "valu" in extra else "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-         "frac": round(achieved / HBM_PEAK_GBPS, 5), "frac_end_to_end": round(e2e / HBM_PEAK_GBPS, 5), "traffic": None,
-         "end_to_end": {"achieved": round(e2e, 2), "frac": round(e2e / HBM_PEAK_GBPS, 5),
-                        "what": "algorithmic bytes of the whole path / wall time of a step (all kernels of the path, launch gaps included)"},
-         "algorithmic_bytes_per_launch": int(alg_bytes),
-         "kernel_ms_per_step": {k: round(v, 3) for k, v in kernel_ms.items()}}
+    r = {"bound": "valu" if extra and "valu" in extra else "hbm", "kernel": dom, "achieved": round(e2e, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(e2e / HBM_PEAK_GBPS, 5), "frac_end_to_end": round(e2e / HBM_PEAK_GBPS, 5), "traffic": None,
+         "algorithmic_bytes_per_launch": int(alg_bytes_path),
+         "kernel_ms_per_step": {k: round(v, 3) for k, v in kernel_ms.items()},
+         "dominant_kernel": {"name": dom, "ms": round(kernel_ms[dom], 3), "own_algorithmic_bytes": int(alg_bytes), "achieved": round(own, 2), "frac": round(own / HBM_PEAK_GBPS, 5)}}
     if traffic:
         r.update(traffic)
+        if r.get("traffic"):
+            r["traffic_over_algorithmic"] = round(r["traffic"] / alg_bytes_path, 3)
     if extra:
         r.update(extra)
     return r
@@ -423,8 +432,8 @@ def committed_traffic(units, dom, workload="hca_decode"):
         return None
     ks, total = wl["kernels"], wl["total_hbm_bytes_per_unit"]
     out = {"traffic": int(round(total * units)),
-           "traffic_source": "profiles/%s, %s: %.1f B per %s over the path's kernels (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, calibrated per access width, dispatches summed per step; counter passes over %s units per step) x %d units; algorithmic %s B"
-                             % (os.path.basename(tfiles[-1]), workload, total, wl.get("unit", "unit"), wl.get("units_per_step", "1000-item batches:"), units, wl.get("algorithmic_bytes_per_unit", "?"))}
+           "traffic_source": "profiles/%s %s: %.1f B per %s (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, calibrated) x %d"
+                             % (os.path.basename(tfiles[-1]), workload, total, wl.get("unit", "unit"), units)}
     key = dom if dom in ks else next((k for k in ks if k.startswith(dom) or dom.startswith(k)), None)
     if key and ks[key].get("hbm_bytes_per_unit"):
         out["traffic_dominant_kernel"] = int(round(ks[key]["hbm_bytes_per_unit"] * units))
@@ -444,7 +453,7 @@ def committed_traffic_awb(hca_frames, adx_rows):
     if not h or not a:
         return None
     return {"traffic": int(round(h * hca_frames + a * adx_rows)),
-            "traffic_source": "profiles/%s: %.1f B per HCA frame (hca_decode pass) x %d + %.1f B per ADX block row (decode kernels of the adx_roundtrip pass) x %d"
+            "traffic_source": "profiles/%s: %.1f B per HCA frame x %d + %.1f B per ADX block row x %d"
                               % (os.path.basename(tfiles[-1]), h, hca_frames, a, adx_rows)}
 
 
@@ -471,7 +480,7 @@ def committed_valu(units, kernel_ms, workload="hca_decode"):
     if not per:
         return None
     return {"valu": {"insts_per_frame": per, "busy": busy, "floor_ms": round(floor, 3) if busy else None,
-                     "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE, counters-only passes, %s)" % (os.path.basename(files[-1]), "%d frames per step" % batch if batch else "1000-stream batch")}}
+                     "source": "profiles/%s (SQ_INSTS_VALU / GRBM_GUI_ACTIVE, %s)" % (os.path.basename(files[-1]), "%d frames per step" % batch if batch else "1000-stream batch")}}
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -537,8 +546,11 @@ def hca_decode_run(D, streams, unique, seconds, quality, family, steps, warmup, 
     job.enable_events(True)
     dt, kms = run_timed(D, lambda: job.run(*bufs), steps, warmup, [job])
     assert not verify or int((bufs[3] != 0).sum().item()) == 0, "items failed on the device"
+    fsz = int.from_bytes(uniq[0][0x1C:0x1E], "big")
     res = {"job": job, "dt": dt, "kernel_ms": kms, "units": job.units, "alg_bytes": job.algorithmic_bytes,
-           "frame_size": int.from_bytes(uniq[0][0x1C:0x1E], "big"), "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"),
+           # what each kernel of the path owns of a frame's algorithmic bytes: the parse reads the frame, the transform writes the PCM
+           "alg_bytes_by_kernel": {"k_hca_parse": fsz * job.units, "k_hca_transform": job.algorithmic_bytes - fsz * job.units},
+           "frame_size": fsz, "frames_per_stream": int.from_bytes(uniq[0][16:20], "big"), "channels": uniq[0][12],
            "census": job.record_census(bufs[2]), "sample": uniq[0],
            "bytes": {"in": job.input_bytes, "out": job.output_bytes, "scratch": job.scratch_bytes}}
     if sustain > 0:
@@ -728,6 +740,7 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     d_in, ho, hscr, hst = hj.alloc(D.dev)
     _, ao, ascr, ast = aj.alloc(D.dev, upload=False)
     gathered = {}
+    aj_out = lambda t: t[:aj.output_bytes]
 
     # the two jobs are independent: the ADX one (one wave per file, as long as its longest clip) runs on a stream of its own and the
     # HCA kernels fill the rest of the chip meanwhile; both are inside the timed region (the main stream waits for the side one)
@@ -741,7 +754,9 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
         hj.run(d_in, ho, hscr, hst)
         main.wait_stream(side)
         if gather and world > 1:
-            gathered["hca"] = shard.gather_bytes_to_root(ho[:hj.output_bytes]); gathered["adx"] = shard.gather_bytes_to_root(ao[:aj.output_bytes])
+            # (launcher smoke test, ranks sharing one GPU over gloo: gloo has no device-tensor send / recv -- the parts travel as host copies)
+            part = (lambda t: t.cpu()) if D.shared else (lambda t: t)
+            gathered["hca"] = shard.gather_bytes_to_root(part(ho[:hj.output_bytes])); gathered["adx"] = shard.gather_bytes_to_root(part(aj_out(ao)))
     dt, kms = run_timed(D, step, max(steps, 1), max(warmup, 1), [hj, aj])
     hca_units, adx_units, n_all = D.reduce([float(hj.units), float(aj.units), float(n)], "sum")
     assert int((hst < 0).sum().item()) == 0 and int((ast < 0).sum().item()) == 0
@@ -766,20 +781,33 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
         v1 = verify_items(ho, [hj.output_offsets[i] for i in hi], [order[i] for i in hi], refs, "AWB HCA items")
         v2 = verify_items(ao, [aj.output_offsets[i] for i in ai], [order[i] for i in ai], refs, "AWB ADX items")
         res["verified"] = {"items": v1["items"] + v2["items"], "bytes": v1["bytes"] + v2["bytes"], "how": v1["how"]}
-        if gather and world > 1:                               # what arrived on the root: every rank's part, by byte sum and length
+        if gather and world > 1:
+            # what arrived on the root: EVERY rank's items, each compared with the oracle's output for the clip it is a copy of (the ranks
+            # send the root which clip sits where in their part), and every part's length and byte sum against its sender's own
             import torch.distributed as dist
-            sums = [None] * world
-            dist.all_gather_object(sums, [int(ho[:hj.output_bytes].sum(dtype=torch.int64).item()), int(ao[:aj.output_bytes].sum(dtype=torch.int64).item()),
-                                          int(hj.output_bytes), int(aj.output_bytes)])
+            mine = [[order[i] for i in hi], [int(hj.output_offsets[i]) for i in hi], [order[i] for i in ai], [int(aj.output_offsets[i]) for i in ai],
+                    int(ho[:hj.output_bytes].sum(dtype=torch.int64).item()), int(ao[:aj.output_bytes].sum(dtype=torch.int64).item()), int(hj.output_bytes), int(aj.output_bytes)]
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
             if D.rank == 0:
+                need = set()
+                for pr in parts:
+                    need.update(pr[0]); need.update(pr[2])
+                refs_all = oracle_many(lambda t: None if t[0] not in need else (refs[t[0]] if refs[t[0]] is not None else
+                                                                                  (O.hca_decode(t[1][1], KEY, subkey) if t[1][0] == "hca" else O.adx_decode(t[1][1]))), list(enumerate(uniq)))
+                items_root = 0
                 for k, key in enumerate(("hca", "adx")):
                     got, offs = gathered[key]
+                    got = got.to(D.dev)
                     assert offs[-1] == got.numel()
                     for rr in range(world):
                         part = got[offs[rr]:offs[rr + 1]]
-                        assert part.numel() == sums[rr][2 + k] and int(part.sum(dtype=torch.int64).item()) == sums[rr][k], "gathered PCM of rank %d differs" % rr
-                assert torch.equal(gathered["hca"][0][:hj.output_bytes], ho[:hj.output_bytes])
+                        assert part.numel() == parts[rr][6 + k] and int(part.sum(dtype=torch.int64).item()) == parts[rr][4 + k], "gathered PCM of rank %d differs" % rr
+                        vv = verify_items(part, parts[rr][2 * k + 1], parts[rr][2 * k], refs_all, "gathered %s items of rank %d" % (key, rr))
+                        items_root += vv["items"]
                 res["gathered_bytes_on_root"] = int(gathered["hca"][0].numel() + gathered["adx"][0].numel())
+                res["gathered_items_verified_on_root"] = items_root
+                assert items_root == int(n_all)
     del d_in, ho, hscr, ao, ascr
     torch.cuda.empty_cache()
     return res
@@ -799,16 +827,26 @@ def secondary_measurements(args, D):
     #  this list, after dozens of jobs' buffers have come and gone, the same downloads ran 10 % slower)
     out["hca_decode_host"] = host_path_run(min(args.streams, args.host_streams), uq, args.seconds)
     out["adx_decode_host"] = host_path_run(min(1000, args.streams), uq, args.seconds, codec="adx")
+    full = args.streams if (args.streams > n and not args.no_full_secondary) else 0      # the same rows at the headline's size (chip filled ~18 times)
+
+    def dec_entry(r, workload, extra=None):
+        e = {"workload": workload, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
+             "channel_frames_per_s": round(r["units"] * r["channels"] / r["dt"], 1),
+             "frac_end_to_end": round(r["alg_bytes"] / r["dt"] / 1e9 / HBM_PEAK_GBPS, 5),
+             "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "transform_kernel": r["job"].dominant_kernel, "record_forms": census_text(r["census"]),
+             "verified_items": r["verified"]["items"]}
+        e.update(extra or {})
+        r.pop("job", None)
+        return e
     for label, q, fam in (("hca_decode_sparse_spectra", 1, "sparse"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_noise", 1, "noise"), ("hca_decode_middle", 2, "tonal"),
                           ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
-        r = hca_decode_run(D, n, uq, args.seconds, q, fam, 3, 1)
-        out[label] = {"workload": "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (n, args.seconds, QNAME[q], fam),
-                      "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
-                      "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "record_forms": census_text(r["census"]),
-                      "verified_items": r["verified"]["items"]}
+        uniq = make_hca_streams(uq, args.seconds, D.rank, q, fam)
+        for size, steps in ((n, 3),) + (((full, 3),) if full else ()):
+            r = hca_decode_run(D, size, uq, args.seconds, q, fam, steps, 1, uniq=uniq)
+            out[label + ("" if size == n else "_full")] = dec_entry(r, "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (size, args.seconds, QNAME[q], fam))
     # the other layouts of the decode path: 6, 8 and 3 channels (plain formats: k_hca_transform_plain's wide form, a wave per four
     # channels), and k_hca_transform<false, 2> with the v3.0 noise fill (a v2.0 stream re-headed as v3.0 with min_resolution 0: every
-    # band below the noise level is reconstructed)
+    # band below the noise level is reconstructed).  Full size = as many channel-frames as the headline (streams x 2 / channels).
     import hca_forge
     nw = max(1, n // 4)
     for label, ch, v3, q in (("hca_decode_6ch", 6, False, 1), ("hca_decode_8ch", 8, False, 1), ("hca_decode_v3_noise_fill", 2, True, 1), ("hca_decode_3ch", 3, False, 1),
@@ -817,10 +855,11 @@ def secondary_measurements(args, D):
         plain = [O.hca_encode(family_wav(8000 + 10 * ch + u, args.seconds, "tonal", ch=ch), q) for u in range(4)]
         if v3:
             plain = [hca_forge.forge_v3(h, 0) for h in plain]
-        r = hca_decode_run(D, nw, 4, args.seconds, q, "tonal", 3, 1, uniq=[O.hca_crypt(h, 1, 56, KEY) for h in plain])
-        out[label] = {"workload": "HCA decode, %d x %.0f s encrypted %d-channel streams, quality %s%s" % (nw, args.seconds, ch, QNAME[q], ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""),
-                      "transform_kernel": r["job"].dominant_kernel, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
-                      "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "verified_items": r["verified"]["items"]}
+        uniq = [O.hca_crypt(h, 1, 56, KEY) for h in plain]
+        for size, steps in ((nw, 3),) + (((full * 2 // ch, 3),) if full else ()):
+            r = hca_decode_run(D, size, 4, args.seconds, q, "tonal", steps, 1, uniq=uniq)
+            out[label + ("" if size == nw else "_full")] = dec_entry(
+                r, "HCA decode, %d x %.0f s encrypted %d-channel streams, quality %s%s" % (size, args.seconds, ch, QNAME[q], ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""))
     r = hca_encode_run(D, n, uq, args.seconds, 1, "tonal", 3, 1)
     out["hca_encode"] = {"workload": "HCA encode (quality High), %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), "frames_per_s": round(r["units"] / r["dt"], 1),
                          "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"], "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()},
@@ -1028,6 +1067,84 @@ def relaunch_under_torchrun(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+LINE_LIMIT = 4096                                              # bytes of the ONE stdout line (the driver's parser dropped round 5's 22 KB line)
+DETAIL_NAME = "bench_detail.json"
+
+
+def _short(x, n):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
+
+
+def compact_line(full):
+    """The ONE line the driver parses, from the full result: the contract's keys, `config` / `roofline` / `cpu_baseline` with their
+    figures and short provenance strings, and where the rest is.  Everything that is left out here (secondaries, the other BASELINE
+    configurations, long descriptions) is in bench_detail.json (emit)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "launcher_smoke_test")
+    line = {k: _short(full[k], 120) for k in keep if k in full}
+    cfg = full.get("config", {})
+    c = {"workload": _short(cfg.get("workload", ""), 230)}
+    for k in ("streams_per_gpu", "files_per_gpu", "frames_per_stream", "unique_streams", "unique_wavs", "chains", "batch_total", "hca_frames", "adx_frames", "distinct_lengths",
+              "clips_per_s", "gathered_bytes_on_root", "gathered_items_verified_on_root", "record_forms"):
+        if k in cfg:
+            c[k] = _short(cfg[k], 90)
+    if "parallelism" in cfg:
+        c["parallelism"] = _short(cfg["parallelism"], 100)
+    v = cfg.get("verified")
+    if v:
+        c["verified"] = {"items": v.get("items"), **({"items_all_ranks": v["items_all_ranks"]} if "items_all_ranks" in v else {}), "bytes": v.get("bytes"),
+                         "how": "every item, on the device, byte for byte vs the CPU oracle"}
+    if cfg.get("sustained"):
+        c["sustained"] = cfg["sustained"]
+    line["config"] = c
+    r = full.get("roofline")
+    if r:
+        rr = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_end_to_end", "traffic", "traffic_over_algorithmic", "algorithmic_bytes_per_launch",
+                                "kernel_ms_per_step", "dominant_kernel") if k in r}
+        if "valu" in r:
+            rr["valu"] = {k: r["valu"][k] for k in ("insts_per_frame", "busy", "floor_ms") if k in r["valu"]}
+        for k, n in (("bytes_per_unit", 80), ("traffic_source", 150)):
+            if r.get(k):
+                rr[k] = _short(r[k], n)
+        line["roofline"] = rr
+    b = full.get("cpu_baseline")
+    if b:
+        bb = {k: _short(b[k], 170) for k in ("value", "unit", "cores", "kind", "cpu_model", "sample") if k in b}
+        if b.get("all_cores"):
+            bb["all_cores"] = {k: b["all_cores"][k] for k in ("value", "cores") if k in b["all_cores"]}
+        line["cpu_baseline"] = bb
+    s = full.get("secondary") or {}
+    if s.get("baseline_configs"):                              # the other BASELINE configurations of the default run: value only (all of it in the detail file)
+        line["other_configs_M_per_s"] = {k.split(" ")[0] + ("/sfx" if "sfx" in k else "/distinct" if "distinct" in k else ""): round(v["value"] / 1e6, 1) for k, v in s["baseline_configs"].items()}
+    line["detail"] = DETAIL_NAME
+    return line
+
+
+def emit(full):
+    """Rank 0: the full result to bench_detail.json (repo root, and $BENCH_DETAIL_DIR when set -- gpurun_out/<tag> on a GPU box) and to
+    stderr; ONE compact JSON line (<= LINE_LIMIT bytes) on stdout."""
+    text = json.dumps(full, indent=1, default=str)
+    for d in [ROOT] + ([os.environ["BENCH_DETAIL_DIR"]] if os.environ.get("BENCH_DETAIL_DIR") else []):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, DETAIL_NAME), "w") as fh:
+                fh.write(text + "\n")
+        except OSError as e:
+            log("could not write %s: %s" % (os.path.join(d, DETAIL_NAME), e))
+    log("---- detail (also in %s) ----" % DETAIL_NAME)
+    log(json.dumps(full, default=str))
+    line = json.dumps(compact_line(full))
+    if len(line) > LINE_LIMIT:                                 # never again a line the driver cannot read: drop the optional parts
+        c = compact_line(full)
+        for k in ("other_configs_M_per_s",):
+            c.pop(k, None)
+        for k in ("traffic_source", "bytes_per_unit", "valu", "dominant_kernel"):
+            c.get("roofline", {}).pop(k, None)
+        c.get("cpu_baseline", {}).pop("sample", None)
+        line = json.dumps(c)
+    assert len(line) <= LINE_LIMIT, len(line)
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1048,6 +1165,7 @@ def main():
     ap.add_argument("--no-distinct", action="store_true", help="skip the all-streams-distinct form of the headline inside the default run")
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
+    ap.add_argument("--no-full-secondary", action="store_true", help="secondaries at --secondary-streams only, not also at the headline's size")
     ap.add_argument("--host-streams", type=int, default=10000, help="streams of the host-memory secondary (host output buffers: 1.92 MB each)")
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
     ap.add_argument("--awb-durations", type=int, default=4096, help="distinct clip lengths of the mixed AWB bank (log-uniform 0.05-2 s; each as an HCA and as an ADX clip)")
@@ -1083,9 +1201,9 @@ def main():
                                                        {"bytes_per_unit": "HCA frame: frame_size + 4096 B; ADX block row: 2 x 82 B (stereo); rank 0's jobs"}))
             if not args.no_cpu:
                 common["cpu_baseline"] = cpu_baseline_awb(cp)
-            print(json.dumps(dict(common, metric="audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", value=r["frames_per_s"], unit="frames/s",
-                                  ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (%d distinct clip lengths x 2 codecs, heads of 24 base signals; %s family)" % (r["distinct_lengths"], r["material"]),
-                                  config=r)), flush=True)
+            emit(dict(common, metric="audio frames/sec, mixed AWB bank decode (BASELINE configs[4])", value=r["frames_per_s"], unit="frames/s",
+                      ms_per_step=r["ms_per_step"], dtype="f32+int32", data="synthetic (%d distinct clip lengths x 2 codecs, heads of 24 base signals; %s family)" % (r["distinct_lengths"], r["material"]),
+                      config=r))
         D.close()
         return
 
@@ -1139,9 +1257,9 @@ def main():
     roof = roofline_of(alg_dom, r["alg_bytes"], kms, dt, traffic, extra)
     out = dict(common, metric="audio frames/sec (decode+encode) at 1/2/4/8 GPU; HBM GB/s vs roofline", value=round(units_all / dt, 1), unit="frames/s",
                ms_per_step=round(dt * 1e3, 3), dtype=dtype,
-               data="synthetic, %s family (%s); %d unique inputs tiled to %d, each copy in its own HBM" % (
-                   args.data, {"tonal": "seeded sines + noise floor", "sparse": "pure / sparse tones and low-passed noise", "noise": "full-scale noise / square / clicks / loud tones in noise",
-                               "mixed": "tonal and sparse alternating", "sfx": "tonal with 0.05-0.5 s of digital silence before and after"}[args.data], unique, streams),
+               data="synthetic, %s family (%s); %d unique tiled to %d, each copy in its own HBM" % (
+                   args.data, {"tonal": "seeded sines + noise floor", "sparse": "sparse tones, low-passed noise", "noise": "full-scale noise / square / clicks",
+                               "mixed": "tonal and sparse alternating", "sfx": "tonal between digital silence"}[args.data], unique, streams),
                config=cfg, roofline=roof)
     # other rows of the same hot path and the host-core baseline: single-GPU run only (ranks of a scaling run must not wait)
     if D.rank == 0 and D.world == 1 and wl == "hca_decode" and not args.no_secondary:
@@ -1155,7 +1273,7 @@ def main():
         os.sched_setaffinity(0, D.affinity0)                   # the host-core baseline gets every core of the box again
         out["cpu_baseline"] = cpu_baseline(*cpu)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world == 1:
         D.close()
 

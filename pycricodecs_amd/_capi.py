@@ -5,6 +5,7 @@ calls fail loudly (CriCodecsError / OSError) -- there is no Python or CPU fallba
 """
 import ctypes as C
 import os
+import subprocess
 
 try:  # load torch's bundled HIP runtime first so both sides share one libamdhip64 (same soname)
     if os.environ.get("CRICODECS_NO_TORCH") == "1":      # (the AddressSanitizer run: its allocator hooks need the system's HIP runtime)
@@ -108,8 +109,13 @@ def _fresh(path):
     if os.environ.get("CRICODECS_NO_REBUILD") == "1":
         raise OSError("%s is not built from this tree (library %s, sources %s): run `python -m pycricodecs_amd.build`" % (path, B.embedded_id(path), want))
     import sys
-    print("pycricodecs_amd: %s is stale or missing (library %s, sources %s): rebuilding" % (os.path.basename(path), B.embedded_id(path), want), file=sys.stderr, flush=True)
-    B.build(verbose=False)
+    have = B.embedded_id(path)
+    print("pycricodecs_amd: %s is stale or missing (library %s, sources %s): rebuilding" % (os.path.basename(path), have, want), file=sys.stderr, flush=True)
+    try:
+        B.build(verbose=False)                                 # (serialised across processes by an flock on the library directory; outputs are renamed into place)
+    except (OSError, subprocess.SubprocessError) as e:
+        raise OSError("%s is not built from this tree (library %s, sources %s) and rebuilding it failed: %s -- run `python -m pycricodecs_amd.build` where hipcc is"
+                      % (path, have, want, e)) from e
 
 
 def _bind(path):

@@ -35,7 +35,13 @@ def _hipcc():
 
 
 def _extra():
-    return os.environ.get("CRI_HIPCC_EXTRA", "").split()
+    """Extra compiler flags (sanitizer builds, -DCRI_ENC_PROFILE).  The product sources hold no switch that changes results; a flag
+    that looks like one of the old timing experiments (-DEXP_*: wrong samples, tools/debug/experiments/) is refused outright."""
+    flags = os.environ.get("CRI_HIPCC_EXTRA", "").split()
+    bad = [f for f in flags if f.startswith("-DEXP_")]
+    if bad:
+        raise OSError("CRI_HIPCC_EXTRA holds %s: experiment switches are not part of the product tree (tools/debug/experiments/variant.sh builds them in a scratch copy)" % " ".join(bad))
+    return flags
 
 
 def _link_extra():
@@ -90,7 +96,7 @@ def _compile(src, obj, defines, verbose):
     """Compiles src -> obj unless obj was made from exactly these inputs (a hash of source + headers + command beside the object)."""
     hipcc = _hipcc()
     cmd = [hipcc] + FLAGS + defines + _extra() + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-    key = _digest([os.path.join(CSRC, src)] + _headers(), " ".join(cmd))
+    key = _digest([os.path.join(CSRC, src)] + _headers(), " ".join(cmd))      # (the stamp is written after the object: a build that died leaves no stamp)
     stamp = obj + ".key"
     try:
         with open(stamp) as f:
@@ -106,7 +112,44 @@ def _compile(src, obj, defines, verbose):
     return obj
 
 
+class _Lock:
+    """One builder at a time per library directory (ranks of a torchrun job and pytest-xdist workers import at the same moment): an
+    flock on LIBDIR/.build.lock; whoever comes second finds the libraries fresh and builds nothing."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(LIBDIR, exist_ok=True)
+        self.fh = open(os.path.join(LIBDIR, ".build.lock"), "w")
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
+        return False
+
+
+def _link(cmd_head, objs, out, verbose):
+    """Links into a temporary name and renames: a process that dlopen()s `out` meanwhile sees the old file or the new one, never half of one."""
+    tmp = out + ".tmp.%d" % os.getpid()
+    cmd = cmd_head + objs + ["-o", tmp, "-Wl,-rpath,/opt/rocm/lib"] + _no_undefined()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def build(force=False, verbose=True):
+    with _Lock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     if not force and not _stale():
         import sysconfig
         ext = os.path.join(LIBDIR, "CriCodecs" + sysconfig.get_config_var("EXT_SUFFIX"))
@@ -125,19 +168,13 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
         objs.append(_compile(src, obj, iddef if src == "cri_capi.cpp" else [], verbose))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + _link_extra() + objs + ["-o", LIB, "-Wl,-rpath,/opt/rocm/lib"] + _no_undefined()
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    _link([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + _link_extra(), objs, LIB, verbose)
     # the testing build: same objects, except the planner (knobs settable) and the test-only kernels
     tobjs = [o for o in objs if not o.endswith("cri_capi.o")]
     for src in TESTING_SOURCES:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + "_testing.o")
         tobjs.append(_compile(src, obj, ["-DCRI_TESTING"] + (iddef if src == "cri_capi.cpp" else []), verbose))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + _link_extra() + tobjs + ["-o", TESTING_LIB, "-Wl,-rpath,/opt/rocm/lib"] + _no_undefined()
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    _link([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + _link_extra(), tobjs, TESTING_LIB, verbose)
     build_extension(verbose)
     assert embedded_id(LIB) == bid and embedded_id(TESTING_LIB) == bid, "the build id did not make it into the libraries"
     return LIB
@@ -148,10 +185,16 @@ def build_extension(verbose=True):
     import sysconfig
     src = os.path.join(CSRC, "pyext", "CriCodecs_ext.cpp")
     out = os.path.join(LIBDIR, "CriCodecs" + sysconfig.get_config_var("EXT_SUFFIX"))
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], src, "-o", out, "-ldl"]
+    tmp = out + ".tmp.%d" % os.getpid()
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], src, "-o", tmp, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return out
 
 

@@ -235,7 +235,7 @@ struct cri_job {
     std::vector<cri_job*> host_parts;
     std::vector<uint32_t> host_part_first;       // [parts + 1] first item of each part
     // One event per stream the job has been run on (two threads may run one job on their own streams; the host path runs its
-    // parts on private streams): the destructor waits for all of them.  Past 16 streams the oldest entry is waited for and reused.
+    // parts on private streams): the destructor waits for all of them.  Past 16 streams finished entries are reused (never waited for).
     std::mutex run_mu;
     std::vector<std::pair<hipStream_t, hipEvent_t>> run_events;
     void note_run(hipStream_t s) {
@@ -246,10 +246,13 @@ struct cri_job {
         hipEvent_t ev = nullptr;
         for (auto& e : run_events) if (e.first == s) { ev = e.second; break; }
         if (!ev) {
-            if (run_events.size() >= 16) {
-                ev = run_events.front().second; run_events.erase(run_events.begin());
-                (void)hipEventSynchronize(ev);
-            } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+            // Past 16 streams an entry whose event has COMPLETED is reused (a query, never a wait: cri_job_run does not block, and a
+            // blocking call here could also break another thread's global-mode capture); while all are pending the list grows.
+            if (run_events.size() >= 16)
+                for (size_t i = 0; i < run_events.size(); i++)
+                    if (hipEventQuery(run_events[i].second) == hipSuccess) { ev = run_events[i].second; run_events.erase(run_events.begin() + (long)i); break; }
+                    else (void)hipGetLastError();              // (hipErrorNotReady is the answer, not a fault)
+            if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
             run_events.emplace_back(s, ev);
         }
         (void)hipEventRecord(ev, s);

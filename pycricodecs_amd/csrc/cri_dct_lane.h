@@ -103,34 +103,3 @@ __device__ __forceinline__ void dct4_inplace(f2 p[4], const DctLane& L) {
     rotate_cross<8, 0>(p, L); rotate_cross<4, 1>(p, L); rotate_cross<2, 2>(p, L); rotate_cross<1, 3>(p, L);       // rotation stages 0..3
     rotate_pairs<4, 4>(p, L); rotate_pairs<2, 5>(p, L); rotate_within<6>(p, L);                                   // rotation stages 4..6
 }
-
-#ifdef EXP_DCT_T
-// TIMING EXPERIMENT ONLY (wrong numbers): what the DCT would cost with the stages on lane16 ^ 1, 2, 4 done between registers after a transposition
-// through LDS (registers <-> lane bits 0..2) and a transposition back -- 8 DPP moves, 8 DPP multiplies and four 16-byte + sixteen 4-byte LDS
-// operations per pass instead of 24 + 24 and 16 swizzles.
-__device__ __forceinline__ void dct_transpose(f2 p[4], float* tb, uint32_t lane) {
-    float* w = tb + (lane >> 3) * 72 + (lane & 7) * 8;
-    *(float4*)w = float4{p[0].x, p[0].y, p[1].x, p[1].y};
-    *(float4*)(w + 4) = float4{p[2].x, p[2].y, p[3].x, p[3].y};
-    wave_lds_sync();
-    const float* r = tb + (lane >> 3) * 72 + (lane & 7);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { p[k].x = r[(2 * k) * 8]; p[k].y = r[(2 * k + 1) * 8]; }
-}
-__device__ __forceinline__ void dct4_inplace_T(f2 p[4], const DctLane& L, float* tb, uint32_t lane) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) p[k] = pk_sum_diff(p[k]);
-    { const f2 a0 = p[0], a2 = p[2]; p[0] = a0 + p[1]; p[1] = a0 - p[1]; p[2] = a2 + p[3]; p[3] = a2 - p[3]; }
-    { const f2 a0 = p[0], a1 = p[1]; p[0] = a0 + p[2]; p[2] = a0 - p[2]; p[1] = a1 + p[3]; p[3] = a1 - p[3]; }
-    dct_transpose(p, tb, lane);
-#pragma unroll
-    for (int k = 0; k < 4; k++) p[k] = pk_sum_diff(p[k]);
-    { const f2 a0 = p[0], a2 = p[2]; p[0] = a0 + p[1]; p[1] = a0 - p[1]; p[2] = a2 + p[3]; p[3] = a2 - p[3]; }
-    { const f2 a0 = p[0], a1 = p[1]; p[0] = a0 + p[2]; p[2] = a0 - p[2]; p[1] = a1 + p[3]; p[3] = a1 - p[3]; }
-    sumdiff_cross<8, 3>(p, L);
-    rotate_cross<8, 0>(p, L);
-    rotate_pairs<4, 4>(p, L); rotate_pairs<2, 5>(p, L); rotate_within<6>(p, L);
-    dct_transpose(p, tb, lane);
-    rotate_pairs<4, 4>(p, L); rotate_pairs<2, 5>(p, L); rotate_within<6>(p, L);
-}
-#endif

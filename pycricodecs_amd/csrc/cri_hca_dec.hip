@@ -89,10 +89,7 @@ __device__ __forceinline__ uint4 ld_u128_unaligned(const uint8_t* p) { uint4 v; 
 // lane that burned more than 4 words in one block) and sits behind a wave-uniform branch, and so do the frame's last,
 // partial chunk and a chunk that would reach past the end of the input blob.
 #define RING_WORDS 16       // (+ 4 spare rows: the sink of a lane that lands nothing)
-#ifndef EXP_PARSE_LDS_PAD
-#define EXP_PARSE_LDS_PAD 0    // (timing experiment: idle LDS per wave, e.g. 4096 = what a 32-word ring would take: three waves per SIMD)
-#endif
-size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)EXP_PARSE_LDS_PAD + (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + 256 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
+size_t hca_parse_lds_bytes(uint32_t n_cipher) { return (size_t)(RING_WORDS + 4) * 256 + 16 * 66 * 4 + 96 + 128 + 128 + 16 + 256 + (size_t)(n_cipher <= 16 ? n_cipher : 0) * 256; }
 
 struct BitFeed {
     const uint8_t* next;     // next chunk of this lane's frame in the input blob
@@ -425,9 +422,6 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     {
         uint32_t si = a.stream_begin, f = 0;
         if (valid) { si = find_stream(a.streams, a.stream_begin, a.stream_end, g); f = g - a.streams[si].first_frame; }
-#ifdef EXP_FOLD_INPUT                                      // (timing / power experiment only -- wrong output: every tile reads the first stream's first 64 frames, i.e. its input out of L2)
-        if (valid) { si = a.stream_begin; f = lane; }
-#endif
         const uint64_t src_offset = a.streams[si].src_offset;
         const uint32_t cidx = a.streams[si].cipher;
         fd.next = a.in + src_offset + (uint64_t)f * F.frame_size;
@@ -609,11 +603,7 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
     //      operation a block waits for (feed_land) is then a whole block old.
     //      Formats the in-lane transform handles (a.narrow) store the lines as int8 -- half the record bytes, and this kernel is
     //      partly bound by the CU's store path -- when no band of the tile's 64 frames can exceed 8 bits (the usual case by far).
-#ifdef EXP_FORCE_NARROW                                    // (timing experiment only -- wrong samples: what a record form with int8 lines for EVERY tile could gain at most)
-    const bool narrow = a.narrow != 0;
-#else
     const bool narrow = a.narrow != 0 && !__any(wide_bits != 0);
-#endif
     //      (channels without coded bands -- a secondary channel of a format with base_band_count 0 -- have no blocks)
     uint32_t first_c = 0;
     while (first_c + 1 < C && F.coded(first_c) == 0) first_c++;
@@ -1561,11 +1551,7 @@ constexpr LcgPow make_lcg_pow() {
     return t;
 }
 __device__ const LcgPow HCA_LCG_POW = make_lcg_pow();
-#ifdef EXP_DCT_T
-#define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048 + 2304)
-#else
 #define HCA_PLAIN_LDS_BYTES (2048 + 1024 + 256 + 64 + 80 + 2048 + 2048)
-#endif
 #define HCA_PLAIN_JOINT_LDS_BYTES (HCA_PLAIN_LDS_BYTES + 2048 + 2048 + 512 + 64 + 128 + 16 + 512 + 256)
 struct PlainPre { uint2 ps; uint32_t fl; uint32_t ib; uint32_t dr; uint32_t sf2[4]; };   // setup inputs of the four units' frames: lane v < 4 holds unit v's record tail {packed, status}, flags
 
@@ -2017,10 +2003,6 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
                 if (ld8) { const uint2 t = *(const uint2*)p; q.x = t.x; q.y = t.y; } else q = *(const uint4*)p;
             }
             __builtin_amdgcn_sched_barrier(0);             // (keep the load here: the compiler would sink it behind most of the DCT)
-#ifdef EXP_DCT_T
-            if (!JOINT && !WIDE) dct4_inplace_T(x, L, (float*)(smem + 2048 + 1024 + 256 + 64 + 80 + 2048 + 2048), lane);
-            else
-#endif
             dct4_inplace(x, L);
             if (WIDE) __syncthreads();                     // (every wave has taken the previous pass's PCM out of the shared piece)
             if (s < 0) {

@@ -776,8 +776,12 @@ __global__ __launch_bounds__(64 * (CT > ENC_MAX_WAVES ? CT : (ENC_MAX_WAVES / CT
 #pragma unroll
             for (int sf = 0; sf < 8; sf++) {
                 const uint32_t tl = incl[sf] >> 16;
-                // BitWriter drops writes that do not fit (IO.cpp:131-134); the rate loop guarantees they do
-                put_bits(words, start + rowbase[sf] + ((incl[sf] & 0xFFFF) - tl), both[sf], tl);
+                // BitWriter drops a write that does not fit (IO.cpp:131-134).  The rate loop's count can come out a few bits short of what the
+                // pack writes (see the checksum below): a code the reference drops then starts inside the frame's last 16 bits, which the
+                // checksum replaces, so writing it is harmless -- but a write that STARTS past the frame's end is skipped, whatever the
+                // shortfall: the image has two spare words behind it, and a pair of codes is at most 26 bits, so nothing leaves `words`.
+                const uint32_t at = start + rowbase[sf] + ((incl[sf] & 0xFFFF) - tl);
+                if (at < F.frame_size * 8) put_bits(words, at, both[sf], tl);
             }
         }
         ENC_MARK(9);
@@ -874,12 +878,13 @@ void launch_hca_encode(const HcaEncArgs& a, hipStream_t s) {
     // persistent workgroups: eight times what the chip holds at once (by wave slots and LDS), each walking its share of the groups -- the
     // set-up is still shared by hundreds of frames, and a workgroup that starts late (an estimate that is off, a slow compute unit) costs an
     // eighth of a share, not a whole one
-    static std::atomic<int> cus_cached{0};
-    int cus = cus_cached.load();
+    static std::atomic<int> cus_cached[64];                // per device (a box may hold devices of different sizes); zero-initialised
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    int cus = dev >= 0 && dev < 64 ? cus_cached[dev].load() : 0;
     if (cus <= 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
-        cus_cached.store(cus);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        if (dev >= 0 && dev < 64) cus_cached[dev].store(cus);
     }
     const uint32_t by_waves = ENC_WAVES_PER_SIMD_OF(a.channels) * 4u * 64u / threads, by_lds = (uint32_t)((160u * 1024u) / ((lds + 511) & ~(size_t)511));
     const uint32_t per_cu = std::max(1u, std::min(by_waves, by_lds));

@@ -83,10 +83,10 @@ static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels
 #define HCA_ET_CODE 2592      // uint8[256]   code; rows 8 .. 15: 0
 #define HCA_ET_WIN4 2848      // float4[8][8] the MDCT window: [register r][lane & 7] = the four factors of the point's two folded inputs (hca.cpp:2529-2553), times 2^-15, with
                               //              the fold's signs: {even a, odd a, even b, odd b}
-#define HCA_ET_LDS_BYTES 4896 // ... up to here the blob is copied into LDS; what follows is read from memory (every lane its own row: the L1 holds the 0.5 KB that are ever hit)
-#define HCA_ET_CLS 4896       // uint2[768]   row (x >> 22: sign, exponent field, top mantissa bit -- a half-binade), |x| < 1: {A, classes below}: class = base + (|x| >= A).  Rows
+#define HCA_ET_LDS_BYTES 3872 // ... up to here the blob is copied into LDS; what follows is read from memory (every lane its own row: the L1 holds the 0.5 KB that are ever hit)
+#define HCA_ET_CLS 3872       // uint2[768]   row (x >> 22: sign, exponent field, top mantissa bit -- a half-binade), |x| < 1: {A, classes below}: class = base + (|x| >= A).  Rows
                               //              256 .. 511 (exponents no |x| < 1 has) are never read
-#define HCA_ET_BYTES 11040
+#define HCA_ET_BYTES 10016    // HCA_ET_CLS + 768 * 8
 #define HCA_ENC_CLAMP_BITS 0x3F7FFFFEu   // ScaleSpectra's clamp 0.9999999f (hca.cpp:2639-2654): the one value the quantiser can push past its table
 
 

@@ -76,3 +76,33 @@ def test_the_gpu_box_runs_the_tree_sources():
     assert _ids() == (want, want)
     loaded = [l.split()[-1] for l in open("/proc/self/maps") if "libcricodecs_hip" in l]
     assert loaded and all(B.embedded_id(p) == want for p in set(loaded)), set(loaded)
+
+
+def test_no_experiment_switches_in_product_sources(monkeypatch):
+    """No preprocessor flag can make the product library produce wrong samples: the timing experiments of rounds 4 / 5 (-DEXP_*) are
+    patches under tools/debug/experiments/ applied to scratch copies, csrc/ holds no `EXP_` text, and the build refuses such a define."""
+    import glob
+    hits = []
+    for p in glob.glob(os.path.join(B.CSRC, "**", "*"), recursive=True):
+        if os.path.isfile(p) and p.endswith((".h", ".hip", ".cpp")):
+            with open(p, errors="replace") as f:
+                hits += ["%s:%d" % (os.path.basename(p), i + 1) for i, line in enumerate(f) if "EXP_" in line or "HCA_ABL_" in line]
+    assert hits == []
+    monkeypatch.setenv("CRI_HIPCC_EXTRA", "-DEXP_FOLD_INPUT")
+    with pytest.raises(OSError, match="experiment switches"):
+        B.source_id()
+    monkeypatch.setenv("CRI_HIPCC_EXTRA", "-DCRI_ENC_PROFILE")
+    assert B.source_id() != ""
+
+
+def test_experiment_patches_apply_to_the_product_sources(tmp_path):
+    """tools/debug/experiments/*.patch stay in step with csrc/ (they are applied to a scratch copy on the GPU box, variant.sh)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    patches = sorted(glob.glob(os.path.join(root, "tools", "debug", "experiments", "*.patch")))
+    assert len(patches) >= 4
+    for p in patches:
+        dst = os.path.join(tmp_path, os.path.basename(p)[:-6])
+        shutil.copytree(B.CSRC, os.path.join(dst, "pycricodecs_amd", "csrc"))
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", p], cwd=dst, capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stdout, r.stderr)

@@ -163,7 +163,7 @@ def test_encoder_threshold_tables_equal_the_quantiser_rule(shim):
     hca_enc_build_tables; here the rule is held against the reference's own expression -- (int)(x * inv + (inv + 1)) -
     (int)(inv + 0.5 - 8) into QuantizeSpectrumBits, |x| >= dead zone for resolutions 8..15 -- on every float within 4096 ulps of
     a threshold, the clamp value and its neighbours, the smallest magnitudes, and two million random values per resolution."""
-    ET_CP, ET_CLS, ET_INV, ET_CLEN, ET_CODE, ET_WIN4, ET_BYTES = 1568, 4896, 2048, 2336, 2592, 2848, 11040          # cri_types.h, HCA_ET_*
+    ET_CP, ET_CLS, ET_INV, ET_CLEN, ET_CODE, ET_WIN4, ET_BYTES = 1568, 3872, 2048, 2336, 2592, 2848, 10016          # cri_types.h, HCA_ET_*
     CLAMP = 0x3F7FFFFE
     buf = (C.c_uint8 * 16384)()
     shim.shim_hca_enc_tables.argtypes = [C.c_void_p, C.c_size_t]

@@ -286,7 +286,7 @@ def test_adx_bitdepth_1_decode():
     """files no encoder writes but the decoder takes: bitdepth 1 with large blocks (forged header, random blocks)"""
     import importlib.util
     import os
-    spec = importlib.util.spec_from_file_location("r2", os.path.join(os.path.dirname(__file__), "test_gpu_round2.py"))
+    spec = importlib.util.spec_from_file_location("r2", os.path.join(os.path.dirname(__file__), "test_gpu_adx.py"))
     r2 = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(r2)
     for args in ((255, 1, 2, 3, 1), (255, 1, 24, 2, 2), (160, 1, 8, 2, 3), (255, 1, 40, 1, 4), (18, 4, 2, 5, 5), (10, 2, 3, 4, 6)):
@@ -329,7 +329,7 @@ def test_hca_crypt_extreme_frame_sizes(fs):
 def test_hca_delay_and_padding_trims(ch):
     """The delay / padding trims of the decode loop (hca.cpp:3392-3425) on forged fmt chunks: odd delays, a delay longer than
     a frame, a padding that reaches into the second-to-last frame -- every channel count the transform kernels are
-    instantiated for (tests/test_gpu_round3.py decodes the same streams on the device)."""
+    instantiated for (tests/test_gpu_hca_decode.py decodes the same streams on the device)."""
     for k, (n, delay, pad) in enumerate([(9000, 128, 0), (9000, 1, 0), (12000, 127, 77), (2048 * 5, 1029, 1500), (700, 0, 3), (1024 * 9, 2, 1)]):
         h = hca_forge.forge_trim(O.hca_encode(synth.wav(2100 + 10 * ch + k, n, ch, 48000), 1), delay, pad)
         both(lambda: O.hca_decode(h), lambda: R.hca_decode(h))

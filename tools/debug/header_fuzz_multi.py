@@ -1,4 +1,4 @@
-"""Developer tool (GPU box): the header-mutation fuzz of tests/test_gpu_parity.py over more base streams (channel counts,
+"""Developer tool (GPU box): the header-mutation fuzz of tests/test_gpu_boundary.py over more base streams (channel counts,
 qualities, longer than one run of 8 frames) and ADX encodings.  usage: python tools/debug/header_fuzz_multi.py [iterations]
 (the ADX half is slow: edits of the sample-count field make both sides decode gigabytes of silence)"""
 import sys
