@@ -813,37 +813,44 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     return res
 
 
-def secondary_measurements(args, D):
-    """Other rows of the path on smaller batches (N = 1 only), every output verified: HCA decode of the other qualities and of
-    wide-band material (int16 records), HCA encode, ADX encode + decode, the USM @SFA layer, the mixed AWB bank."""
-    import torch
-    from pycricodecs_amd import usm
-    from pycricodecs_amd.batch import Job
-    import oracle_lib as O
+def _sec_sizes(args):
     n = args.secondary_streams
-    uq = min(args.unique, 16)
-    out = {}
+    return n, min(args.unique, 16), (args.streams if (args.streams > n and not args.no_full_secondary) else 0)      # (.., .., the headline's size: the chip filled ~18 times)
+
+
+def _dec_entry(r, workload, extra=None):
+    e = {"workload": workload, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
+         "channel_frames_per_s": round(r["units"] * r["channels"] / r["dt"], 1),
+         "frac_end_to_end": round(r["alg_bytes"] / r["dt"] / 1e9 / HBM_PEAK_GBPS, 5),
+         "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "transform_kernel": r["job"].dominant_kernel, "record_forms": census_text(r["census"]),
+         "verified_items": r["verified"]["items"]}
+    e.update(extra or {})
+    r.pop("job", None)
+    return e
+
+
+def sec_host_paths(args, D, out):
+    n, uq, full = _sec_sizes(args)
     # (first: the 44 GB of device buffers it needs are allocated while the device's memory is still in large pieces -- at the end of
     #  this list, after dozens of jobs' buffers have come and gone, the same downloads ran 10 % slower)
     out["hca_decode_host"] = host_path_run(min(args.streams, args.host_streams), uq, args.seconds)
     out["adx_decode_host"] = host_path_run(min(1000, args.streams), uq, args.seconds, codec="adx")
-    full = args.streams if (args.streams > n and not args.no_full_secondary) else 0      # the same rows at the headline's size (chip filled ~18 times)
 
-    def dec_entry(r, workload, extra=None):
-        e = {"workload": workload, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
-             "channel_frames_per_s": round(r["units"] * r["channels"] / r["dt"], 1),
-             "frac_end_to_end": round(r["alg_bytes"] / r["dt"] / 1e9 / HBM_PEAK_GBPS, 5),
-             "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "transform_kernel": r["job"].dominant_kernel, "record_forms": census_text(r["census"]),
-             "verified_items": r["verified"]["items"]}
-        e.update(extra or {})
-        r.pop("job", None)
-        return e
+
+def sec_decode_families(args, D, out):
+    """HCA decode of the other material families and qualities, stereo: at --secondary-streams and at the headline's size."""
+    n, uq, full = _sec_sizes(args)
     for label, q, fam in (("hca_decode_sparse_spectra", 1, "sparse"), ("hca_decode_mixed", 1, "mixed"), ("hca_decode_noise", 1, "noise"), ("hca_decode_middle", 2, "tonal"),
                           ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
         uniq = make_hca_streams(uq, args.seconds, D.rank, q, fam)
-        for size, steps in ((n, 3),) + (((full, 3),) if full else ()):
-            r = hca_decode_run(D, size, uq, args.seconds, q, fam, steps, 1, uniq=uniq)
-            out[label + ("" if size == n else "_full")] = dec_entry(r, "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (size, args.seconds, QNAME[q], fam))
+        for tag, size in (("", n),) + ((("_full", full),) if full else ()):
+            r = hca_decode_run(D, size, uq, args.seconds, q, fam, 3, 1, uniq=uniq)
+            out[label + tag] = _dec_entry(r, "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (size, args.seconds, QNAME[q], fam))
+
+
+def sec_decode_layouts(args, D, out):
+    import oracle_lib as O
+    n, uq, full = _sec_sizes(args)
     # the other layouts of the decode path: 6, 8 and 3 channels (plain formats: k_hca_transform_plain's wide form, a wave per four
     # channels), and k_hca_transform<false, 2> with the v3.0 noise fill (a v2.0 stream re-headed as v3.0 with min_resolution 0: every
     # band below the noise level is reconstructed).  Full size = as many channel-frames as the headline (streams x 2 / channels).
@@ -856,10 +863,14 @@ def secondary_measurements(args, D):
         if v3:
             plain = [hca_forge.forge_v3(h, 0) for h in plain]
         uniq = [O.hca_crypt(h, 1, 56, KEY) for h in plain]
-        for size, steps in ((nw, 3),) + (((full * 2 // ch, 3),) if full else ()):
-            r = hca_decode_run(D, size, 4, args.seconds, q, "tonal", steps, 1, uniq=uniq)
-            out[label + ("" if size == nw else "_full")] = dec_entry(
+        for tag, size in (("", nw),) + ((("_full", max(1, full * 2 // ch)),) if full else ()):
+            r = hca_decode_run(D, size, 4, args.seconds, q, "tonal", 3, 1, uniq=uniq)
+            out[label + tag] = _dec_entry(
                 r, "HCA decode, %d x %.0f s encrypted %d-channel streams, quality %s%s" % (size, args.seconds, ch, QNAME[q], ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""))
+
+
+def sec_encode_and_adx(args, D, out):
+    n, uq, full = _sec_sizes(args)
     r = hca_encode_run(D, n, uq, args.seconds, 1, "tonal", 3, 1)
     out["hca_encode"] = {"workload": "HCA encode (quality High), %d x %.0f s 48 kHz stereo WAVs" % (n, args.seconds), "frames_per_s": round(r["units"] / r["dt"], 1),
                          "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"], "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()},
@@ -870,6 +881,14 @@ def secondary_measurements(args, D):
                             "chains": 2 * n, "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()},
                             "achieved_GBps": {k: round(r["alg_bytes_by_kernel"][k] / (v * 1e-3) / 1e9, 2) for k, v in r["kernel_ms"].items() if k in r["alg_bytes_by_kernel"]},
                             "verified_items": r["verified"]["items"]}
+
+
+def sec_usm(args, D, out):
+    import torch
+    from pycricodecs_amd import usm
+    from pycricodecs_amd.batch import Job
+    import oracle_lib as O
+    n, uq, full = _sec_sizes(args)
     # USM audio layer: ADX files as masked @SFA chunk streams, then the demux of a container made of them (HBM-bound copies)
     adx_u = [O.adx_encode(family_wav(3000 + u, args.seconds, "tonal")) for u in range(uq)]
     adx_items = tile(adx_u, 250)                               # (a container carries at most 256 audio channels)
@@ -894,9 +913,24 @@ def secondary_measurements(args, D):
                         "chunks_per_s": round(job.units / dt, 1), "ms_per_step": round(dt * 1e3, 3), "verified_items": v["items"]}
     del bufs
     torch.cuda.empty_cache()
+
+
+def sec_awb(args, D, out):
     r = awb_mixed_run(D, args.awb_clips, 3, 1, n_durations=args.awb_durations)
     r.pop("_roofline_parts"); r.pop("_cpu_parts")
     out["awb_mixed_decode"] = r
+
+
+SECONDARY_PARTS = ["sec_host_paths", "sec_decode_families", "sec_decode_layouts", "sec_encode_and_adx", "sec_usm", "sec_awb"]
+
+
+def secondary_measurements(args, D):
+    """Other rows of the path (N = 1 only), every output verified: HCA decode of the other qualities, material families (int16 records)
+    and channel layouts -- at 1000 streams and at the headline's size --, HCA encode, ADX encode + decode, the USM @SFA layer, the mixed
+    AWB bank, the host-memory paths, the single-file calls, and every other BASELINE configuration at its written size."""
+    out = {}
+    for name in SECONDARY_PARTS:                               # (host paths first: their 44 GB of device buffers are allocated while the device's memory is still in large pieces)
+        globals()[name](args, D, out)
     out["single_call_ms"] = single_call_latency(args.seconds)
     lines = baseline_config_lines(args, D)
     # one compact object of everything above, next to the BASELINE configurations at the END of the line (the driver keeps the tail of stdout)
@@ -917,6 +951,9 @@ def baseline_config_lines(args, D):
     import torch
     lines = {}
     cs = args.config_cpu_seconds
+    ni = lambda n: max(4, int(round(n * args.config_items_scale)))
+    sec = lambda x: max(0.3, x * args.config_seconds_scale)
+    scaled = "" if (args.config_items_scale == 1.0 and args.config_seconds_scale == 1.0) else " [NOT the written size: items x %g, seconds x %g]" % (args.config_items_scale, args.config_seconds_scale)
 
     def line(r, workload, dtype, unit_bytes, cpu, traffic_key=None):
         kms = r["kernel_ms"]
@@ -941,25 +978,25 @@ def baseline_config_lines(args, D):
         del r
         torch.cuda.empty_cache()
     # configs[1]
-    r = adx_roundtrip_run(D, 1000, 16, 10.0, "tonal", 3, 1)
-    lines["configs[1] adx_roundtrip"] = line(r, "BASELINE configs[1]: ADX encode + decode round trip (bs18/bd4/mode3/v4), 1000 48 kHz stereo WAVs x 10 s; a frame = one block row, counted for the encode and for the decode",
+    r = adx_roundtrip_run(D, ni(1000), min(16, ni(1000)), sec(10.0), "tonal", 3, 1)
+    lines["configs[1] adx_roundtrip"] = line(r, "BASELINE configs[1]: ADX encode + decode round trip (bs18/bd4/mode3/v4), 1000 48 kHz stereo WAVs x 10 s; a frame = one block row, counted for the encode and for the decode" + scaled,
                                              "int32", "blocksize + 2*samples_per_block = 82 B per block, encode and decode each", None if args.no_cpu else cpu_baseline("adxrt", r["sample"], 2 * r["frames_per_stream"], cs), "adx_roundtrip")
-    r = adx_roundtrip_run(D, 1000, 16, 10.0, "sfx", 3, 1)
-    lines["configs[1] adx_roundtrip, sfx material"] = line(r, "the same on the SFX family (0.05-0.5 s of digital silence before and after the sound)", "int32", "82 B per block, encode and decode each", None, "adx_roundtrip_sfx")
+    r = adx_roundtrip_run(D, ni(1000), min(16, ni(1000)), sec(10.0), "sfx", 3, 1)
+    lines["configs[1] adx_roundtrip, sfx material"] = line(r, "the same on the SFX family (0.05-0.5 s of digital silence before and after the sound)" + scaled, "int32", "82 B per block, encode and decode each", None, "adx_roundtrip_sfx")
     # configs[3]
-    r = hca_encode_run(D, 10000, 16, 30.0, 1, "tonal", 3, 1)
-    lines["configs[3] hca_encode"] = line(r, "BASELINE configs[3]: HCA encode (v2.0, quality High), 10000 48 kHz stereo WAVs x 30 s", "f32",
+    r = hca_encode_run(D, ni(10000), min(16, ni(10000)), sec(30.0), 1, "tonal", 3, 1)
+    lines["configs[3] hca_encode"] = line(r, "BASELINE configs[3]: HCA encode (v2.0, quality High), 10000 48 kHz stereo WAVs x 30 s" + scaled, "f32",
                                           "frame_size + 2*1024*channels = %d + 4096 B per frame" % r["frame_size"], None if args.no_cpu else cpu_baseline("hcaenc", r["sample"], r["frames_per_stream"], cs), "hca_encode")
     r.pop("job", None)
     torch.cuda.empty_cache()
     # configs[4]
     for fam in ("tonal", "sfx"):
-        r = awb_mixed_run(D, args.config_awb_clips, 3, 1, family=fam, n_durations=args.awb_durations)
+        r = awb_mixed_run(D, ni(args.config_awb_clips), 3, 1, family=fam, n_durations=args.awb_durations)
         rp, cp = r.pop("_roofline_parts"), r.pop("_cpu_parts")
         kms = rp["kernel_ms"]
         dom = max(kms, key=kms.get)
         lines["configs[4] awb_mixed" + ("" if fam == "tonal" else ", sfx material")] = {
-            "workload": "BASELINE configs[4] on one GPU: " + r["workload"], "value": r["frames_per_s"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "dtype": "f32+int32",
+            "workload": "BASELINE configs[4] on one GPU: " + r["workload"] + scaled, "value": r["frames_per_s"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "dtype": "f32+int32",
             "frames_per_step": r["hca_frames"] + r["adx_frames"], "clips_per_s": r["clips_per_s"], "bank_bytes": r["bank_bytes_rank0"], "pcm_bytes": r["pcm_bytes_rank0"],
             "roofline": roofline_of(rp["alg_bytes_by_kernel"].get(dom, rp["alg_bytes"]), rp["alg_bytes"], kms, rp["dt"], committed_traffic_awb(r["hca_frames"], r["adx_frames"]),
                                     {"bytes_per_unit": "HCA frame: frame_size + 4096 B; ADX block row: 2 x 82 B (stereo)"}),
@@ -1069,6 +1106,7 @@ def relaunch_under_torchrun(args):
 
 LINE_LIMIT = 4096                                              # bytes of the ONE stdout line (the driver's parser dropped round 5's 22 KB line)
 DETAIL_NAME = "bench_detail.json"
+DETAIL_ROOT = ROOT                                         # where emit() writes it (and $BENCH_DETAIL_DIR)
 
 
 def _short(x, n):
@@ -1123,7 +1161,7 @@ def emit(full):
     """Rank 0: the full result to bench_detail.json (repo root, and $BENCH_DETAIL_DIR when set -- gpurun_out/<tag> on a GPU box) and to
     stderr; ONE compact JSON line (<= LINE_LIMIT bytes) on stdout."""
     text = json.dumps(full, indent=1, default=str)
-    for d in [ROOT] + ([os.environ["BENCH_DETAIL_DIR"]] if os.environ.get("BENCH_DETAIL_DIR") else []):
+    for d in [DETAIL_ROOT] + ([os.environ["BENCH_DETAIL_DIR"]] if os.environ.get("BENCH_DETAIL_DIR") else []):
         try:
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, DETAIL_NAME), "w") as fh:
@@ -1170,6 +1208,9 @@ def main():
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
     ap.add_argument("--awb-durations", type=int, default=4096, help="distinct clip lengths of the mixed AWB bank (log-uniform 0.05-2 s; each as an HCA and as an ADX clip)")
     ap.add_argument("--config-awb-clips", type=int, default=100000, help="clips of the configs[4] line inside the default run (one GPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="seconds of reference CPU work of the headline's cpu_baseline (single thread; again on all cores)")
+    ap.add_argument("--config-items-scale", type=float, default=1.0, help="dry runs / quick checks ONLY: the other BASELINE configurations inside the default run at this fraction of their written item counts (anything but 1 is labelled in their workload strings)")
+    ap.add_argument("--config-seconds-scale", type=float, default=1.0, help="the same for their seconds per item")
     ap.add_argument("--config-cpu-seconds", type=float, default=4.0, help="seconds of reference CPU work per baseline of the configs lines (single thread; again on all cores)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1271,7 +1312,7 @@ def main():
         out["config"]["host"] = dict(D.numa, note="the rank runs on the cores of its GPU's socket (matters to the host-memory lines only)")
     if rank == 0 and not args.no_cpu:
         os.sched_setaffinity(0, D.affinity0)                   # the host-core baseline gets every core of the box again
-        out["cpu_baseline"] = cpu_baseline(*cpu)
+        out["cpu_baseline"] = cpu_baseline(*cpu, seconds=args.cpu_seconds)
     if rank == 0:
         emit(out)
     if world == 1:

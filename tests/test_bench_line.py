@@ -55,7 +55,7 @@ def test_compact_line_is_small_and_complete(name, full):
 def test_emit_prints_one_short_line_and_writes_the_detail_file(tmp_path, monkeypatch, capsys):
     name, full = max(full_lines(), key=lambda t: len(json.dumps(t[1])))
     assert len(json.dumps(full)) > 8000                         # (a default run's result with its secondaries)
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "DETAIL_ROOT", str(tmp_path))
     monkeypatch.setenv("BENCH_DETAIL_DIR", str(tmp_path / "out"))
     bench.emit(full)
     cap = capsys.readouterr()
