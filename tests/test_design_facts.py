@@ -1,0 +1,55 @@
+"""DESIGN.md's statements about registers, spills, scratch and waves per SIMD are the compiler's (round 5's document said "no spills at
+80 registers" of a kernel the compiler gives 2 VGPR + 107 SGPR spills): the kernels DESIGN quotes are compiled here with the product's
+flags (`tools/kernel_resources.py`: hipcc -Rpass-analysis=kernel-resource-usage, no GPU needed) and both DESIGN.md's sentences and the
+committed table `profiles/r06_kernel_resources.txt` are held to the result."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# kernel -> (VGPRs, waves per SIMD, VGPR spills, SGPR spills, scratch bytes per lane), and how DESIGN.md section 2 words it
+QUOTED = {
+    "k_hca_parse<false, true>": ((128, 4, 2, 76, 12), "128 VGPR / 4 / 2 VGPR + 76 SGPR spills, 12 B scratch"),
+    "k_hca_transform_plain<2, false, false, false, false>": ((126, 4, 0, 0, 0), "126 VGPR / 4 / none"),
+    "k_hca_transform_plain<4, false, false, true, false>": ((128, 4, 6, 0, 28), "plain: 128 VGPR / 4 / **6 VGPR spills, 28 B scratch**"),
+    "k_hca_transform_plain<2, false, true, false, true>": ((168, 3, 11, 70, 48), "168 VGPR / 3 / **11-12 VGPR spills, 48 B**"),
+    "k_hca_encode<2>": ((80, 6, 2, 107, 12), "80 VGPR / 6 / **2 VGPR + 107 SGPR spills, 12 B scratch**"),
+    "k_adx_seg_decode": ((90, 5, 0, 0, 0), "90 VGPR / 5 / none"),
+    "k_adx_lane_encode": ((144, 3, 0, 0, 0), "144 VGPR / 3 / none"),
+    "k_hca_crypt_wpf": ((24, 8, 0, 0, 0), "24 VGPR / 8"),
+}
+
+
+@pytest.fixture(scope="module")
+def compiled():
+    import kernel_resources as K
+    return K.kernel_resources()
+
+
+def test_the_compiler_says_what_design_quotes(compiled):
+    with open(os.path.join(ROOT, "DESIGN.md")) as fh:
+        design = fh.read()
+    for kernel, (want, wording) in QUOTED.items():
+        r = compiled[kernel]
+        got = (r["vgpr"], r["waves_per_simd"], r["vgpr_spills"], r["sgpr_spills"], r["scratch_bytes"])
+        assert got == want, (kernel, got, want)
+        assert wording in design, "DESIGN.md no longer says %r of %s" % (wording, kernel)
+    assert "no spills at 80 registers" not in design
+
+
+def test_the_committed_table_is_the_compilers(compiled):
+    """profiles/r06_kernel_resources.txt, row by row, for every kernel of the library."""
+    rows = {}
+    with open(os.path.join(ROOT, "profiles", "r06_kernel_resources.txt")) as fh:
+        for line in fh:
+            m = re.match(r"^(k_\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+) \|", line)
+            if m:
+                rows[m.group(1)] = tuple(int(x) for x in m.groups()[1:])
+    assert len(rows) >= 60
+    for kernel, r in compiled.items():
+        want = (r["vgpr"], r["sgpr"], r["waves_per_simd"], r["vgpr_spills"], r["sgpr_spills"], r["scratch_bytes"])
+        assert rows.get(kernel[:78]) == want, (kernel, rows.get(kernel[:78]), want)

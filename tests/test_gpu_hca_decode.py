@@ -358,6 +358,38 @@ def test_device_floats_vs_oracle(cc, ch, q, v3):
     assert good >= 2
 
 
+@pytest.mark.parametrize("ch,q,v3", [(1, 1, False), (2, 1, False), (2, 3, False), (4, 2, False), (6, 1, False), (8, 3, False), (3, 1, False), (5, 2, False), (2, 1, True), (6, 2, True)])
+def test_pcm_of_the_shipped_instances_is_the_clamp_of_the_validation_floats(cc, ch, q, v3):
+    """The floats are stored by the `FLT = true` instances of the transform kernels (cri_job_run_floats), the shipped run uses the
+    `FLT = false` ones: same arithmetic, different kernels.  Here both run on the same streams: the shipped run's WAVs equal the
+    validation run's byte for byte, and their samples are (int)(f * 32768) of the validation run's floats, clamped to int16
+    (hca.cpp:1987-1992 as the x86-64 build evaluates it), trimmed by the encoder delay."""
+    from pycricodecs_amd.batch import Job
+    items = []
+    for seed, n in ((60, 7000), (61, 1024), (62, 2500)):
+        h = O.hca_encode(synth.wav(seed + ch, n, ch, 48000), q)
+        items.append(hca_forge.forge_v3(h, 0) if v3 else h)
+    outs_v, status_v, (d_f, offs) = run_job_floats(Job.hca_decode(items), floats=True)
+    outs_s, status_s = run_job(Job.hca_decode(items))
+    fl = d_f.cpu().numpy()
+    good = 0
+    for i, h in enumerate(items):
+        assert status_s[i] == status_v[i], i
+        if status_s[i] != 0:                                   # (a forged v3.0 header on frames of another layout: rejected both ways)
+            continue
+        good += 1
+        assert bytes(outs_s[i]) == bytes(outs_v[i]), i
+        wav = bytes(outs_s[i])
+        at = wav.find(b"data") + 8
+        pcm = np.frombuffer(wav, dtype="<i2", offset=at)
+        delay, nch = int.from_bytes(h[20:22], "big"), h[12]
+        v = (fl[int(offs[i]):int(offs[i + 1])] * np.float32(32768.0)).astype(np.float64)
+        qv = np.where(np.isfinite(v) & (v > -2147483904.0) & (v < 2147483648.0), np.trunc(v), -2147483648.0)
+        qv = np.clip(qv, -32768, 32767).astype(np.int16)
+        assert np.array_equal(qv[delay * nch:delay * nch + pcm.size], pcm), i
+    assert good >= 2
+
+
 def test_device_floats_random_frames(cc):
     """random-byte frames (saturating samples, escape codes, reads past the frame end): the floats agree bit for bit too"""
     from pycricodecs_amd.batch import Job
