@@ -822,7 +822,9 @@ def _dec_entry(r, workload, extra=None):
     e = {"workload": workload, "frames_per_s": round(r["units"] / r["dt"], 1), "ms_per_step": round(r["dt"] * 1e3, 3), "frames": r["units"],
          "channel_frames_per_s": round(r["units"] * r["channels"] / r["dt"], 1),
          "frac_end_to_end": round(r["alg_bytes"] / r["dt"] / 1e9 / HBM_PEAK_GBPS, 5),
-         "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "transform_kernel": r["job"].dominant_kernel, "record_forms": census_text(r["census"]),
+         "kernel_ms": {k: round(v, 3) for k, v in r["kernel_ms"].items()}, "transform_kernel": r["job"].dominant_kernel,
+         # the transform instance of every format group (cri_hca_group_info.transform_form): 0 generic, 1 general, 2 / 3 / 4 in-lane plain / joint / noise fill, | 8 wide
+         "transform_forms": r["job"].transform_forms(), "record_forms": census_text(r["census"]),
          "verified_items": r["verified"]["items"]}
     e.update(extra or {})
     r.pop("job", None)

@@ -140,6 +140,9 @@ class FakeJob:
     def record_census(self, d_scratch):
         return {"frames": self.units, "narrow": self.units}
 
+    def transform_forms(self):
+        return [2]
+
     def split(self, blob):
         return [blob[int(self.output_offsets[i]):int(self.output_offsets[i]) + int(self.item_sizes[i])] for i in range(self.n)]
 
