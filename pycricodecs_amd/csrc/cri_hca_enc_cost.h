@@ -29,6 +29,7 @@ __device__ __forceinline__ int enc_band_cost(uint2 row, uint32_t cl0, uint32_t c
 // The same for the rate loop's search steps, which only want the SUM over many bands: `acc` plus the row's second word as it is plus
 // the two counts -- the low 20 bits of a sum of these are the bits (the resolution / anomaly fields above them add up to junk that
 // never carries downwards).  Six instructions a band: two adds, two ands, two counts that accumulate.
+#ifdef __HIPCC__                 // (gfx950 instructions by name: not part of the host-side enumeration of this header, tests/shim/device_fn_host.cpp)
 __device__ __forceinline__ uint32_t enc_band_cost_raw(uint2 row, uint32_t cl0, uint32_t cl1, uint32_t acc) {
     // (v_bcnt_u32_b32 adds its second operand: written out, because the compiler counts into a fresh register and adds afterwards)
     uint32_t r;
@@ -36,6 +37,7 @@ __device__ __forceinline__ uint32_t enc_band_cost_raw(uint2 row, uint32_t cl0, u
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"((cl1 + row.x) & 0x10101010u), "v"(r));
     return acc;
 }
+#endif
 #define ENC_BITS_MASK 0xFFFFFu
 
 }  // namespace cri
