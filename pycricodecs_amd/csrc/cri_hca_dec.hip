@@ -23,6 +23,7 @@
 #include <algorithm>
 #include "cri_kernels.h"
 #include "cri_device.h"
+#include "cri_bits.h"
 #include "../../include/cricodecs_hip.h"
 
 #define CRI_TABLE_QUAL static __device__ const
@@ -37,16 +38,7 @@ namespace cri {
 // bytes at a time and checksums and deciphers the four words on their way into the lane's LDS ring (feed_land), so the
 // deciphered words never exist in HBM.
 //
-// CRC-16 (poly 0x8005, init 0, MSB first; hca.cpp:186-211) without a table and 32 message bits per step.  The frame is valid
-// iff its polynomial M(x) (CRC field included) is divisible by P = x^16 + x^15 + x^2 + 1 = (x + 1)(x^15 + x + 1):
-//   modulo x + 1          the remainder is the parity of M: one xor per word, one popcount at the end;
-//   modulo Q = x^15+x+1   x^15 = x + 1, hence x^32 = (x^15)^2 x^2 = (x^2 + 1) x^2 = x^4 + x^2: appending a word W to a running
-//                         value R gives T = W ^ R<<4 ^ R<<2, and one fold of T's bits from 15 up (T>>15 times x + 1) brings it
-//                         back under 18 bits.  R is only reduced completely at the end.
-// (the checksum is over the bytes as stored, before the decipher.)
-__device__ __forceinline__ uint32_t crcq_fold(uint32_t t) { const uint32_t h = t >> 15; return (t & 0x7FFFu) ^ h ^ (h << 1); }
-__device__ __forceinline__ uint32_t crcq_word(uint32_t r, uint32_t w_be) { return crcq_fold(w_be ^ (r << 4) ^ (r << 2)); }
-__device__ __forceinline__ uint32_t crcq_byte(uint32_t r, uint32_t b) { return crcq_fold((r << 8) ^ b); }   // x^8 needs no reduction: r < 2^18
+// (the checksum arithmetic -- CRC-16 without a table, 32 message bits per step -- is in cri_bits.h: crcq_word / crcq_byte / crcq_fold)
 
 // Format parameters held in registers (scalar) for the whole kernel: reading them through the HcaFormat pointer inside the
 // loops would turn every use into a memory load.
@@ -787,15 +779,7 @@ __device__ __forceinline__ uint32_t band_resolution(const Fmt& F, const uint8_t*
     return res > F.max_res ? F.max_res : (res < F.min_res ? F.min_res : res);
 }
 
-// n steps of the decoder's generator r' = 0x343FD r + 0x269EC3 (hca.cpp:1616) in O(log n): affine maps composed by squaring
-__device__ __forceinline__ uint32_t lcg_jump(uint32_t r, uint32_t n) {
-    uint32_t am = 0x343FDu, ac = 0x269EC3u, rm = 1, rc = 0;
-    while (n) {
-        if (n & 1) { rm *= am; rc = rc * am + ac; }
-        ac = (am + 1) * ac; am *= am; n >>= 1;
-    }
-    return rm * r + rc;
-}
+// (the generator's O(log n) jump-ahead, lcg_jump, is in cri_bits.h)
 
 // noise / valid band lists of one frame and channel (the `noises` array of hca.cpp:1489-1497), two bands per lane.
 // Returns the draws one subframe of this channel consumes (noise_count, or 0 when reconstruct_noise returns early).

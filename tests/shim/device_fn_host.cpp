@@ -107,3 +107,36 @@ extern "C" int host_enc_band_cost(const uint8_t* tables, uint32_t first, uint32_
     *cases = n.load(); *mismatches = bad.load();
     return 0;
 }
+
+// ---- cri_bits.h: the frame intake's table-free CRC-16 and the noise generator's jump-ahead
+#include "../../pycricodecs_amd/csrc/cri_bits.h"
+
+// the parse's acceptance rule (cri_hca_dec.hip, feed_land + the check behind the last block): words of the frame big-endian through
+// crcq_word, a tail of single bytes through crcq_byte, parity of everything; valid iff the folded remainder is 0 and the parity even.
+// Returns 1 = accepted, 0 = rejected.
+extern "C" int host_crc_accepts(const uint8_t* msg, size_t len) {
+    uint32_t r = 0, par = 0;
+    size_t i = 0;
+    for (; i + 4 <= len; i += 4) {
+        const uint32_t w_be = (uint32_t)msg[i] << 24 | (uint32_t)msg[i + 1] << 16 | (uint32_t)msg[i + 2] << 8 | msg[i + 3];
+        r = cri::crcq_word(r, w_be);
+        par ^= w_be;
+    }
+    for (; i < len; i++) { r = cri::crcq_byte(r, msg[i]); par ^= msg[i]; }
+    return cri::crcq_fold(r) == 0 && (__builtin_popcount(par) & 1) == 0;
+}
+
+// lcg_jump(r, n) against n single steps of hca.cpp:1616, for n = 0 .. n_max from `seeds` start values; and the group law on large jumps
+extern "C" unsigned long long host_lcg_jump_mismatches(uint32_t seeds, uint32_t n_max) {
+    unsigned long long bad = 0;
+    for (uint32_t s = 0; s < seeds; s++) {
+        uint32_t r0 = s * 2654435761u + 1u, r = r0;
+        for (uint32_t n = 0; n <= n_max; n++) {
+            if (cri::lcg_jump(r0, n) != r) bad++;
+            r = r * 0x343FDu + 0x269EC3u;
+        }
+        const uint32_t a = s * 40503u + 12345u, b = 0xFFFFFFFFu - s * 977u;          // (a + b wraps: the generator's period divides 2^32)
+        if (cri::lcg_jump(cri::lcg_jump(r0, a), b) != cri::lcg_jump(r0, a + b)) bad++;
+    }
+    return bad;
+}
