@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # CRI_TEST_HOSTWAVE=1 (tests/test_hostwave.py, never a GPU box): the `-m gpu` parity tests on the emulated build of the library
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hostwave"))
+    import mode
+    mode.enable()
 
 
 @pytest.fixture

@@ -358,7 +358,7 @@ def test_device_floats_vs_oracle(cc, ch, q, v3):
     assert good >= 2
 
 
-@pytest.mark.parametrize("ch,q,v3", [(1, 1, False), (2, 1, False), (2, 3, False), (4, 2, False), (6, 1, False), (8, 3, False), (3, 1, False), (5, 2, False), (2, 1, True), (6, 2, True)])
+@pytest.mark.parametrize("ch,q,v3", [(1, 1, False), (2, 1, False), (2, 3, False), (4, 2, False), (6, 1, False), (8, 3, False), (3, 1, False), (5, 2, False), (2, 1, True), (6, 1, True), (6, 2, True)])
 def test_pcm_of_the_shipped_instances_is_the_clamp_of_the_validation_floats(cc, ch, q, v3):
     """The floats are stored by the `FLT = true` instances of the transform kernels (cri_job_run_floats), the shipped run uses the
     `FLT = false` ones: same arithmetic, different kernels.  Here both run on the same streams: the shipped run's WAVs equal the
@@ -373,10 +373,16 @@ def test_pcm_of_the_shipped_instances_is_the_clamp_of_the_validation_floats(cc, 
     outs_s, status_s = run_job(Job.hca_decode(items))
     fl = d_f.cpu().numpy()
     good = 0
+    accepted = 0
     for i, h in enumerate(items):
         assert status_s[i] == status_v[i], i
-        if status_s[i] != 0:                                   # (a forged v3.0 header on frames of another layout: rejected both ways)
+        try:
+            O.hca_decode(h)
+            accepted += 1
+        except O.OracleError:                                  # (a forged v3.0 header on frames of another layout -- all of 6 ch / quality 2: rejected by every side)
+            assert status_s[i] != 0, i
             continue
+        assert status_s[i] == 0, i
         good += 1
         assert bytes(outs_s[i]) == bytes(outs_v[i]), i
         wav = bytes(outs_s[i])
@@ -387,7 +393,7 @@ def test_pcm_of_the_shipped_instances_is_the_clamp_of_the_validation_floats(cc, 
         qv = np.where(np.isfinite(v) & (v > -2147483904.0) & (v < 2147483648.0), np.trunc(v), -2147483648.0)
         qv = np.clip(qv, -32768, 32767).astype(np.int16)
         assert np.array_equal(qv[delay * nch:delay * nch + pcm.size], pcm), i
-    assert good >= 2
+    assert good == accepted and (good >= 2 or (ch, q, v3) == (6, 2, True))
 
 
 def test_device_floats_random_frames(cc):

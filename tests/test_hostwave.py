@@ -1,0 +1,117 @@
+"""The `-m gpu` parity tests, run WITHOUT a GPU against the product's own kernel sources under a lockstep wave64 emulation (tests/hostwave/).
+
+tests/hostwave/build.py compiles pycricodecs_amd/csrc/*.hip|cpp for x86-64 (clang, -ffp-contract=off) against a stand-in for
+<hip/hip_runtime.h>: one fiber per lane, cross-lane instructions (DPP, ds_swizzle, ds_bpermute, readlane, ballots) as rendezvous of a
+wave's fibers, LDS as a per-workgroup arena with a guard page behind the launch's dynamic size, device memory = host memory.  The only
+rewriting of the sources is tests/hostwave/translate.py's: inline gfx950 assembly to the same single operation in C++, `__shared__`
+declarations to references into the arena.  The result is the same C ABI under the same file name; CRICODECS_LIB_DIR points the unchanged
+Python package at it and the unchanged tests/test_gpu_*.py compare it with the pinned oracle and the golden vectors.
+
+What this holds the kernels to: indices, bit work, cross-lane patterns, LDS layouts and sizes, float operation order -- on every case
+the GPU suite has.  What only the GPU run can show: the compiler's gfx950 code, timing, the runtime (graphs, streams).  It is test
+infrastructure: nothing under pycricodecs_amd/ includes, links or loads it, and on a GPU box the same tests run on the HIP library.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HW = os.path.join(ROOT, "tests", "hostwave")
+CXX = os.environ.get("HOSTWAVE_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+sys.path.insert(0, HW)
+
+# what needs a real device or the real runtime (stream capture, a second process on the GPU, seconds of sustained random banks)
+NEEDS_DEVICE = [
+    "tests/test_gpu_boundary.py::test_job_run_captured_in_a_hip_graph",
+    "tests/test_gpu_boundary.py::test_a_failed_launch_is_reported_also_while_capturing",
+    "tests/test_gpu_boundary.py::test_job_destroyed_with_work_in_flight",
+    "tests/test_gpu_boundary.py::test_randomised_parity_soak_for_a_few_seconds",     # (run below with its own budget)
+    "tests/test_gpu_multirank.py",
+]
+
+
+@pytest.fixture(scope="module")
+def emulated_lib():
+    if not os.path.exists(CXX):
+        pytest.skip("no clang++ at %s" % CXX)
+    r = subprocess.run([sys.executable, os.path.join(HW, "build.py")], cwd=ROOT, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lib = os.path.join(HW, "lib")
+    assert os.path.exists(os.path.join(lib, "libcricodecs_hip.so")) and os.path.exists(os.path.join(lib, "libcricodecs_hip_testing.so"))
+    return lib
+
+
+def _env(lib):
+    env = dict(os.environ)
+    env.update(CRI_TEST_HOSTWAVE="1", CRICODECS_LIB_DIR=lib, CRICODECS_NO_REBUILD="1", HOSTWAVE_THREADS="4")
+    return env
+
+
+def test_emulated_library_is_the_trees_sources(emulated_lib):
+    """Same build id as the tree (the binding refuses anything else), same exported C ABI as the HIP library's header."""
+    from pycricodecs_amd import build as B
+    for name in ("libcricodecs_hip.so", "libcricodecs_hip_testing.so"):
+        assert B.embedded_id(os.path.join(emulated_lib, name)) == B.source_id()
+    with open(os.path.join(ROOT, "include", "cricodecs_hip.h")) as f:
+        declared = set(re.findall(r"\b(cri_[a-z0-9_]+)\s*\(", f.read()))
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(emulated_lib, "libcricodecs_hip.so")], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (cri_[a-z0-9_]+)", out))
+    assert declared and declared <= exported, sorted(declared - exported)
+
+
+def test_gpu_parity_suite_on_the_emulated_kernels(emulated_lib):
+    """Every `-m gpu` test of tests/test_gpu_{adx,hca_decode,hca_encode,wav,boundary,containers}.py except the handful that need the real
+    runtime: all pass on the emulated kernels -- the same assertions, oracle and golden vectors the GPU box's run uses."""
+    files = ["tests/test_gpu_%s.py" % n for n in ("adx", "hca_decode", "hca_encode", "wav", "boundary", "containers")]
+    cmd = [sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "900", "-n", "6"]
+    for d in NEEDS_DEVICE:
+        cmd += ["--deselect", d]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(emulated_lib), capture_output=True, text=True, timeout=3000)
+    tail = r.stdout[-4000:] + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 430, tail
+    assert " failed" not in r.stdout and " error" not in r.stdout, tail
+
+
+def test_randomised_parity_soak_on_the_emulated_kernels(emulated_lib):
+    """tools/parity_soak.py (random banks of WAVs through every batch job and the single-file calls, every output against the oracle,
+    corrupted and forged streams among them) for twenty seconds on the emulated kernels: no mismatch."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_soak.py"), "20", "606", "0"], cwd=ROOT, env=_env(emulated_lib), capture_output=True, text=True, timeout=1200)
+    tail = "\n".join(r.stdout.splitlines()[-12:]) + r.stderr[-2000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) comparisons.*?(\d+) mismatch", r.stdout.splitlines()[-1] if r.stdout else "")
+    assert "mismatches 0" in r.stdout or (m and int(m.group(2)) == 0), tail
+
+
+def test_translator_knows_every_instruction_it_meets_and_refuses_the_rest():
+    """tests/hostwave/translate.py: the inline assembly of the sources maps to single C++ operations with the modifiers decoded
+    (op_sel / neg_lo / neg_hi of the packed instructions, the DPP controls); an instruction it does not know stops the build."""
+    import translate as T
+    t = lambda s: T.translate_line(s, "x:1")
+    assert t('asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));') == "r = hw::v_pk<'+'>(a, b, 0, 3, 0, 2);"
+    assert t('asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(u), "v"(tw));') == "q = hw::v_pk<'*'>(u, tw, 3, 1, 0, 0);"
+    assert t('asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(p));') == "r = hw::v_pk<'+'>(p, p, 2, 2, 0, 2);"
+    assert "0x128" in t('asm("v_mul_f32_dpp %0, %1, -%2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));') and "(-(c))" in \
+        t('asm("v_mul_f32_dpp %0, %1, -%2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(v), "v"(c));')
+    assert t('x = 1; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s) : "v"(a), "v"(f(b, c)), "v"(p >> 12)); y = 2;') == "x = 1; s = hw::v_mad_i32_i24(a, f(b, c), p >> 12); y = 2;"
+    assert t('if (q) asm volatile("ds_add_u32 %0, %1\\n\\ts_waitcnt lgkmcnt(0)" :: "v"(lds_address(&s[i])), "v"(raw) : "memory");') == "if (q) hw::ds_add_u32(lds_address(&s[i]), raw);"
+    assert t('asm volatile("" : "+v"(lane));') == "((void)0);"
+    assert t('// asm("v_nop") in a comment stays') == '// asm("v_nop") in a comment stays'
+    assert t("    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];") == "    uint8_t* const smem = (uint8_t*)hw::dyn_lds();"
+    assert "hw::static_lds(sizeof(xl_lds_t), 16" in t("    __shared__ __attribute__((aligned(16))) int32_t xl[64];")
+    with pytest.raises(SystemExit):
+        t('asm("v_dot2_f32_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));')
+    # and every source of the product translates line for line
+    csrc = os.path.join(ROOT, "pycricodecs_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(csrc, f)) as fh:
+                src = fh.read()
+            out = T.translate(src, f)
+            assert out.count("\n") == src.count("\n"), f
+            code = "\n".join(l[:T._comment_start(l)] for l in out.split("\n"))
+            assert not re.search(r"\basm\s*(volatile\s*)?\(", code) and "__shared__" not in code, f

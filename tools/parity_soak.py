@@ -23,6 +23,9 @@ import numpy as np
 import oracle_lib as O
 from pycricodecs_amd import synth, CriCodecs as cc, _capi
 from pycricodecs_amd.batch import Job
+sys.path.insert(0, "tests/hostwave")
+import mode                                    # (CRI_TEST_HOSTWAVE=1: the same soak on the emulated build of the library, tests/test_hostwave.py)
+mode.enable()
 
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
