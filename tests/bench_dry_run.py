@@ -16,7 +16,10 @@ sys.path.insert(0, HERE)
 def main():
     import bench
     import fake_device
-    fake_device.install(bench)
+    if os.environ.get("CRI_TEST_HOSTWAVE") == "1":             # the real batch.Job on the emulated kernels (tests/hostwave), not the oracle-backed double
+        fake_device.install_emulated(bench)
+    else:
+        fake_device.install(bench)
 
     def relaunch(args):                                        # bench.relaunch_under_torchrun, on this wrapper
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

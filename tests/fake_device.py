@@ -191,3 +191,23 @@ def install(bench, monkeypatch=None):
     setattr_(bench, "sec_host_paths", lambda args, D, out: out.update(hca_decode_host={"skipped": "dry run"}, adx_decode_host={"skipped": "dry run"}))
     setattr_(bench, "sec_usm", lambda args, D, out: out.update(sfa_pack={"skipped": "dry run"}, usm_demux={"skipped": "dry run"}))
     setattr_(bench, "single_call_latency", lambda seconds: {"skipped": "dry run"})
+
+
+def install_emulated(bench, monkeypatch=None):
+    """The other kind of dry run (CRI_TEST_HOSTWAVE=1, tests/test_hostwave.py): bench.py on the REAL batch.Job over the EMULATED build of the
+    library (tests/hostwave: the product's kernel sources on the CPU) -- every call of the C ABI the script makes, the library's own host
+    paths, the event read-out and the job's own figures (units, algorithmic bytes, dominant kernel) are the real ones; only the device
+    layer of torch is replaced.  Timings mean nothing here either."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostwave"))
+    import mode
+    assert mode.enable(), "CRI_TEST_HOSTWAVE=1 and CRICODECS_LIB_DIR=tests/hostwave/lib are the caller's to set"
+
+    def setattr_(obj, name, value):
+        if monkeypatch is not None:
+            monkeypatch.setattr(obj, name, value, raising=False)
+        else:
+            setattr(obj, name, value)
+    setattr_(bench, "Dist", make_dist(bench))
+    setattr_(torch.cuda, "empty_cache", lambda *a, **k: None)

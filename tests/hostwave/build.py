@@ -102,5 +102,20 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_selftest():
+    """tests/hostwave/selftest.cpp (the emulator's own instructions against their closed forms) -> build/selftest"""
+    os.makedirs(WORK, exist_ok=True)
+    with open(os.path.join(HERE, "selftest.cpp")) as f:
+        text = T.translate(f.read(), "selftest.cpp")
+    src = os.path.join(WORK, "selftest_translated.cpp")
+    with open(src, "w") as f:
+        f.write(text)
+    out = os.path.join(WORK, "selftest")
+    subprocess.run([CXX] + [f for f in FLAGS if f != "-fPIC"] + [src, os.path.join(HERE, "hostwave.cpp"), "-o", out], check=True)
+    return out
+
+
 if __name__ == "__main__":
+    if "--selftest" in sys.argv:
+        sys.exit(subprocess.run([build_selftest()]).returncode)
     build(force="--force" in sys.argv)

@@ -50,6 +50,22 @@ def _env(lib):
     return env
 
 
+def test_emulator_instructions_against_their_closed_forms():
+    """tests/hostwave/selftest.cpp: every DPP control the emulator models (quad permutations, row shifts / rotations / mirrors /
+    broadcasts with row and bank masks and bound_ctrl), ds_swizzle's bit and quad modes, ds_bpermute, readlane, ballots, mbcnt, HIP's
+    shuffles with widths, v_perm / alignbit / bfe / sad / mul24 / med3 / cvt_pk, exchanges inside a divergent branch, barriers between
+    four waves with two of them leaving early, LDS carving -- and a read one byte past a launch's dynamic LDS dies on the guard page
+    with a message that says so."""
+    if not os.path.exists(CXX):
+        pytest.skip("no clang++ at %s" % CXX)
+    import build as HB
+    exe = HB.build_selftest()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+    r = subprocess.run([exe, "overrun"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "LDS byte 4096 of a launch with 4096 bytes of dynamic LDS" in r.stderr, r.stdout + r.stderr
+
+
 def test_emulated_library_is_the_trees_sources(emulated_lib):
     """Same build id as the tree (the binding refuses anything else), same exported C ABI as the HIP library's header."""
     from pycricodecs_amd import build as B
@@ -85,6 +101,59 @@ def test_randomised_parity_soak_on_the_emulated_kernels(emulated_lib):
     assert r.returncode == 0, tail
     m = re.search(r"(\d+) comparisons.*?(\d+) mismatch", r.stdout.splitlines()[-1] if r.stdout else "")
     assert "mismatches 0" in r.stdout or (m and int(m.group(2)) == 0), tail
+
+
+def _bench(lib, tmp_path, argv, timeout=1500):
+    import json
+    env = _env(lib)
+    env["BENCH_DETAIL_DIR"] = str(tmp_path)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_run.py")] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [x for x in r.stdout.split("\n") if x.strip().startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-1500:]
+    with open(os.path.join(str(tmp_path), "bench_detail.json")) as f:
+        return json.loads(lines[0]), json.load(f)
+
+
+def test_bench_default_run_on_the_emulated_kernels(emulated_lib, tmp_path):
+    """bench.py's default invocation at toy sizes with the REAL batch.Job over the emulated library (tests/bench_dry_run.py under
+    CRI_TEST_HOSTWAVE=1; tests/test_bench_dry_run.py runs the same flow on an oracle-backed double of the Job): the headline with its
+    event read-out and record census, the sustained loop, every secondary at both sizes -- the library's own host paths, the USM audio
+    layer and the five single-file calls among them --, the other BASELINE configurations, the reference on the host's cores; every
+    output of every job verified against the oracle; one line of <= 4 KB."""
+    line, detail = _bench(emulated_lib, tmp_path, ["--streams", "6", "--unique", "2", "--seconds", "0.3", "--steps", "2", "--warmup", "1", "--secondary-streams", "4",
+                                                    "--awb-clips", "24", "--awb-durations", "6", "--config-awb-clips", "24", "--config-items-scale", "0.0005",
+                                                    "--config-seconds-scale", "0.02", "--cpu-seconds", "0.4", "--config-cpu-seconds", "0.4", "--sustain", "0.2"])
+    assert line["value"] > 0 and line["config"]["verified"]["items"] == 6 and line["cpu_baseline"]["value"] > 0
+    r = line["roofline"]
+    assert set(r["kernel_ms_per_step"]) == {"k_hca_parse", "k_hca_transform"} and r["dominant_kernel"]["name"] in r["kernel_ms_per_step"]
+    assert r["frac"] == r["frac_end_to_end"] and r["algorithmic_bytes_per_launch"] == 6 * 15 * (682 + 4096)
+    sec = detail["secondary"]
+    forms = {"hca_decode_middle": [3], "hca_decode_6ch": [10], "hca_decode_v3_noise_fill": [4], "hca_decode_6ch_v3_noise_fill": [12], "hca_decode_6ch_middle": [11], "hca_decode_sparse_spectra": [2]}
+    for k, f in forms.items():                                 # the transform instance each secondary takes (cri_job_hca_groups), verified items at both sizes
+        assert sec[k]["transform_forms"] == f and sec[k]["verified_items"] > 0 and sec[k + "_full"]["verified_items"] > 0, k
+    assert sec["hca_decode_sparse_spectra"]["record_forms"].startswith("0 of 60 frames crossed scratch as int8")      # sparse material: int16 lines
+    assert sec["hca_decode_host"]["verified_items"] > 0 and sec["adx_decode_host"]["verified_items"] > 0 and sec["usm_demux"]["verified_items"] > 0
+    assert sec["hca_encode"]["verified_items"] > 0 and sec["adx_roundtrip"]["verified_items"] > 0 and sec["awb_mixed_decode"]["verified"]["items"] == 24
+    assert all(sec["single_call_ms"][k][0] > 0 for k in ("AdxDecode", "AdxEncode", "HcaDecode", "HcaEncode", "HcaCrypt"))
+    cfgs = sec["baseline_configs"]
+    assert set(k.split(" ")[0] for k in cfgs) == {"configs[1]", "configs[3]", "configs[4]"} and all(v["verified"]["items"] > 0 for v in cfgs.values())
+
+
+@pytest.mark.parametrize("workload", ["hca_encode", "adx_roundtrip"])
+def test_bench_workloads_on_the_emulated_kernels(emulated_lib, tmp_path, workload):
+    line, _ = _bench(emulated_lib, tmp_path, ["--workload", workload, "--no-cpu", "--no-secondary", "--streams", "6", "--unique", "2", "--seconds", "0.3", "--steps", "1", "--warmup", "0"])
+    assert line["config"]["verified"]["items"] == (12 if workload == "adx_roundtrip" else 6) and line["value"] > 0
+
+
+def test_bench_two_rank_launcher_on_the_emulated_kernels(emulated_lib, tmp_path):
+    """bench.py --gpus 2 --workload awb_mixed --scaling strong: two ranks (gloo), each decoding its share of the bank on the emulated
+    kernels, gather_bytes_to_root, and the root's check of EVERY gathered item of both ranks against the oracle."""
+    line, _ = _bench(emulated_lib, tmp_path, ["--gpus", "2", "--workload", "awb_mixed", "--scaling", "strong", "--awb-clips", "40", "--awb-durations", "12", "--steps", "1", "--warmup", "1", "--no-cpu"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["gathered_items_verified_on_root"] == 40 and line["config"]["gathered_bytes_on_root"] > 0
 
 
 def test_translator_knows_every_instruction_it_meets_and_refuses_the_rest():
