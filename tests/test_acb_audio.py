@@ -94,6 +94,21 @@ def test_decode_of_the_whole_bank_in_one_job(tmp_path):
             assert bytes(payload[:len(item)]) == item
     a.extract(decode=True, key=KEY, dirname=str(tmp_path / "out"))
     assert sorted(os.listdir(tmp_path / "out")) == sorted(a.names(True))
-    # a wrong key is not an error in the reference (the checksum covers the enciphered bytes): the same wrong samples here
-    wrong = AcbAudio(bank, types).files(decode=True, key=KEY + 1)
-    assert bytes(wrong[0][1]) == O.hca_decode(items[0], KEY + 1, subkey) != O.hca_decode(items[0], KEY, subkey)
+    # a wrong key: the checksum covers the enciphered bytes, so the frames pass it and are parsed as garbage -- which the reference either
+    # rejects (a frame that does not parse: "incorrect key or unknown exception") or decodes to wrong samples.  The same here, key by key.
+    right = {n: O.hca_decode(items[n], KEY, subkey) for n in (0, 1, 4, 6)}
+    wrong_samples = refused = 0
+    for k in (KEY + 1, KEY + 2, KEY ^ 0xFFFF):
+        for n in (0, 1, 4, 6):
+            one = AcbAudio(bank, [t if i == n else 14 for i, t in enumerate(types)])      # only waveform n is decoded
+            try:
+                want = O.hca_decode(items[n], k, subkey)
+            except O.OracleError:
+                with pytest.raises(ValueError):
+                    one.files(decode=True, key=k)
+                refused += 1
+                continue
+            got_n = one.files(decode=True, key=k)[n][1]
+            assert bytes(got_n) == want != right[n], (n, hex(k))
+            wrong_samples += 1
+    assert wrong_samples >= 2 and refused >= 2

@@ -79,9 +79,10 @@ def test_emulated_library_is_the_trees_sources(emulated_lib):
 
 
 def test_gpu_parity_suite_on_the_emulated_kernels(emulated_lib):
-    """Every `-m gpu` test of tests/test_gpu_{adx,hca_decode,hca_encode,wav,boundary,containers}.py except the handful that need the real
-    runtime: all pass on the emulated kernels -- the same assertions, oracle and golden vectors the GPU box's run uses."""
-    files = ["tests/test_gpu_%s.py" % n for n in ("adx", "hca_decode", "hca_encode", "wav", "boundary", "containers")]
+    """Every `-m gpu` test of tests/ (test_gpu_{adx,hca_decode,hca_encode,wav,boundary,containers}.py, test_acb_audio.py, test_build_id.py)
+    except the handful that need the real runtime: all pass on the emulated kernels -- the same assertions, oracle and golden vectors the
+    GPU box's run uses."""
+    files = ["tests"]
     cmd = [sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "900", "-n", "6"]
     for d in NEEDS_DEVICE:
         cmd += ["--deselect", d]
