@@ -422,7 +422,12 @@ struct hw_stream { int id; };
 struct hw_event { std::chrono::steady_clock::time_point t; };
 
 extern "C" {
-hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255 + 256) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipMalloc(void** p, size_t n) {
+    const size_t sz = (n + 255 + 256) & ~(size_t)255;
+    *p = aligned_alloc(256, sz);
+    if (*p) memset(*p, 0xCD, sz);                  // device memory is not zero when it is handed out
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }

@@ -17,7 +17,9 @@ def enable():
     alloc = batch.Job.alloc
 
     def alloc_on_host(self, device="cuda:0", upload=True):
-        return alloc(self, "cpu", upload)
+        bufs = alloc(self, "cpu", upload)
+        bufs[2].fill_(0xCD)                        # scratch is `torch.empty` on the device: nothing may depend on what it held
+        return bufs
     batch.Job.alloc = alloc_on_host
     batch.Job._hostwave = True
 
