@@ -7,6 +7,30 @@ import os
 ON = os.environ.get("CRI_TEST_HOSTWAVE") == "1"
 
 
+_keep = []
+
+
+def guarded(nbytes, dtype):
+    """uint8 tensor of nbytes whose storage is fenced by PROT_NONE pages (never unmapped: test processes are short-lived)."""
+    import ctypes
+    import mmap
+    import torch
+    page = mmap.PAGESIZE
+    body = (nbytes + 63) // 64 * 64
+    total = (body + page - 1) // page * page + 2 * page
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mmap.restype = ctypes.c_void_p
+    libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    base = libc.mmap(None, total, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
+    assert base and base != ctypes.c_void_p(-1).value
+    assert libc.mprotect(base, page, 0) == 0 and libc.mprotect(base + total - page, page, 0) == 0
+    start = base + total - page - body
+    arr = (ctypes.c_uint8 * nbytes).from_address(start)
+    _keep.append(arr)
+    return torch.frombuffer(arr, dtype=dtype)
+
+
 def enable():
     if not ON:
         return False
@@ -17,9 +41,20 @@ def enable():
     alloc = batch.Job.alloc
 
     def alloc_on_host(self, device="cuda:0", upload=True):
-        bufs = alloc(self, "cpu", upload)
-        bufs[2].fill_(0xCD)                        # scratch is `torch.empty` on the device: nothing may depend on what it held
-        return bufs
+        if os.environ.get("HOSTWAVE_GUARD") != "1":
+            bufs = alloc(self, "cpu", upload)
+            bufs[2].fill_(0xCD)                    # scratch is `torch.empty` on the device: nothing may depend on what it held
+            return bufs
+        # HOSTWAVE_GUARD=1: every device buffer of the job between two inaccessible pages, its END (rounded up to 64 bytes) on the
+        # page boundary -- a kernel that reads or writes past a buffer (or before it) dies there, with the emulator's report
+        d_in = guarded(max(self.input_bytes, 1), torch.uint8)
+        if upload and self.input_bytes:
+            d_in.zero_()
+            self.upload(d_in)
+        d_out = guarded(max(self.output_bytes, 1), torch.uint8); d_out.zero_()
+        d_scratch = guarded(max(self.scratch_bytes, 1), torch.uint8); d_scratch.fill_(0xCD)
+        d_status = guarded(max(self.n, 1) * 4, torch.uint8).view(torch.int32); d_status.zero_()
+        return d_in, d_out, d_scratch, d_status
     batch.Job.alloc = alloc_on_host
     batch.Job._hostwave = True
 

@@ -46,7 +46,8 @@ def emulated_lib():
 
 def _env(lib):
     env = dict(os.environ)
-    env.update(CRI_TEST_HOSTWAVE="1", CRICODECS_LIB_DIR=lib, CRICODECS_NO_REBUILD="1", HOSTWAVE_THREADS="4")
+    # HOSTWAVE_GUARD: every device buffer a test hands to a job lies between two inaccessible pages, scratch is poisoned (tests/hostwave/mode.py)
+    env.update(CRI_TEST_HOSTWAVE="1", CRICODECS_LIB_DIR=lib, CRICODECS_NO_REBUILD="1", HOSTWAVE_THREADS="4", HOSTWAVE_GUARD="1")
     return env
 
 
@@ -81,7 +82,8 @@ def test_emulated_library_is_the_trees_sources(emulated_lib):
 def test_gpu_parity_suite_on_the_emulated_kernels(emulated_lib):
     """Every `-m gpu` test of tests/ (test_gpu_{adx,hca_decode,hca_encode,wav,boundary,containers}.py, test_acb_audio.py, test_build_id.py)
     except the handful that need the real runtime: all pass on the emulated kernels -- the same assertions, oracle and golden vectors the
-    GPU box's run uses."""
+    GPU box's run uses -- with every device buffer fenced by inaccessible pages, scratch and device allocations poisoned, and LDS ending at
+    a guard page: no kernel touches memory outside its buffers or depends on what memory held."""
     files = ["tests"]
     cmd = [sys.executable, "-m", "pytest"] + files + ["-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "900", "-n", "6"]
     for d in NEEDS_DEVICE:
