@@ -736,6 +736,24 @@ __global__ __launch_bounds__(64, 4) void k_hca_parse(HcaDecArgs a) {
         uint32_t* tail = (uint32_t*)(rec + HCA_REC_TAIL(C));
         tail[0] = packed; tail[1] = (uint32_t)status; tail[2] = flags | (narrow ? HCA_REC_NARROW : 0u); tail[3] = draws;      // k_hca_noise_scan turns tail[3] into a prefix
     }
+    // The frames' code descriptions also go into their RECORDS (HCA_REC_DESC) for the in-lane transform: this lane's own stores of the
+    // scalefactor pass come back (four blocks = 16 words a time) and leave transposed like the scalefactors, 64 B per frame and flush.
+    // (here, after the last block, where nothing of the parse is live any more: placed between the scalefactor passes and the spectra
+    //  loop the same lines cost three more spilled registers.)
+    if (hca_transform_form(a) >= HCA_TR_INLANE_PLAIN) {
+        for (uint32_t c = 0; c < C; c++) {
+#pragma unroll
+            for (uint32_t half = 0; half < 2; half++) {
+#pragma unroll
+                for (uint32_t q4 = 0; q4 < 4; q4++) {
+                    const uint4 mv = metag[(c * 8 + half * 4 + q4) * 64];
+                    ostage[(q4 * 4 + 0) * OST + lane] = mv.x; ostage[(q4 * 4 + 1) * OST + lane] = mv.y;
+                    ostage[(q4 * 4 + 2) * OST + lane] = mv.z; ostage[(q4 * 4 + 3) * OST + lane] = mv.w;
+                }
+                flush16(ostage, recq, rb16, nvalid, lane, HCA_REC_DESC(C, c) + half * 64, 16);
+            }
+        }
+    }
 }
 
 void launch_hca_parse(const HcaDecArgs& a, hipStream_t s) {
@@ -1685,8 +1703,6 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
             if (shared && (from_prev || tc == CRI_CH_PRIMARY)) ratio_mask |= 1u << r;
         }
     }
-    // this lane's two bands (2 * lane, 2 * lane + 1) in a frame's code descriptions: [tile][channel][block of 16 bands][frame 64][16 B]
-    const uint8_t* desc0 = a.scratch + a.resg_offset + (lane >> 3) * 1024 + (lane & 7) * 2;
     const bool dword_ok = ((st.delay * CT * 2) & 3) == 0;
     uint8_t* dst = a.out + st.dst_offset;
 
@@ -1718,9 +1734,9 @@ __global__ __launch_bounds__(WIDE ? 192 : 64, JOINT ? CRI_JOINT_WAVES : CRI_PLAI
 #pragma unroll
         for (uint32_t v = 0; v < 4; v++) {
             bool live; const uint32_t f = unit_frame(v, s, live);
-            const uint32_t gf = st.first_frame + f;
-            const uint32_t d2 = *(const uint16_t*)(desc0 + (((uint64_t)(gf >> 6) * CT + chan_of(v)) * 8 * 64 + (gf & 63)) * 16);
-            p.sf2[v] = ((const uint16_t*)(rec0 + (uint64_t)f * F.record_bytes + HCA_REC_SF(CT, chan_of(v))))[lane] | d2 << 16;      // scalefactors | descriptions << 16
+            const uint8_t* rf = rec0 + (uint64_t)f * F.record_bytes;
+            const uint32_t d2 = ((const uint16_t*)(rf + HCA_REC_DESC(CT, chan_of(v))))[lane];      // this lane's two bands (2 * lane, 2 * lane + 1)
+            p.sf2[v] = ((const uint16_t*)(rf + HCA_REC_SF(CT, chan_of(v))))[lane] | d2 << 16;      // scalefactors | descriptions << 16
         }
         return p;
     };
@@ -2090,7 +2106,7 @@ size_t hca_transform_lds_bytes(uint32_t C, bool plain) {
 }
 
 // Which transform kernel a format group takes (also reported to callers: cri_job_hca_groups)
-uint32_t hca_transform_form(const HcaDecArgs& a) {
+__host__ __device__ uint32_t hca_transform_form(const HcaDecArgs& a) {
     const bool in_regs = a.channels <= 8 && (a.plain || a.inlane || a.channels == 1 || a.channels == 2 || a.channels == 4 || ((a.channels == 6 || a.channels == 8) && a.pairs_even));
     if (!in_regs) return HCA_TR_GENERIC;
     const bool small = a.channels == 1 || a.channels == 2 || a.channels == 4;

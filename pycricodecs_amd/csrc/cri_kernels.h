@@ -42,7 +42,7 @@ struct HcaDecArgs {
 // transform kernel of a format group: k_hca_transform_generic, k_hca_transform<.> (general, in registers), or an instance of the
 // in-lane kernel k_hca_transform_plain (plain / joint stereo + HFR / + v3.0 noise fill), | HCA_TR_WIDE = a wave per four channels
 enum { HCA_TR_GENERIC = 0, HCA_TR_GENERAL = 1, HCA_TR_INLANE_PLAIN = 2, HCA_TR_INLANE_JOINT = 3, HCA_TR_INLANE_NOISE = 4, HCA_TR_WIDE = 8 };
-uint32_t hca_transform_form(const HcaDecArgs& a);
+__host__ __device__ uint32_t hca_transform_form(const HcaDecArgs& a);
 size_t hca_parse_lds_bytes(uint32_t n_cipher);
 void launch_hca_parse(const HcaDecArgs& a, hipStream_t s);
 void launch_hca_transform(const HcaDecArgs& a, hipStream_t s);

@@ -47,15 +47,20 @@ struct HcaStream {
 // Between k_hca_parse and the transform kernels a frame's unpacked state travels through scratch in two places.
 //
 // 1. Frame record (per frame, consecutive in frame order within a format group; HcaStream::scratch_offset = the stream's first):
-//      uint8 scalefactors[C][128] | uint8 intensity[C][8] | uint32 tail[4]
+//      uint8 scalefactors[C][128] | uint8 intensity[C][8] | uint32 tail[4] | (from the next 64-byte boundary) uint8 code descriptions[C][128]
 //      tail = { packed_noise_level, status (0 or CRI_ERR_HCA_FRAME), flags (bit c: channel c reuses intensity[1..7];
 //               HCA_REC_NARROW), generator draws (v3.0 noise fill; k_hca_noise_scan turns it into a prefix) }
+//      code descriptions = band_meta of every band (cri_hca_dec.hip), for formats the in-lane transform takes: the parse keeps them
+//      tile-major for its own eight passes over them (HcaDecArgs::resg_offset) and copies them here, so that a transform wave finds a
+//      frame's 128 bytes per channel in one line instead of sixteen 16-byte pieces of sixteen lines it shares with seven other frames
+//      (tools/traffic_census.py: 2.6 KB of lines per stereo frame for 0.33 KB used -> 0.4 KB)
 //    (an odd number of 64-byte lines: k_hca_parse stores the same 64 B of 16 consecutive records per instruction, and with an
 //     even line stride those would land on a fraction of the L2 channels)
-static inline uint32_t hca_record_bytes(uint32_t channels) { return ((((channels * (128u + 8u) + 16u) + 63u) >> 6) | 1u) << 6; }
 #define HCA_REC_SF(C, c) ((c) * 128u)
 #define HCA_REC_INT(C, c) ((C) * 128u + (c) * 8u)
 #define HCA_REC_TAIL(C) ((C) * 136u)
+#define HCA_REC_DESC(C, c) ((((C) * 136u + 16u + 63u) & ~63u) + (c) * 128u)
+static inline uint32_t hca_record_bytes(uint32_t channels) { return (((HCA_REC_DESC(channels, channels) + 63u) >> 6) | 1u) << 6; }
 #define HCA_REC_NARROW 0x40000000u   // tail flags: the frame's quantised lines are int8 and NEGATED (formats with HcaDecArgs::narrow
                                      // only: k_hca_parse -> k_hca_transform_plain)
 //

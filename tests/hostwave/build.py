@@ -38,7 +38,12 @@ def _key(paths, salt):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, traffic=False):
+    """traffic=True: the census build (tools/traffic_census.py) into lib_traffic/ -- the kernel files compiled with -fsanitize=thread and
+    linked against hostwave.cpp's own __tsan_* hooks (no sanitizer runtime); analysis only, not used by any test of parity."""
+    global OUT, WORK
+    if traffic:
+        OUT, WORK = os.path.join(HERE, "lib_traffic"), os.path.join(HERE, "build_traffic")
     os.makedirs(OUT, exist_ok=True)
     src_dir = os.path.join(WORK, "pkg", "csrc")
     os.makedirs(src_dir, exist_ok=True)
@@ -57,7 +62,10 @@ def build(force=False, verbose=True):
     deps = [os.path.join(src_dir, f) for f in names if f.endswith(".h")] + [os.path.join(HERE, "include", "hip", "hip_runtime.h")]
 
     def compile_one(src, obj, defines):
-        cmd = [CXX] + FLAGS + defines + ["-c", src, "-o", obj]
+        extra = []
+        if traffic:
+            extra = ["-DHOSTWAVE_TRAFFIC"] + (["-fsanitize=thread"] if src.endswith(".hip") else [])
+        cmd = [CXX] + FLAGS + extra + defines + ["-c", src, "-o", obj]
         key = _key([src] + deps, " ".join(cmd))
         try:
             if not force and open(obj + ".key").read() == key and os.path.exists(obj):
@@ -83,7 +91,7 @@ def build(force=False, verbose=True):
     prod = objs[1:1 + len(PB.SOURCES)]
     test = [o for o in prod if not o.endswith("cri_capi.o")] + objs[1 + len(PB.SOURCES):]
     for out, group in ((os.path.join(OUT, "libcricodecs_hip.so"), prod), (os.path.join(OUT, "libcricodecs_hip_testing.so"), test)):
-        cmd = [CXX, "-shared", "-fPIC", "-pthread", rt] + group + ["-o", out + ".tmp", "-Wl,--no-undefined", "-Wl,-Bsymbolic"]
+        cmd = [CXX, "-shared", "-fPIC", "-pthread", rt] + group + ["-o", out + ".tmp", "-Wl,--no-undefined", "-Wl,-Bsymbolic", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -118,4 +126,4 @@ def build_selftest():
 if __name__ == "__main__":
     if "--selftest" in sys.argv:
         sys.exit(subprocess.run([build_selftest()]).returncode)
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, traffic="--traffic" in sys.argv)

@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 #include <atomic>
+#include <algorithm>
+#include <string>
 
 extern "C" void hw_switch(void** save_sp, void* load_sp);
 asm(R"(
@@ -261,6 +263,12 @@ static void worker_init(Worker* k) {
     mprotect(k->lds + LDS_STATIC_BYTES + LDS_DYNAMIC_MAX, 4096, PROT_NONE);
 }
 
+#ifdef HOSTWAVE_TRAFFIC
+static void traffic_begin(const char* name, dim3 grid, dim3 block);
+static void traffic_end();
+static void traffic_block_end(Worker* k);
+#endif
+
 static void run_block(Worker* k, dim3 grid, dim3 block, uint32_t bx, uint32_t by, uint32_t bz, size_t lds) {
     Block& b = k->block;
     const uint32_t n = block.x * block.y * block.z;
@@ -309,6 +317,9 @@ static void run_block(Worker* k, dim3 grid, dim3 block, uint32_t bx, uint32_t by
     cur = &k->lanes[0];
     hw_switch(&k->main_sp, k->lanes[0].sp);
     cur = nullptr;
+#ifdef HOSTWAVE_TRAFFIC
+    traffic_block_end(k);
+#endif
 }
 
 // ---- the pool
@@ -363,7 +374,7 @@ struct Pool {
 static Pool* g_pool = nullptr;
 static std::mutex g_launch_mu;
 
-void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx) {
+void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx, const char* name) {
     std::lock_guard<std::mutex> one(g_launch_mu);                      // launches are synchronous and one at a time
     if (g_verbose < 0) { const char* e = getenv("HOSTWAVE_VERBOSE"); g_verbose = e && *e == '1'; }
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
@@ -372,6 +383,9 @@ void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx
     if (n > MAX_LANES || lds > LDS_DYNAMIC_MAX) { fprintf(stderr, "hostwave: launch of %u threads / %zu bytes of LDS\n", n, lds); abort(); }
     if (!g_pool) { g_pool = new Pool; g_pool->start(); }
     Pool& p = *g_pool;
+#ifdef HOSTWAVE_TRAFFIC
+    traffic_begin(name, grid, block);
+#endif
     std::unique_lock<std::mutex> lk(p.mu);
     p.grid = grid; p.block = block; p.lds = lds; p.fn = fn; p.ctx = ctx;
     p.next = 0; p.total = total;
@@ -379,6 +393,9 @@ void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx
     p.generation++;
     p.cv_work.notify_all();
     p.cv_done.wait(lk, [&] { return p.active == 0; });
+#ifdef HOSTWAVE_TRAFFIC
+    traffic_end();
+#endif
 }
 
 // ---- cross-lane instructions
@@ -416,6 +433,164 @@ uint32_t ds_swizzle(uint32_t v, uint32_t pattern, uint32_t site) {
     return take(s, true, 0, true, site);
 }
 }  // namespace hw
+
+
+#ifdef HOSTWAVE_TRAFFIC
+// ---------------------------------------------------------------- memory-traffic census (tools/traffic_census.py; never part of the test build)
+// The kernel files are compiled with -fsanitize=thread and NOT linked with its runtime: the __tsan_* hooks below see every load and
+// store of the device code.  An access to global ("device") memory is filed under its static instruction (the hook's return address),
+// its wave and the how-many-th time that lane executes it -- which names one wave-level memory instruction -- and when the workgroup
+// ends every such instruction yields: bytes the lanes asked for, distinct 128-byte lines, 64- and 32-byte sectors they lie in.  Summed
+// per static instruction this says where a kernel's traffic comes from IF no line survived in a cache between two instructions
+// (`line_bytes`), next to the launch's footprint (distinct lines: every line fetched once).  Measured HBM traffic lies in between.
+#include <unordered_map>
+#include <unordered_set>
+#include <dlfcn.h>
+namespace hw {
+struct WaveInstr { uint32_t useful = 0; bool write = false; std::vector<uint64_t> sectors; };      // 32-byte sector numbers touched
+struct SiteTotal { uint64_t instrs = 0, useful = 0, line = 0, s64 = 0, s32 = 0; bool write = false; };
+struct LaneOcc {
+    std::unordered_map<uintptr_t, uint32_t> n;
+    // the lane's previous access: a 16-byte vector load of the device is up to four dword accesses here (the types are 4-byte aligned
+    // structs on the host) -- accesses that continue the previous one are folded into it, up to the 16 bytes of a dwordx4
+    const uint8_t* last_end = nullptr; uint64_t last_key = 0; uint32_t last_bytes = 0; bool last_write = false;
+};
+struct Census {
+    std::unordered_map<uint64_t, WaveInstr> live;       // key: hash(site, wave, occurrence) of the running workgroup
+    std::unordered_map<uint64_t, uintptr_t> site_of;    // same key -> site
+    LaneOcc occ[MAX_LANES];
+    std::unordered_map<uintptr_t, SiteTotal> totals;    // this worker's share of the launch
+    std::unordered_set<uint64_t> lines_r, lines_w;      // footprint (line numbers)
+    uint64_t lds_accesses = 0, lds_bytes = 0;
+};
+static thread_local Census* tc = nullptr;
+static std::mutex g_census_mu;
+static std::unordered_map<uintptr_t, SiteTotal> g_totals;
+static std::unordered_set<uint64_t> g_lines_r, g_lines_w;
+static uint64_t g_lds_accesses, g_lds_bytes;
+static std::string g_kernel;
+static dim3 g_grid, g_block;
+
+static void traffic_begin(const char* name, dim3 grid, dim3 block) {
+    g_totals.clear(); g_lines_r.clear(); g_lines_w.clear(); g_lds_accesses = g_lds_bytes = 0;
+    g_kernel = name ? name : "?"; g_grid = grid; g_block = block;
+}
+
+static inline void census_access(const void* addr, uint32_t size, bool write, uintptr_t site) {
+    Lane* l = cur;
+    if (!l || !size) return;                                             // host code of the same translation unit
+    Worker* k = tw;
+    const uint8_t* a = (const uint8_t*)addr;
+    if (a >= k->stacks && a < k->stacks + STACK_BYTES * MAX_LANES) return;      // a lane's own stack ("registers", spills)
+    if ((a >= (const uint8_t*)k && a < (const uint8_t*)(k + 1)) || a == (const uint8_t*)&cur) return;      // the emulator's own state (threadIdx, a rendezvous' results)
+    if (!tc) tc = new Census;
+    Census& c = *tc;
+    if (a >= k->lds && a < k->lds + LDS_STATIC_BYTES + LDS_DYNAMIC_MAX) { c.lds_accesses++; c.lds_bytes += size; return; }
+    LaneOcc& lo = c.occ[l->linear];
+    uint64_t key;
+    if (a == lo.last_end && write == lo.last_write && lo.last_bytes + size <= 16 && c.live.count(lo.last_key)) {
+        key = lo.last_key;
+        lo.last_bytes += size;
+    } else {
+        const uint32_t occ = lo.n[site]++;
+        key = ((uint64_t)site * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)l->wave->index << 40) ^ ((uint64_t)occ * 0xC2B2AE3D27D4EB4Full);
+        lo.last_key = key; lo.last_bytes = size; lo.last_write = write;
+    }
+    lo.last_end = a + size;
+    WaveInstr& w = c.live[key];
+    if (w.sectors.empty()) c.site_of[key] = site;
+    w.useful += size;
+    w.write = write;
+    for (uint64_t s = (uintptr_t)a >> 5; s <= ((uintptr_t)a + size - 1) >> 5; s++) w.sectors.push_back(s);
+}
+
+static void traffic_block_end(Worker* k) {
+    if (!tc) return;
+    Census& c = *tc;
+    for (auto& kv : c.live) {
+        WaveInstr& w = kv.second;
+        std::sort(w.sectors.begin(), w.sectors.end());
+        w.sectors.erase(std::unique(w.sectors.begin(), w.sectors.end()), w.sectors.end());
+        uint64_t n32 = w.sectors.size(), n64 = 0, n128 = 0, p64 = ~0ull, p128 = ~0ull;
+        for (uint64_t s : w.sectors) {
+            if ((s >> 1) != p64) { n64++; p64 = s >> 1; }
+            if ((s >> 2) != p128) { n128++; p128 = s >> 2; (w.write ? c.lines_w : c.lines_r).insert(s >> 2); }
+        }
+        SiteTotal& t = c.totals[c.site_of[kv.first]];
+        t.instrs++; t.useful += w.useful; t.line += 128 * n128; t.s64 += 64 * n64; t.s32 += 32 * n32; t.write = w.write;
+    }
+    c.live.clear(); c.site_of.clear();
+    for (uint32_t i = 0; i < k->block.n_lanes; i++) { c.occ[i].n.clear(); c.occ[i].last_end = nullptr; }
+    std::lock_guard<std::mutex> g(g_census_mu);
+    for (auto& kv : c.totals) {
+        SiteTotal& t = g_totals[kv.first];
+        t.instrs += kv.second.instrs; t.useful += kv.second.useful; t.line += kv.second.line; t.s64 += kv.second.s64; t.s32 += kv.second.s32; t.write = kv.second.write;
+    }
+    c.totals.clear();
+    g_lines_r.insert(c.lines_r.begin(), c.lines_r.end()); g_lines_w.insert(c.lines_w.begin(), c.lines_w.end());
+    c.lines_r.clear(); c.lines_w.clear();
+    g_lds_accesses += c.lds_accesses; g_lds_bytes += c.lds_bytes; c.lds_accesses = c.lds_bytes = 0;
+}
+
+static void traffic_end() {
+    const char* path = getenv("HOSTWAVE_TRAFFIC_OUT");
+    if (!path) return;
+    FILE* f = fopen(path, "a");
+    if (!f) return;
+    Dl_info info;
+    uintptr_t base = 0;
+    const char* lib = "";
+    if (dladdr((void*)&traffic_end, &info)) { base = (uintptr_t)info.dli_fbase; lib = info.dli_fname; }
+    fprintf(f, "{\"kernel\": \"%s\", \"grid\": %u, \"block\": %u, \"lib\": \"%s\", \"footprint_read_bytes\": %llu, \"footprint_write_bytes\": %llu, \"lds_lane_accesses\": %llu, \"lds_bytes\": %llu, \"sites\": [",
+            g_kernel.c_str(), g_grid.x * g_grid.y * g_grid.z, g_block.x * g_block.y * g_block.z, lib, (unsigned long long)g_lines_r.size() * 128, (unsigned long long)g_lines_w.size() * 128,
+            (unsigned long long)g_lds_accesses, (unsigned long long)g_lds_bytes);
+    bool first = true;
+    for (auto& kv : g_totals) {
+        const SiteTotal& t = kv.second;
+        fprintf(f, "%s{\"site\": %llu, \"rw\": \"%s\", \"instrs\": %llu, \"useful\": %llu, \"line\": %llu, \"s64\": %llu, \"s32\": %llu}", first ? "" : ", ", (unsigned long long)(kv.first - base),
+                t.write ? "w" : "r", (unsigned long long)t.instrs, (unsigned long long)t.useful, (unsigned long long)t.line, (unsigned long long)t.s64, (unsigned long long)t.s32);
+        first = false;
+    }
+    fprintf(f, "]}\n");
+    fclose(f);
+}
+}  // namespace hw
+
+#define HW_SITE ((uintptr_t)__builtin_return_address(0))
+extern "C" {
+void __tsan_init(void) {}
+void __tsan_func_entry(void*) {}
+void __tsan_func_exit(void) {}
+void __tsan_vptr_update(void**, void*) {}
+void __tsan_vptr_read(void**) {}
+#define HW_RW(N) \
+    void __tsan_read##N(void* a) { hw::census_access(a, N, false, HW_SITE); } \
+    void __tsan_write##N(void* a) { hw::census_access(a, N, true, HW_SITE); } \
+    void __tsan_unaligned_read##N(void* a) { hw::census_access(a, N, false, HW_SITE); } \
+    void __tsan_unaligned_write##N(void* a) { hw::census_access(a, N, true, HW_SITE); }
+HW_RW(1) HW_RW(2) HW_RW(4) HW_RW(8) HW_RW(16)
+void __tsan_read_range(void* a, unsigned long n) { hw::census_access(a, (uint32_t)n, false, HW_SITE); }
+void __tsan_write_range(void* a, unsigned long n) { hw::census_access(a, (uint32_t)n, true, HW_SITE); }
+void* __tsan_memcpy(void* d, const void* s, size_t n) { hw::census_access(s, (uint32_t)n, false, HW_SITE); hw::census_access(d, (uint32_t)n, true, HW_SITE + 1); return memcpy(d, s, n); }
+void* __tsan_memmove(void* d, const void* s, size_t n) { hw::census_access(s, (uint32_t)n, false, HW_SITE); hw::census_access(d, (uint32_t)n, true, HW_SITE + 1); return memmove(d, s, n); }
+void* __tsan_memset(void* d, int v, size_t n) { hw::census_access(d, (uint32_t)n, true, HW_SITE); return memset(d, v, n); }
+#define HW_ATOMIC(BITS, T) \
+    T __tsan_atomic##BITS##_load(const volatile T* a, int) { hw::census_access((const void*)a, BITS / 8, false, HW_SITE); return __atomic_load_n(a, __ATOMIC_RELAXED); } \
+    void __tsan_atomic##BITS##_store(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); __atomic_store_n(a, v, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_exchange(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_exchange_n(a, v, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_fetch_add(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_fetch_add(a, v, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_fetch_sub(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_fetch_sub(a, v, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_fetch_and(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_fetch_and(a, v, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_fetch_or(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_fetch_or(a, v, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_fetch_xor(volatile T* a, T v, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_fetch_xor(a, v, __ATOMIC_RELAXED); } \
+    int __tsan_atomic##BITS##_compare_exchange_strong(volatile T* a, T* c, T v, int, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_compare_exchange_n(a, c, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); } \
+    T __tsan_atomic##BITS##_compare_exchange_val(volatile T* a, T c, T v, int, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); __atomic_compare_exchange_n(a, &c, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return c; } \
+    int __tsan_atomic##BITS##_compare_exchange_weak(volatile T* a, T* c, T v, int, int) { hw::census_access((const void*)a, BITS / 8, true, HW_SITE); return __atomic_compare_exchange_n(a, c, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }
+HW_ATOMIC(8, uint8_t) HW_ATOMIC(16, uint16_t) HW_ATOMIC(32, uint32_t) HW_ATOMIC(64, uint64_t)
+void __tsan_atomic_thread_fence(int) {}
+void __tsan_atomic_signal_fence(int) {}
+}
+#endif
 
 // ---------------------------------------------------------------- the fake runtime: host memory, everything synchronous
 struct hw_stream { int id; };

@@ -148,9 +148,9 @@ struct Block {
 };
 extern thread_local Lane* cur;
 
-void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx);
+void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx, const char* name);
 template <class F> static void launch_thunk(void* p) { (*(F*)p)(); }
-template <class F> inline void launch(dim3 grid, dim3 block, size_t lds, hipStream_t, F f) { launch_grid(grid, block, lds, &launch_thunk<F>, &f); }
+template <class F> inline void launch(dim3 grid, dim3 block, size_t lds, hipStream_t, F f, const char* name) { launch_grid(grid, block, lds, &launch_thunk<F>, &f, name); }
 
 void* dyn_lds();
 void* static_lds(uint32_t bytes, uint32_t align, uint32_t site);
@@ -256,7 +256,7 @@ inline void ds_add_u32(uint32_t lds_addr, uint32_t v) { *(uint32_t*)(uintptr_t)l
 #define blockDim (hw::cur->block->bdim)
 #define gridDim (hw::cur->block->gdim)
 #define warpSize 64
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hw::launch((grid), (block), (lds), (stream), [=]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hw::launch((grid), (block), (lds), (stream), [=]() { kernel(__VA_ARGS__); }, #kernel)
 
 #define __syncthreads() hw::syncthreads()
 #define __builtin_amdgcn_wave_barrier() hw::wave_barrier(__LINE__)
