@@ -16,7 +16,7 @@ QUOTED = {
     "k_hca_parse<false, true>": ((128, 4, 2, 83, 12), "128 VGPR / 4 / 2 VGPR + 83 SGPR spills, 12 B scratch"),
     "k_hca_transform_plain<2, false, false, false, false>": ((124, 4, 0, 0, 0), "124 VGPR / 4 / none"),
     "k_hca_transform_plain<4, false, false, true, false>": ((128, 4, 4, 0, 20), "plain: 128 VGPR / 4 / **4 VGPR spills, 20 B scratch**"),
-    "k_hca_transform_plain<2, false, true, false, true>": ((168, 3, 11, 70, 48), "168 VGPR / 3 / **11-12 VGPR spills, 48 B**"),
+    "k_hca_transform_plain<2, false, true, false, true>": ((168, 3, 7, 72, 32), "168 VGPR / 3 / **1-9 VGPR spills, 8-40 B** (stereo 7, 32 B"),
     "k_hca_encode<2>": ((80, 6, 2, 107, 12), "80 VGPR / 6 / **2 VGPR + 107 SGPR spills, 12 B scratch**"),
     "k_adx_seg_decode": ((90, 5, 0, 0, 0), "90 VGPR / 5 / none"),
     "k_adx_lane_encode": ((144, 3, 0, 0, 0), "144 VGPR / 3 / none"),
