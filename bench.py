@@ -813,6 +813,19 @@ def awb_mixed_run(D, clips, steps, warmup, gather=False, verify=True, strong=Fal
     return res
 
 
+PROCESS_T0 = time.time()
+
+
+def _full_size_in_budget(args, label):
+    """The full-size form of a secondary is taken while the run is inside --full-secondary-budget seconds of wall time: the default run
+    must end within minutes whatever the box (its one JSON line is printed last).  What is skipped says so in bench_detail.json."""
+    spent = time.time() - PROCESS_T0
+    if spent <= args.full_secondary_budget:
+        return True
+    log("%s at the headline's size: skipped (%.0f s of wall time spent, budget %.0f s)" % (label, spent, args.full_secondary_budget))
+    return False
+
+
 def _sec_sizes(args):
     n = args.secondary_streams
     return n, min(args.unique, 16), (args.streams if (args.streams > n and not args.no_full_secondary) else 0)      # (.., .., the headline's size: the chip filled ~18 times)
@@ -846,6 +859,9 @@ def sec_decode_families(args, D, out):
                           ("hca_decode_low", 3, "tonal"), ("hca_decode_lowest", 4, "tonal")):
         uniq = make_hca_streams(uq, args.seconds, D.rank, q, fam)
         for tag, size in (("", n),) + ((("_full", full),) if full else ()):
+            if tag and not _full_size_in_budget(args, label):
+                out[label + tag] = {"skipped": "wall-time budget of the default run (--full-secondary-budget)"}
+                continue
             r = hca_decode_run(D, size, uq, args.seconds, q, fam, 3, 1, uniq=uniq)
             out[label + tag] = _dec_entry(r, "HCA decode, %d x %.0f s encrypted stereo streams, quality %s, %s material" % (size, args.seconds, QNAME[q], fam))
 
@@ -866,6 +882,9 @@ def sec_decode_layouts(args, D, out):
             plain = [hca_forge.forge_v3(h, 0) for h in plain]
         uniq = [O.hca_crypt(h, 1, 56, KEY) for h in plain]
         for tag, size in (("", nw),) + ((("_full", max(1, full * 2 // ch)),) if full else ()):
+            if tag and not _full_size_in_budget(args, label):
+                out[label + tag] = {"skipped": "wall-time budget of the default run (--full-secondary-budget)"}
+                continue
             r = hca_decode_run(D, size, 4, args.seconds, q, "tonal", 3, 1, uniq=uniq)
             out[label + tag] = _dec_entry(
                 r, "HCA decode, %d x %.0f s encrypted %d-channel streams, quality %s%s" % (size, args.seconds, ch, QNAME[q], ", v3.0 header with min_resolution 0 (noise fill)" if v3 else ""))
@@ -1206,6 +1225,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the all-items check against the oracle (profiling runs)")
     ap.add_argument("--secondary-streams", type=int, default=1000)
     ap.add_argument("--no-full-secondary", action="store_true", help="secondaries at --secondary-streams only, not also at the headline's size")
+    ap.add_argument("--full-secondary-budget", type=float, default=150.0, help="the full-size forms of the secondaries are taken while the run has spent less wall time than this (seconds); the rest of the default run (round 5: 142 s in all) follows whatever it says")
     ap.add_argument("--host-streams", type=int, default=10000, help="streams of the host-memory secondary (host output buffers: 1.92 MB each)")
     ap.add_argument("--awb-clips", type=int, default=12500, help="clips per GPU of the mixed AWB bank (100 000 / 8 GPUs)")
     ap.add_argument("--awb-durations", type=int, default=4096, help="distinct clip lengths of the mixed AWB bank (log-uniform 0.05-2 s; each as an HCA and as an ADX clip)")

@@ -82,6 +82,16 @@ def test_default_run_with_secondaries_and_cpu_baseline(monkeypatch, capsys, tmp_
     assert "configs[3]" in line["other_configs_M_per_s"]
 
 
+def test_full_size_secondaries_respect_the_wall_time_budget(monkeypatch, capsys, tmp_path):
+    """--full-secondary-budget: past it the full-size forms are skipped and say so; the 1000-stream forms, the configurations and the line stay."""
+    line, detail = run_main(monkeypatch, capsys, tmp_path, SMALL[:6] + ["--steps", "1", "--warmup", "0", "--secondary-streams", "4", "--awb-clips", "24", "--awb-durations", "6",
+                                                                           "--config-awb-clips", "24", "--config-items-scale", "0.0005", "--config-seconds-scale", "0.02",
+                                                                           "--no-cpu", "--sustain", "0", "--full-secondary-budget", "0"])
+    sec = detail["secondary"]
+    assert sec["hca_decode_middle"]["verified_items"] > 0 and "skipped" in sec["hca_decode_middle_full"] and "skipped" in sec["hca_decode_6ch_full"]
+    assert "hca_decode_middle_full" not in sec["summary_M_per_s"] and len(sec["baseline_configs"]) >= 3
+
+
 @pytest.mark.timeout(600)
 def test_two_rank_launcher_gathers_and_verifies_on_the_root():
     """bench.py --gpus 2 --workload awb_mixed --scaling strong over gloo: the LPT deal, both ranks' jobs, gather_bytes_to_root, and the
