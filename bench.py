@@ -434,6 +434,9 @@ def committed_traffic(units, dom, workload="hca_decode"):
     out = {"traffic": int(round(total * units)),
            "traffic_source": "profiles/%s %s: %.1f B per %s (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, calibrated) x %d"
                              % (os.path.basename(tfiles[-1]), workload, total, wl.get("unit", "unit"), units)}
+    if workload.startswith("hca_decode") and os.path.basename(tfiles[-1]) < "r06":
+        # (the pass predates round 6's change of where the transform reads the code descriptions: tools/traffic_census.py models -2.1 KB read, +0.5 KB moved by the parse)
+        out["traffic_source"] += "; counted before round 6 moved the code descriptions into the frame records"
     key = dom if dom in ks else next((k for k in ks if k.startswith(dom) or dom.startswith(k)), None)
     if key and ks[key].get("hbm_bytes_per_unit"):
         out["traffic_dominant_kernel"] = int(round(ks[key]["hbm_bytes_per_unit"] * units))
