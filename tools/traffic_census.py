@@ -37,38 +37,47 @@ import numpy as np, oracle_lib as O
 from pycricodecs_amd import synth
 from pycricodecs_amd.batch import Job
 KEY = 0xCF222F1FE0748978
-n, secs, wl = %(streams)d, %(seconds)f, %(workload)r
-wavs = [synth.wav(500 + i, int(48000 * secs), 2, 48000) for i in range(n)]
+n, secs, wl, ch, q, v3 = %(streams)d, %(seconds)f, %(workload)r, %(channels)d, %(quality)d, %(v3)d
+wavs = [synth.wav(500 + i, int(48000 * secs), ch, 48000) for i in range(n)]
 def run(job):
     bufs = job.alloc("cpu"); job.run(*bufs)
     st = bufs[3].numpy()[:job.n]
     assert (st == 0).all(), st
     return job, bufs
 if wl == "hca_decode":
-    items = [O.hca_crypt(O.hca_encode(w, 1), 1, 56, KEY, 0) for w in wavs]
+    import hca_forge
+    plain = [O.hca_encode(w, q) for w in wavs]
+    if v3:
+        plain = [hca_forge.forge_v3(h, 0) for h in plain]
+    items = [O.hca_crypt(h, 1, 56, KEY, 0) for h in plain]
     job, bufs = run(Job.hca_decode(items, keys=[KEY] * n))
     outs = job.split(bytes(bufs[1].numpy()))
     assert all(bytes(o) == O.hca_decode(h, KEY, 0) for o, h in zip(outs, items))
+    print("FORMS", job.transform_forms())
     print("UNITS", job.units, "frames")
 elif wl == "hca_encode":
-    job, bufs = run(Job.hca_encode(wavs, quality=1))
+    job, bufs = run(Job.hca_encode(wavs, quality=q))
     print("UNITS", job.units, "frames")
 else:
-    job, bufs = run(Job.adx_encode(wavs))
-    enc = [bytes(x) for x in job.split(bytes(bufs[1].numpy()))]
-    assert all(e == O.adx_encode(w) for e, w in zip(enc, wavs))
-    j2, b2 = run(Job.adx_decode(enc))
+    from pycricodecs_amd import _capi
+    import contextlib
+    knobs = _capi.testing_knobs(adx_mapping=%(adx_mapping)r) if %(adx_mapping)r != "auto" else contextlib.nullcontext()
+    with knobs:                                # (the testing build of the census library: the planner's mapping forced, as the parity tests do)
+        job, bufs = run(Job.adx_encode(wavs))
+        enc = [bytes(x) for x in job.split(bytes(bufs[1].numpy()))]
+        assert all(e == O.adx_encode(w) for e, w in zip(enc, wavs))
+        j2, b2 = run(Job.adx_decode(enc))
     print("UNITS", job.units, "block rows (each counted once: encode and decode both run)")
 '''
 
 
-def run_census(workload, streams, seconds):
+def run_census(workload, streams, seconds, channels=2, quality=1, v3=0, adx_mapping="auto"):
     subprocess.run([sys.executable, os.path.join(HW, "build.py"), "--traffic"], check=True, stdout=subprocess.DEVNULL)
     lib = os.path.join(HW, "lib_traffic")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "census.jsonl")
         env = dict(os.environ, CRI_TEST_HOSTWAVE="1", CRICODECS_LIB_DIR=lib, CRICODECS_NO_REBUILD="1", HOSTWAVE_TRAFFIC_OUT=out, HOSTWAVE_THREADS="8")
-        r = subprocess.run([sys.executable, "-c", WORKLOAD % dict(root=ROOT, streams=streams, seconds=seconds, workload=workload)], env=env, capture_output=True, text=True, cwd=ROOT)
+        r = subprocess.run([sys.executable, "-c", WORKLOAD % dict(root=ROOT, streams=streams, seconds=seconds, workload=workload, channels=channels, quality=quality, v3=v3, adx_mapping=adx_mapping)], env=env, capture_output=True, text=True, cwd=ROOT)
         if r.returncode:
             raise SystemExit(r.stdout[-2000:] + r.stderr[-4000:])
         units = int(re.search(r"UNITS (\d+)", r.stdout).group(1))
@@ -102,9 +111,13 @@ def main():
     ap.add_argument("--streams", type=int, default=96)
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--quality", type=int, default=1, help="HCA quality 0..4 (1 = High, the headline)")
+    ap.add_argument("--v3", action="store_true", help="hca_decode: the streams re-headed as v3.0 with min_resolution 0 (noise fill)")
+    ap.add_argument("--adx-mapping", default="auto", choices=["auto", "chain", "file", "seg", "lane", "wave"], help="adx_roundtrip: force the planner's mapping (the lane-per-segment kernels of large batches on a small one)")
     ap.add_argument("--min-share", type=float, default=0.02, help="source lines below this share of a kernel's line bytes are folded into 'other'")
     args = ap.parse_args()
-    units, launches, lib = run_census(args.workload, args.streams, args.seconds)
+    units, launches, lib = run_census(args.workload, args.streams, args.seconds, args.channels, args.quality, int(args.v3), args.adx_mapping)
     sym = symbolize(lib, {s["site"] for l in launches for s in l["sites"]})
     kernels = collections.OrderedDict()
     for l in launches:
@@ -116,7 +129,7 @@ def main():
             for f in ("instrs", "useful", "line", "s64", "s32"):
                 c[f] += s[f]
     report = {"workload": args.workload, "streams": args.streams, "seconds": args.seconds, "units": units, "kernels": {}}
-    print("%s: %d streams x %.2f s, %d units; bytes PER UNIT" % (args.workload, args.streams, args.seconds, units))
+    print("%s: %d streams x %.2f s (%d channels, quality %d%s), %d units; bytes PER UNIT" % (args.workload, args.streams, args.seconds, args.channels, args.quality, ", v3.0 noise fill" if args.v3 else "", units))
     for name, k in kernels.items():
         tot = {rw: collections.Counter() for rw in "rw"}
         for (where, rw), c in k["lines"].items():
