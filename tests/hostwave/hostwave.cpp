@@ -447,7 +447,7 @@ uint32_t ds_swizzle(uint32_t v, uint32_t pattern, uint32_t site) {
 #include <unordered_set>
 #include <dlfcn.h>
 namespace hw {
-struct WaveInstr { uint32_t useful = 0; bool write = false; std::vector<uint64_t> sectors; };      // 32-byte sector numbers touched
+struct WaveInstr { uint32_t useful = 0; bool write = false; uint32_t seq = 0; uint32_t wave = 0; std::vector<uint64_t> sectors; };      // 32-byte sector numbers touched; seq: order of first touch inside the workgroup
 struct SiteTotal { uint64_t instrs = 0, useful = 0, line = 0, s64 = 0, s32 = 0; bool write = false; };
 struct LaneOcc {
     std::unordered_map<uintptr_t, uint32_t> n;
@@ -459,12 +459,15 @@ struct Census {
     std::unordered_map<uint64_t, WaveInstr> live;       // key: hash(site, wave, occurrence) of the running workgroup
     std::unordered_map<uint64_t, uintptr_t> site_of;    // same key -> site
     LaneOcc occ[MAX_LANES];
+    uint32_t next_seq = 0;
     std::unordered_map<uintptr_t, SiteTotal> totals;    // this worker's share of the launch
     std::unordered_set<uint64_t> lines_r, lines_w;      // footprint (line numbers)
     uint64_t lds_accesses = 0, lds_bytes = 0;
 };
 static thread_local Census* tc = nullptr;
 static std::mutex g_census_mu;
+static FILE* g_trace = nullptr;
+static uint64_t g_launch_no = 0;
 static std::unordered_map<uintptr_t, SiteTotal> g_totals;
 static std::unordered_set<uint64_t> g_lines_r, g_lines_w;
 static uint64_t g_lds_accesses, g_lds_bytes;
@@ -472,6 +475,8 @@ static std::string g_kernel;
 static dim3 g_grid, g_block;
 
 static void traffic_begin(const char* name, dim3 grid, dim3 block) {
+    if (!g_trace) if (const char* t = getenv("HOSTWAVE_TRACE_OUT")) g_trace = fopen(t, "ab");
+    g_launch_no++;
     g_totals.clear(); g_lines_r.clear(); g_lines_w.clear(); g_lds_accesses = g_lds_bytes = 0;
     g_kernel = name ? name : "?"; g_grid = grid; g_block = block;
 }
@@ -498,19 +503,41 @@ static inline void census_access(const void* addr, uint32_t size, bool write, ui
     }
     lo.last_end = a + size;
     WaveInstr& w = c.live[key];
-    if (w.sectors.empty()) c.site_of[key] = site;
+    if (w.sectors.empty()) { c.site_of[key] = site; w.seq = c.next_seq++; w.wave = l->wave->index; }
     w.useful += size;
     w.write = write;
     for (uint64_t s = (uintptr_t)a >> 5; s <= ((uintptr_t)a + size - 1) >> 5; s++) w.sectors.push_back(s);
 }
 
+// HOSTWAVE_TRACE_OUT: every workgroup's memory instructions in program order (per wave: the order of first touch), each with the
+// 128-byte lines it touches -- what tools/l2_replay.py interleaves over a model of one XCD's L2.  Binary records of uint64:
+//   [0xB10C, launch number, block number, n] then n x [wave << 56 | write << 48 | seq << 16 | n_lines, lines...]
+static void trace_block(Worker* k, Census& c) {
+    std::vector<const WaveInstr*> order;
+    order.reserve(c.live.size());
+    for (auto& kv : c.live) order.push_back(&kv.second);
+    std::sort(order.begin(), order.end(), [](const WaveInstr* a, const WaveInstr* b) { return a->seq < b->seq; });
+    std::vector<uint64_t> rec;
+    const Block& b = k->block;
+    rec.push_back(0xB10C); rec.push_back(g_launch_no); rec.push_back((uint64_t)b.bid.x + (uint64_t)b.gdim.x * (b.bid.y + (uint64_t)b.gdim.y * b.bid.z)); rec.push_back(order.size());
+    for (const WaveInstr* w : order) {
+        uint64_t prev = ~0ull; std::vector<uint64_t> lines;
+        for (uint64_t sct : w->sectors) if ((sct >> 2) != prev) { prev = sct >> 2; lines.push_back(prev); }
+        rec.push_back(((uint64_t)w->wave << 56) | ((uint64_t)(w->write ? 1 : 0) << 48) | ((uint64_t)(w->seq & 0xFFFFFFFFu) << 16) | (lines.size() & 0xFFFF));
+        rec.insert(rec.end(), lines.begin(), lines.end());
+    }
+    std::lock_guard<std::mutex> g(g_census_mu);
+    fwrite(rec.data(), 8, rec.size(), g_trace);
+}
+
 static void traffic_block_end(Worker* k) {
     if (!tc) return;
     Census& c = *tc;
+    for (auto& kv : c.live) { WaveInstr& w = kv.second; std::sort(w.sectors.begin(), w.sectors.end()); w.sectors.erase(std::unique(w.sectors.begin(), w.sectors.end()), w.sectors.end()); }
+    if (g_trace) trace_block(k, c);
+    c.next_seq = 0;
     for (auto& kv : c.live) {
         WaveInstr& w = kv.second;
-        std::sort(w.sectors.begin(), w.sectors.end());
-        w.sectors.erase(std::unique(w.sectors.begin(), w.sectors.end()), w.sectors.end());
         uint64_t n32 = w.sectors.size(), n64 = 0, n128 = 0, p64 = ~0ull, p128 = ~0ull;
         for (uint64_t s : w.sectors) {
             if ((s >> 1) != p64) { n64++; p64 = s >> 1; }
@@ -541,8 +568,9 @@ static void traffic_end() {
     uintptr_t base = 0;
     const char* lib = "";
     if (dladdr((void*)&traffic_end, &info)) { base = (uintptr_t)info.dli_fbase; lib = info.dli_fname; }
-    fprintf(f, "{\"kernel\": \"%s\", \"grid\": %u, \"block\": %u, \"lib\": \"%s\", \"footprint_read_bytes\": %llu, \"footprint_write_bytes\": %llu, \"lds_lane_accesses\": %llu, \"lds_bytes\": %llu, \"sites\": [",
-            g_kernel.c_str(), g_grid.x * g_grid.y * g_grid.z, g_block.x * g_block.y * g_block.z, lib, (unsigned long long)g_lines_r.size() * 128, (unsigned long long)g_lines_w.size() * 128,
+    if (g_trace) fflush(g_trace);
+    fprintf(f, "{\"kernel\": \"%s\", \"launch\": %llu, \"grid\": %u, \"block\": %u, \"lib\": \"%s\", \"footprint_read_bytes\": %llu, \"footprint_write_bytes\": %llu, \"lds_lane_accesses\": %llu, \"lds_bytes\": %llu, \"sites\": [",
+            g_kernel.c_str(), (unsigned long long)g_launch_no, g_grid.x * g_grid.y * g_grid.z, g_block.x * g_block.y * g_block.z, lib, (unsigned long long)g_lines_r.size() * 128, (unsigned long long)g_lines_w.size() * 128,
             (unsigned long long)g_lds_accesses, (unsigned long long)g_lds_bytes);
     bool first = true;
     for (auto& kv : g_totals) {

@@ -71,13 +71,17 @@ else:
 '''
 
 
-def run_census(workload, streams, seconds, channels=2, quality=1, v3=0, adx_mapping="auto"):
-    subprocess.run([sys.executable, os.path.join(HW, "build.py"), "--traffic"], check=True, stdout=subprocess.DEVNULL)
-    lib = os.path.join(HW, "lib_traffic")
+def run_census(workload, streams, seconds, channels=2, quality=1, v3=0, adx_mapping="auto", trace=None, lib_dir=None):
+    if not lib_dir:
+        subprocess.run([sys.executable, os.path.join(HW, "build.py"), "--traffic"], check=True, stdout=subprocess.DEVNULL)
+    lib = lib_dir or os.path.join(HW, "lib_traffic")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "census.jsonl")
         env = dict(os.environ, CRI_TEST_HOSTWAVE="1", CRICODECS_LIB_DIR=lib, CRICODECS_NO_REBUILD="1", HOSTWAVE_TRAFFIC_OUT=out, HOSTWAVE_THREADS="8")
-        r = subprocess.run([sys.executable, "-c", WORKLOAD % dict(root=ROOT, streams=streams, seconds=seconds, workload=workload, channels=channels, quality=quality, v3=v3, adx_mapping=adx_mapping)], env=env, capture_output=True, text=True, cwd=ROOT)
+        if trace:                                              # every workgroup's memory instructions in order, for tools/l2_replay.py
+            env["HOSTWAVE_TRACE_OUT"] = trace
+        root = os.path.abspath(os.path.join(lib, "..", "..", "..")) if lib_dir else ROOT      # (a census build of ANOTHER tree, e.g. round 5's decoder: its own package and build id)
+        r = subprocess.run([sys.executable, "-c", WORKLOAD % dict(root=root, streams=streams, seconds=seconds, workload=workload, channels=channels, quality=quality, v3=v3, adx_mapping=adx_mapping)], env=env, capture_output=True, text=True, cwd=root)
         if r.returncode:
             raise SystemExit(r.stdout[-2000:] + r.stderr[-4000:])
         units = int(re.search(r"UNITS (\d+)", r.stdout).group(1))
