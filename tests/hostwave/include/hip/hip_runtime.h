@@ -3,7 +3,7 @@
 // run under a lockstep emulation of a gfx950 workgroup: one fiber per lane, wave64 cross-lane operations (DPP, ds_swizzle,
 // ds_bpermute, readlane, ballot) as rendezvous between the fibers of a wave, LDS as a per-workgroup arena with a guard page behind the
 // launch's dynamic size, "device memory" = host memory.  The parity tests of tests/test_gpu_*.py then run against the SAME sources
-// without a GPU (tests/test_hostwave.py).  Nothing under pycricodecs_amd/ includes, links or loads this; it is no CPU fallback.
+// without a GPU (tests/test_hostwave.py; tests/hostwave/README.md).  Nothing under pycricodecs_amd/ includes, links or loads this; it is no CPU fallback.
 //
 // What it checks: the kernels' data flow -- indices, bit twiddling, cross-lane patterns, LDS layouts and sizes, float arithmetic in
 // IEEE binary32 with the same operation order (no contraction; explicit fma where the source says fma).  What it cannot check: the
