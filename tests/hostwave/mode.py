@@ -42,9 +42,20 @@ def enable():
 
     def alloc_on_host(self, device="cuda:0", upload=True):
         if os.environ.get("HOSTWAVE_GUARD") != "1":
-            bufs = alloc(self, "cpu", upload)
-            bufs[2].fill_(0xCD)                    # scratch is `torch.empty` on the device: nothing may depend on what it held
-            return bufs
+            # (256-byte aligned like a device allocation: the traffic census counts 128-byte lines)
+            def al(n, dtype=torch.uint8, fill=None):
+                raw = torch.empty(n * torch.empty((), dtype=dtype).element_size() + 256, dtype=torch.uint8)
+                off = (-raw.data_ptr()) % 256
+                t = raw[off:off + n * torch.empty((), dtype=dtype).element_size()].view(dtype)
+                if fill is not None:
+                    t.fill_(fill)
+                return t
+            d_in = al(max(self.input_bytes, 1))
+            if upload and self.input_bytes:
+                d_in.zero_()
+                self.upload(d_in)
+            # scratch is `torch.empty` on the device: nothing may depend on what it held
+            return d_in, al(max(self.output_bytes, 1), fill=0), al(max(self.scratch_bytes, 1), fill=0xCD), al(max(self.n, 1), torch.int32, fill=0)
         # HOSTWAVE_GUARD=1: every device buffer of the job between two inaccessible pages, its END (rounded up to 64 bytes) on the
         # page boundary -- a kernel that reads or writes past a buffer (or before it) dies there, with the emulator's report
         d_in = guarded(max(self.input_bytes, 1), torch.uint8)
