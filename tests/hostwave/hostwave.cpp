@@ -511,7 +511,7 @@ static inline void census_access(const void* addr, uint32_t size, bool write, ui
 
 // HOSTWAVE_TRACE_OUT: every workgroup's memory instructions in program order (per wave: the order of first touch), each with the
 // 128-byte lines it touches -- what tools/l2_replay.py interleaves over a model of one XCD's L2.  Binary records of uint64:
-//   [0xB10C, launch number, block number, n] then n x [wave << 56 | write << 48 | seq << 16 | n_lines, lines...]
+//   [0xB10C, launch number, block number, n] then n x [wave << 56 | write << 48 | seq << 16 | n_lines, (line << 4 | sector mask)...]
 static void trace_block(Worker* k, Census& c) {
     std::vector<const WaveInstr*> order;
     order.reserve(c.live.size());
@@ -521,8 +521,12 @@ static void trace_block(Worker* k, Census& c) {
     const Block& b = k->block;
     rec.push_back(0xB10C); rec.push_back(g_launch_no); rec.push_back((uint64_t)b.bid.x + (uint64_t)b.gdim.x * (b.bid.y + (uint64_t)b.gdim.y * b.bid.z)); rec.push_back(order.size());
     for (const WaveInstr* w : order) {
+        // (lines as line number << 4 | mask of the line's four 32-byte sectors the instruction touches)
         uint64_t prev = ~0ull; std::vector<uint64_t> lines;
-        for (uint64_t sct : w->sectors) if ((sct >> 2) != prev) { prev = sct >> 2; lines.push_back(prev); }
+        for (uint64_t sct : w->sectors) {
+            if ((sct >> 2) != prev) { prev = sct >> 2; lines.push_back(prev << 4); }
+            lines.back() |= 1ull << (sct & 3);
+        }
         rec.push_back(((uint64_t)w->wave << 56) | ((uint64_t)(w->write ? 1 : 0) << 48) | ((uint64_t)(w->seq & 0xFFFFFFFFu) << 16) | (lines.size() & 0xFFFF));
         rec.insert(rec.end(), lines.begin(), lines.end());
     }

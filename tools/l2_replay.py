@@ -7,7 +7,7 @@ Model (deliberately small): one XCD = 32 CUs x `--waves-per-cu` resident waves (
 taken in launch order as slots free up; per round every resident workgroup issues its next memory instruction (equal progress); the
 L2 is 4 MiB of 128-byte lines, 16-way set associative, LRU, write-back with write-allocate-without-fetch; there is no L1 in front of
 it and no Infinity Cache behind it (FETCH_SIZE / WRITE_SIZE count what crosses between L2 and the fabric either way).  Read misses x 128 B
-= modelled fetch traffic, dirty evictions (+ what is dirty at the end) x 128 B = modelled write traffic, both PER UNIT.
+= modelled fetch traffic, the dirty 32-byte sectors of evicted lines (+ what is dirty at the end) = modelled write traffic, both PER UNIT.
 
 It is calibrated, not validated: `profiles/r05_a_traffic.json` has the counters of round 5's kernels at the headline's size (parse read
 5427 / written 2664, transform read 6565 / written 4094 B per frame); `--lib-dir` runs any census build of the library (e.g. one made from
@@ -53,8 +53,9 @@ def read_trace(path):
 
 
 def replay(blocks, slots):
-    """(read-miss lines, written-back lines, line requests) of one launch"""
-    sets = [collections.OrderedDict() for _ in range(SETS)]       # line -> dirty
+    """(read-miss lines, written-back 32-byte sectors, line requests) of one launch"""
+    sets = [collections.OrderedDict() for _ in range(SETS)]       # line -> mask of dirty sectors
+    pop = [bin(i).count("1") for i in range(16)]
     miss = wb = req = 0
     pending = collections.deque(range(len(blocks)))
     active = []                                                    # [block index, position]
@@ -71,7 +72,8 @@ def replay(blocks, slots):
             write, lines = instrs[st[1]]
             st[1] += 1
             nxt.append(st)
-            for ln in lines:
+            for lm in lines:
+                ln, m = lm >> 4, (lm & 15) if write else 0
                 req += 1
                 s = sets[ln % SETS]
                 d = s.pop(ln, None)
@@ -80,12 +82,12 @@ def replay(blocks, slots):
                         miss += 1
                     if len(s) >= WAYS:
                         _, dirty = s.popitem(last=False)
-                        wb += dirty
-                    s[ln] = write
+                        wb += pop[dirty]
+                    s[ln] = m
                 else:
-                    s[ln] = d or write
+                    s[ln] = d | m
         active = nxt
-    wb += sum(sum(s.values()) for s in sets)
+    wb += sum(pop[d] for s in sets for d in s.values())
     return miss, wb, req
 
 
@@ -110,7 +112,7 @@ def main():
             continue
         slots = 32 * max(1, args.waves_per_cu // max(1, threads // 64))
         miss, wb, req = replay(tr[launch], slots)
-        r = {"workgroups": len(tr[launch]), "resident": slots, "fetched": miss * 128 / units, "written_back": wb * 128 / units, "line_requests": req * 128 / units}
+        r = {"workgroups": len(tr[launch]), "resident": slots, "fetched": miss * 128 / units, "written_back": wb * 32 / units, "line_requests": req * 128 / units}
         out["kernels"][name] = r
         print("  %-24s %5d workgroups (%d resident): fetched %7.1f  written back %7.1f  (line requests %8.1f)" % (name, r["workgroups"], slots, r["fetched"], r["written_back"], r["line_requests"]))
     tot = sum(k["fetched"] + k["written_back"] for k in out["kernels"].values())
