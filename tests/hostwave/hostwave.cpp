@@ -56,6 +56,7 @@ static const size_t STACK_BYTES = 1u << 20;        // per lane (virtual; touched
 static const uint32_t MAX_LANES = 1024;
 static const uint32_t LDS_STATIC_BYTES = 64 * 1024, LDS_DYNAMIC_MAX = 160 * 1024;
 static int g_verbose = -1;
+static int g_order = 0;                            // HOSTWAVE_ORDER: which lane of a workgroup runs first and which way the ring goes
 static std::atomic<uint64_t> g_subset_completions{0};
 
 struct Worker {                                    // one per host thread of the pool
@@ -305,6 +306,7 @@ static void run_block(Worker* k, dim3 grid, dim3 block, uint32_t bx, uint32_t by
         l.block = &b;
         l.next = &k->lanes[(i + 1) % n];
         l.prev = &k->lanes[(i + n - 1) % n];
+        if (g_order == 1) std::swap(l.next, l.prev);       // HOSTWAVE_ORDER=reverse: the ring runs the other way (waves and lanes in descending order)
         l.done = false;
         l.released = false;
         l.stack = k->stacks + (size_t)i * STACK_BYTES;
@@ -314,8 +316,10 @@ static void run_block(Worker* k, dim3 grid, dim3 block, uint32_t bx, uint32_t by
         for (int r = 3; r <= 8; r++) top[-r] = nullptr;
         l.sp = &top[-8];
     }
-    cur = &k->lanes[0];
-    hw_switch(&k->main_sp, k->lanes[0].sp);
+    // the lane that runs first: 0, the last one (reverse), or the first lane of a wave drawn from the block's number (HOSTWAVE_ORDER=rotate)
+    Lane* first = &k->lanes[g_order == 1 ? n - 1 : (g_order == 2 ? 64 * (((bx + 7 * by) * 2654435761u >> 7) % b.n_waves) : 0)];
+    cur = first;
+    hw_switch(&k->main_sp, first->sp);
     cur = nullptr;
 #ifdef HOSTWAVE_TRAFFIC
     traffic_block_end(k);
@@ -376,7 +380,10 @@ static std::mutex g_launch_mu;
 
 void launch_grid(dim3 grid, dim3 block, size_t lds, void (*fn)(void*), void* ctx, const char* name) {
     std::lock_guard<std::mutex> one(g_launch_mu);                      // launches are synchronous and one at a time
-    if (g_verbose < 0) { const char* e = getenv("HOSTWAVE_VERBOSE"); g_verbose = e && *e == '1'; }
+    if (g_verbose < 0) {
+        const char* e = getenv("HOSTWAVE_VERBOSE"); g_verbose = e && *e == '1';
+        const char* o = getenv("HOSTWAVE_ORDER"); g_order = o && !strcmp(o, "reverse") ? 1 : (o && !strcmp(o, "rotate") ? 2 : 0);
+    }
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
     const uint32_t n = block.x * block.y * block.z;
     if (!total || !n) return;

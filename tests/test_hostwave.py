@@ -96,6 +96,22 @@ def test_gpu_parity_suite_on_the_emulated_kernels(emulated_lib):
     assert " failed" not in r.stdout and " error" not in r.stdout, tail
 
 
+@pytest.mark.parametrize("order", ["reverse", "rotate"])
+def test_kernels_with_several_waves_do_not_depend_on_the_order_the_waves_run_in(emulated_lib, order):
+    """HOSTWAVE_ORDER: the emulator starts a workgroup with its last lane and runs the ring backwards (reverse), or starts with a wave
+    drawn from the block number (rotate).  The kernels whose workgroups hold several waves -- k_hca_encode (frames x channels), the wide
+    transforms (a wave per four channels), k_adx_lane_encode -- and everything else of the encoder / ADX / WAV tests give the same bytes:
+    what one wave reads of another's LDS or global data is behind a barrier."""
+    env = _env(emulated_lib)
+    env["HOSTWAVE_ORDER"] = order
+    cmd = [sys.executable, "-m", "pytest", "tests/test_gpu_hca_encode.py", "tests/test_gpu_adx.py", "tests/test_gpu_wav.py", "tests/test_gpu_hca_decode.py", "-k",
+           "not fuzz and not exhaustive and not band_cost", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "900", "-n", "6"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and " failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 250, r.stdout[-1500:]
+
+
 def test_randomised_parity_soak_on_the_emulated_kernels(emulated_lib):
     """tools/parity_soak.py (random banks of WAVs through every batch job and the single-file calls, every output against the oracle,
     corrupted and forged streams among them) for twenty seconds on the emulated kernels: no mismatch."""
