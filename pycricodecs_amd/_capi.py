@@ -123,6 +123,10 @@ def _bind(path):
     if not os.path.exists(path):
         raise OSError("%s not built: run `python -m pycricodecs_amd.build` (hipcc, gfx950)" % path)
     L = C.CDLL(path)
+    if hasattr(L, "hostwave_divergent_completions") and os.environ.get("CRI_TEST_HOSTWAVE") != "1":
+        # tests/hostwave builds the same sources for the CPU under a wave64 emulator, under the same file name, for the parity tests:
+        # never a way to run the product (CRICODECS_LIB_DIR pointing there by accident must not turn into a silent CPU path)
+        raise OSError("%s is the emulated TEST build of the library (tests/hostwave), not the HIP library: refusing to use it outside the test suite" % path)
     L.cri_build_id.argtypes = []
     L.cri_build_id.restype = C.c_char_p
     u8p, u64p, i32p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)

@@ -79,6 +79,14 @@ def test_emulated_library_is_the_trees_sources(emulated_lib):
     assert declared and declared <= exported, sorted(declared - exported)
 
 
+def test_the_package_refuses_the_emulated_library_outside_the_test_suite(emulated_lib):
+    """CRICODECS_LIB_DIR pointing at tests/hostwave/lib without CRI_TEST_HOSTWAVE=1 is an error, not a CPU path."""
+    env = _env(emulated_lib)
+    env.pop("CRI_TEST_HOSTWAVE")
+    r = subprocess.run([sys.executable, "-c", "from pycricodecs_amd import _capi; _capi.lib()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "emulated TEST build" in r.stderr, r.stderr[-1500:]
+
+
 def test_gpu_parity_suite_on_the_emulated_kernels(emulated_lib):
     """Every `-m gpu` test of tests/ (test_gpu_{adx,hca_decode,hca_encode,wav,boundary,containers}.py, test_acb_audio.py, test_build_id.py)
     except the handful that need the real runtime: all pass on the emulated kernels -- the same assertions, oracle and golden vectors the
