@@ -98,13 +98,14 @@ def main():
     ap.add_argument("--waves-per-cu", type=int, default=16)
     ap.add_argument("--lib-dir", default=None, help="a census build of the library (default: this tree's, tests/hostwave/lib_traffic)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--data", default="tonal", choices=["tonal", "sparse", "noise", "mixed", "sfx"])
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
         trace = os.path.join(td, "trace.bin")
-        units, launches, _lib = T.run_census("hca_decode", args.streams, args.seconds, trace=trace, lib_dir=args.lib_dir)
+        units, launches, _lib = T.run_census("hca_decode", args.streams, args.seconds, trace=trace, lib_dir=args.lib_dir, family=args.data)
         tr = read_trace(trace)
     names = {l["launch"]: (T.kernel_class(l["kernel"]), l["block"]) for l in launches}
-    out = {"workload": "hca_decode", "streams": args.streams, "seconds": args.seconds, "frames": units, "model": "one XCD: 32 CUs x %d waves, 4 MiB 16-way LRU L2, no L1, equal progress" % args.waves_per_cu, "kernels": {}}
+    out = {"workload": "hca_decode", "data": args.data, "streams": args.streams, "seconds": args.seconds, "frames": units, "model": "one XCD: 32 CUs x %d waves, 4 MiB 16-way LRU L2, no L1, equal progress" % args.waves_per_cu, "kernels": {}}
     print("hca_decode: %d streams x %.0f s = %d frames; bytes per frame through the modelled L2" % (args.streams, args.seconds, units))
     for launch in sorted(tr):
         name, threads = names.get(launch, ("?", 64))

@@ -37,8 +37,12 @@ import numpy as np, oracle_lib as O
 from pycricodecs_amd import synth
 from pycricodecs_amd.batch import Job
 KEY = 0xCF222F1FE0748978
-n, secs, wl, ch, q, v3 = %(streams)d, %(seconds)f, %(workload)r, %(channels)d, %(quality)d, %(v3)d
-wavs = [synth.wav(500 + i, int(48000 * secs), ch, 48000) for i in range(n)]
+n, secs, wl, ch, q, v3, fam = %(streams)d, %(seconds)f, %(workload)r, %(channels)d, %(quality)d, %(v3)d, %(family)r
+if fam == "tonal":
+    wavs = [synth.wav(500 + i, int(48000 * secs), ch, 48000) for i in range(n)]
+else:                                          # bench.py's other signal families (sparse: int16 lines; noise; mixed; sfx)
+    import bench
+    wavs = [bench.family_wav(500 + i, secs, fam, ch=ch) for i in range(n)]
 def run(job):
     bufs = job.alloc("cpu"); job.run(*bufs)
     st = bufs[3].numpy()[:job.n]
@@ -71,7 +75,7 @@ else:
 '''
 
 
-def run_census(workload, streams, seconds, channels=2, quality=1, v3=0, adx_mapping="auto", trace=None, lib_dir=None):
+def run_census(workload, streams, seconds, channels=2, quality=1, v3=0, adx_mapping="auto", trace=None, lib_dir=None, family="tonal"):
     if not lib_dir:
         subprocess.run([sys.executable, os.path.join(HW, "build.py"), "--traffic"], check=True, stdout=subprocess.DEVNULL)
     lib = lib_dir or os.path.join(HW, "lib_traffic")
@@ -81,7 +85,7 @@ def run_census(workload, streams, seconds, channels=2, quality=1, v3=0, adx_mapp
         if trace:                                              # every workgroup's memory instructions in order, for tools/l2_replay.py
             env["HOSTWAVE_TRACE_OUT"] = trace
         root = os.path.abspath(os.path.join(lib, "..", "..", "..")) if lib_dir else ROOT      # (a census build of ANOTHER tree, e.g. round 5's decoder: its own package and build id)
-        r = subprocess.run([sys.executable, "-c", WORKLOAD % dict(root=root, streams=streams, seconds=seconds, workload=workload, channels=channels, quality=quality, v3=v3, adx_mapping=adx_mapping)], env=env, capture_output=True, text=True, cwd=root)
+        r = subprocess.run([sys.executable, "-c", WORKLOAD % dict(root=root, streams=streams, seconds=seconds, workload=workload, channels=channels, quality=quality, v3=v3, adx_mapping=adx_mapping, family=family)], env=env, capture_output=True, text=True, cwd=root)
         if r.returncode:
             raise SystemExit(r.stdout[-2000:] + r.stderr[-4000:])
         units = int(re.search(r"UNITS (\d+)", r.stdout).group(1))
@@ -118,10 +122,11 @@ def main():
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--quality", type=int, default=1, help="HCA quality 0..4 (1 = High, the headline)")
     ap.add_argument("--v3", action="store_true", help="hca_decode: the streams re-headed as v3.0 with min_resolution 0 (noise fill)")
+    ap.add_argument("--data", default="tonal", choices=["tonal", "sparse", "noise", "mixed", "sfx"], help="bench.py's signal families (sparse: int16 lines)")
     ap.add_argument("--adx-mapping", default="auto", choices=["auto", "chain", "file", "seg", "lane", "wave"], help="adx_roundtrip: force the planner's mapping (the lane-per-segment kernels of large batches on a small one)")
     ap.add_argument("--min-share", type=float, default=0.02, help="source lines below this share of a kernel's line bytes are folded into 'other'")
     args = ap.parse_args()
-    units, launches, lib = run_census(args.workload, args.streams, args.seconds, args.channels, args.quality, int(args.v3), args.adx_mapping)
+    units, launches, lib = run_census(args.workload, args.streams, args.seconds, args.channels, args.quality, int(args.v3), args.adx_mapping, family=args.data)
     sym = symbolize(lib, {s["site"] for l in launches for s in l["sites"]})
     kernels = collections.OrderedDict()
     for l in launches:
