@@ -51,6 +51,7 @@ hw_switch:
 
 namespace hw {
 thread_local Lane* cur = nullptr;
+thread_local bool nt_store_now = false;
 
 static const size_t STACK_BYTES = 1u << 20;        // per lane (virtual; touched pages only)
 static const uint32_t MAX_LANES = 1024;
@@ -454,7 +455,7 @@ uint32_t ds_swizzle(uint32_t v, uint32_t pattern, uint32_t site) {
 #include <unordered_set>
 #include <dlfcn.h>
 namespace hw {
-struct WaveInstr { uint32_t useful = 0; bool write = false; uint32_t seq = 0; uint32_t wave = 0; std::vector<uint64_t> sectors; };      // 32-byte sector numbers touched; seq: order of first touch inside the workgroup
+struct WaveInstr { uint32_t useful = 0; bool write = false; bool nt = false; uint32_t seq = 0; uint32_t wave = 0; std::vector<uint64_t> sectors; };      // 32-byte sector numbers touched; seq: order of first touch inside the workgroup
 struct SiteTotal { uint64_t instrs = 0, useful = 0, line = 0, s64 = 0, s32 = 0; bool write = false; };
 struct LaneOcc {
     std::unordered_map<uintptr_t, uint32_t> n;
@@ -513,12 +514,13 @@ static inline void census_access(const void* addr, uint32_t size, bool write, ui
     if (w.sectors.empty()) { c.site_of[key] = site; w.seq = c.next_seq++; w.wave = l->wave->index; }
     w.useful += size;
     w.write = write;
+    w.nt = w.nt || nt_store_now;
     for (uint64_t s = (uintptr_t)a >> 5; s <= ((uintptr_t)a + size - 1) >> 5; s++) w.sectors.push_back(s);
 }
 
 // HOSTWAVE_TRACE_OUT: every workgroup's memory instructions in program order (per wave: the order of first touch), each with the
 // 128-byte lines it touches -- what tools/l2_replay.py interleaves over a model of one XCD's L2.  Binary records of uint64:
-//   [0xB10C, launch number, block number, n] then n x [wave << 56 | write << 48 | seq << 16 | n_lines, (line << 4 | sector mask)...]
+//   [0xB10C, launch number, block number, n] then n x [wave << 56 | (write | streaming << 1) << 48 | seq << 16 | n_lines, (line << 4 | sector mask)...]
 static void trace_block(Worker* k, Census& c) {
     std::vector<const WaveInstr*> order;
     order.reserve(c.live.size());
@@ -534,7 +536,7 @@ static void trace_block(Worker* k, Census& c) {
             if ((sct >> 2) != prev) { prev = sct >> 2; lines.push_back(prev << 4); }
             lines.back() |= 1ull << (sct & 3);
         }
-        rec.push_back(((uint64_t)w->wave << 56) | ((uint64_t)(w->write ? 1 : 0) << 48) | ((uint64_t)(w->seq & 0xFFFFFFFFu) << 16) | (lines.size() & 0xFFFF));
+        rec.push_back(((uint64_t)w->wave << 56) | ((uint64_t)(w->write ? (w->nt ? 3 : 1) : 0) << 48) | ((uint64_t)(w->seq & 0xFFFFFFFFu) << 16) | (lines.size() & 0xFFFF));
         rec.insert(rec.end(), lines.begin(), lines.end());
     }
     std::lock_guard<std::mutex> g(g_census_mu);

@@ -326,6 +326,10 @@ template <class T> static inline T atomicMax(T* p, T v) {
 }
 template <class T> static inline T atomicCAS(T* p, T cmp, T v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return cmp; }
 
+// streaming stores: the census build tells them apart (they do not allocate in the modelled L2: tools/l2_replay.py)
+namespace hw { extern thread_local bool nt_store_now; }
+#define __builtin_nontemporal_store(v, p) do { hw::nt_store_now = true; *(p) = (v); hw::nt_store_now = false; } while (0)
+
 // sources guard gfx950-only helpers (inline assembly by name) with __HIPCC__; here those are translated and wanted
 #ifndef __HIPCC__
 #define __HIPCC__ 1

@@ -5,7 +5,8 @@ the 128-byte lines it touches), interleaved the way a chip keeps them in flight 
 
 Model (deliberately small): one XCD = 32 CUs x `--waves-per-cu` resident waves (16 for the decode kernels: four per SIMD); workgroups are
 taken in launch order as slots free up; per round every resident workgroup issues its next memory instruction (equal progress); the
-L2 is 4 MiB of 128-byte lines, 16-way set associative, LRU, write-back with write-allocate-without-fetch; there is no L1 in front of
+L2 is 4 MiB of 128-byte lines, 16-way set associative, LRU, write-back with write-allocate-without-fetch (streaming stores -- the
+parse's quantised lines -- are written through without allocating); there is no L1 in front of
 it and no Infinity Cache behind it (FETCH_SIZE / WRITE_SIZE count what crosses between L2 and the fabric either way).  Read misses x 128 B
 = modelled fetch traffic, the dirty 32-byte sectors of evicted lines (+ what is dirty at the end) = modelled write traffic, both PER UNIT.
 
@@ -46,7 +47,7 @@ def read_trace(path):
         for _ in range(cnt):
             h = a[i]
             k = h & 0xFFFF
-            instrs.append(((h >> 48) & 1, tuple(a[i + 1:i + 1 + k])))
+            instrs.append(((h >> 48) & 3, tuple(a[i + 1:i + 1 + k])))
             i += 1 + k
         launches[launch][block] = instrs
     return {l: [b[k] for k in sorted(b)] for l, b in launches.items()}
@@ -72,6 +73,14 @@ def replay(blocks, slots):
             write, lines = instrs[st[1]]
             st[1] += 1
             nxt.append(st)
+            if write == 3:                                     # a streaming store (global_store ... nt): written through, nothing allocated
+                for lm in lines:
+                    req += 1
+                    wb += pop[lm & 15]
+                    d = sets[(lm >> 4) % SETS].pop(lm >> 4, None)
+                    if d:
+                        wb += pop[d & ~(lm & 15)]
+                continue
             for lm in lines:
                 ln, m = lm >> 4, (lm & 15) if write else 0
                 req += 1
